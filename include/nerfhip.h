@@ -1,0 +1,258 @@
+/*
+ * nerfhip.h -- C ABI of the MI355X-native NeRF render hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (metaverse3d2022/Nerf-Cuda) has no FFI layer: its boundary is the C++ class
+ * ngp::NerfRender (include/nerf-cuda/nerf_render.h:29-50) calling CUDA kernels
+ * and tiny-cuda-nn objects directly.  Every entry point below names the
+ * reference interface it replaces; the C++ class that mirrors ngp::NerfRender
+ * on top of this header lives in nerf-cuda_amd/host/nerf_render.h.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures: device memory is passed as
+ *     void* (a HIP device pointer), streams as void* (hipStream_t, NULL = the
+ *     context's own stream).
+ *   - every function returns an int status: 0 = NRF_OK, otherwise an
+ *     NRF_E_* code; nrf_last_error() returns a thread-local message.
+ *     No C++ exception crosses this boundary.
+ *   - one context per device; a context is used by one thread at a time.
+ *   - there is NO CPU fallback: if the HIP runtime finds no gfx950 device,
+ *     nrf_create fails with NRF_E_NODEVICE.
+ */
+#ifndef NERFHIP_H_
+#define NERFHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRF_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+  NRF_OK = 0,
+  NRF_E_INVALID = 1,     /* bad argument / null pointer / bad shape          */
+  NRF_E_UNSUPPORTED = 2, /* config the HIP path does not implement           */
+  NRF_E_NODEVICE = 3,    /* no usable gfx950 device                          */
+  NRF_E_HIP = 4,         /* a HIP runtime call failed                        */
+  NRF_E_STATE = 5,       /* call order violated (e.g. render before load)    */
+  NRF_E_PARAMS = 6       /* parameter count / density grid size mismatch:
+                            reference nerf_network.h:425-427,
+                            nerf_render.cu:467-469                           */
+};
+
+/* ---- enums mirrored from the reference's JSON vocabulary ---------------- */
+/* tcnn activation names, T/src/network.cu:41-60 */
+enum {
+  NRF_ACT_NONE = 0,
+  NRF_ACT_RELU = 1,
+  NRF_ACT_EXPONENTIAL = 2,
+  NRF_ACT_SIGMOID = 3,
+  NRF_ACT_SQUAREPLUS = 4,
+  NRF_ACT_SOFTPLUS = 5,
+  NRF_ACT_SINE = 6
+};
+/* direction encodings, T/src/encoding.cu:97-117 */
+enum {
+  NRF_DIR_SH = 0,        /* SphericalHarmonics, degree 1..8 (4 on the hot path) */
+  NRF_DIR_FREQUENCY = 1, /* Frequency, n_frequencies                            */
+  NRF_DIR_IDENTITY = 2
+};
+/* hash-grid flavours, T/include/tiny-cuda-nn/encodings/grid.h:1366-1367 */
+enum { NRF_GRID_HASH = 0, NRF_GRID_DENSE = 1, NRF_GRID_TILED = 2 };
+
+/* ---- model description ---------------------------------------------------
+ * Replaces: NerfRender::load_snapshot + reset_network + NerfNetwork ctor +
+ * NerfNetwork::deserialize (nerf_render.cu:431-473,111-184;
+ * nerf_network.h:95-144,424-443).  The caller has already parsed the
+ * msgpack snapshot; all pointers are HOST pointers and are copied.           */
+typedef struct nrf_model_desc {
+  uint32_t abi_version; /* = NRF_ABI_VERSION */
+
+  /* "encoding" block (position hash grid, 3-D input) */
+  uint32_t grid_type;             /* NRF_GRID_*                               */
+  uint32_t n_levels;              /* L, <= 16                                 */
+  uint32_t n_features_per_level;  /* F, only 2 on the HIP path                */
+  uint32_t log2_hashmap_size;     /* log2 T                                   */
+  uint32_t base_resolution;       /* Nmin                                     */
+  float per_level_scale;          /* b (already derived, nerf_render.cu:158)  */
+
+  /* "network" (density MLP) and "rgb_network" blocks */
+  uint32_t n_neurons;              /* 64 on the HIP path                      */
+  uint32_t density_hidden_layers;  /* n_hidden_layers of "network"            */
+  uint32_t density_activation;     /* hidden activation                       */
+  uint32_t density_output_activation;
+  uint32_t density_n_output;       /* 16 (nerf_network.h:120-122)             */
+  uint32_t sigma_activation;       /* nerf_network.h:125, default Exponential */
+  uint32_t rgb_hidden_layers;
+  uint32_t rgb_activation;
+  uint32_t rgb_output_activation;
+
+  /* "dir_encoding" block (Composite{SH|Frequency|Identity on 3 dims}) */
+  uint32_t dir_encoding;  /* NRF_DIR_*                                        */
+  uint32_t sh_degree;     /* for NRF_DIR_SH                                   */
+  uint32_t n_frequencies; /* for NRF_DIR_FREQUENCY                            */
+
+  /* "snapshot" block, nerf_render.cu:441-453 */
+  float aabb[6];
+  float bound;
+  float scale;
+  uint32_t cascade;           /* C */
+  uint32_t density_grid_size; /* H */
+  float mean_density;
+
+  /* fp32 parameters in the reference order (nerf_network.h:273-291):
+   * density MLP | rgb MLP | hash grid | (dir encoding: none).
+   * Each MLP: first [n_neurons x in] | hidden [n_neurons x n_neurons]... |
+   * last [16 x n_neurons], row-major [out][in], no biases.                   */
+  const float* params;
+  uint64_t n_params;
+  /* float density grid [C*H*H*H], index level*H^3 + x*H^2 + y*H + z          */
+  const float* density_grid;
+  uint64_t n_density_grid;
+} nrf_model_desc;
+
+/* Level geometry derived on the host exactly as the reference does
+ * (grid.h:899-931 ctor, grid.h:186-190 kernel).                              */
+typedef struct nrf_level_table {
+  uint32_t n_levels;
+  uint32_t offset[17];     /* in entries (F values each); offset[L] = total   */
+  uint32_t resolution[16]; /* grid_resolution = ceil(scale)+1                 */
+  float scale[16];         /* exp2f(l*log2f(b))*Nmin - 1                      */
+} nrf_level_table;
+
+/* Render parameters.  The reference keeps these as private members without
+ * setters (nerf_render.h:55-78); defaults here equal those members.          */
+typedef struct nrf_options {
+  float bg_color;      /* 1      m_bg_color (int in the reference)            */
+  float min_near;      /* 0.2    m_min_near                                   */
+  float dt_gamma;      /* 1/128  m_dt_gamma                                   */
+  int32_t max_steps;   /* 1024   m_max_infer_steps                            */
+  float density_scale; /* 1      m_density_scale                              */
+  int32_t perturb;     /* 0      m_perturb (only 0 implemented)               */
+  /* Sharding of one frame over ranks: the frame is cut into 8x8-pixel tiles,
+   * tile id = ty*ceil(W/8)+tx, and tile id % shard_count == shard_index
+   * belongs to this context.  Replaces the pixel interleave
+   * p = NGPU*tid + gpu of render_utils.h:37.                                 */
+  int32_t shard_index; /* 0 */
+  int32_t shard_count; /* 1 */
+} nrf_options;
+
+/* One rendered frame (device memory owned by the context, valid until the
+ * next nrf_render on the same context).  Replaces ngp::Image
+ * (common.h:75-89) plus the float buffers image/depth/weight_sum
+ * (nerf_render.cu:200-202).                                                  */
+typedef struct nrf_frame {
+  int32_t width, height;
+  int32_t n_tiles;      /* tiles rendered by this shard                       */
+  void* rgba;           /* device float [n_px][4]; rgb after background blend
+                           (render_utils.h:259-261), a = weight_sum           */
+  void* depth;          /* device float [n_px] (render_utils.h:262-263)       */
+  /* layout: shard_count==1 -> row-major [H][W]; otherwise tile-major
+   * [n_tiles][64] in ascending tile id, see nrf_untile.                      */
+  int32_t tile_major;
+} nrf_frame;
+
+typedef struct nrf_stats {
+  uint64_t n_rays;      /* rays generated by this shard                       */
+  uint64_t n_samples;   /* march-emitted samples evaluated by the network     */
+  uint64_t n_rounds;    /* sum over wave tiles of march/eval/composite rounds */
+  float render_ms;      /* device time of the last nrf_render (hipEvents)     */
+} nrf_stats;
+
+typedef struct nrf_context nrf_context;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+const char* nrf_last_error(void);
+int nrf_abi_version(void);
+/* NerfRender::NerfRender(), nerf_render.cu:46-57 (per-GPU stream creation)   */
+int nrf_create(int device, nrf_context** out);
+int nrf_destroy(nrf_context* ctx);
+void nrf_default_options(nrf_options* o);
+
+/* host-only helper: level geometry + parameter count for a description.
+ * n_params check of nerf_network.h:425.                                      */
+int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t);
+int nrf_expected_n_params(const nrf_model_desc* d, uint64_t* n);
+/* host-only: the reference's automatic per_level_scale, nerf_render.cu:158-165:
+ * fp32 exp(log(2048*bound/base_resolution)/(n_levels-1)).                    */
+int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t n_levels,
+                                float* out);
+
+/* load_snapshot + reset_network + deserialize                                */
+int nrf_load_model(nrf_context* ctx, const nrf_model_desc* d);
+/* NerfRender::set_resolution, nerf_render.cu:186-236 (idempotent here)       */
+int nrf_set_resolution(nrf_context* ctx, int width, int height);
+int nrf_set_options(nrf_context* ctx, const nrf_options* o);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* NerfRender::render_frame, nerf_render.cu:238-367.
+ * cam = {fl_x, fl_y, cx, cy} (common.h:68-74); pose = row-major 4x4
+ * camera-to-world in the NeRF/Blender convention (converted with
+ * nerf_matrix_to_ngp, render_utils.h:68-77).  Asynchronous on `stream`
+ * unless stream==NULL, in which case the call returns after completion.      */
+int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
+               void* stream, nrf_frame* out);
+/* Binds caller-owned device buffers (e.g. a render buffer's RGBA plane or a
+ * torch tensor) as the target of subsequent nrf_render calls: rgba float
+ * [n_px][4], depth float [n_px], n_px as nrf_frame describes.  NULL, NULL
+ * returns to the context's own buffers.  Replaces the host round trip
+ * render_frame -> host_to_accumulate_buffer of main.cu:87-129.               */
+int nrf_bind_output(nrf_context* ctx, void* rgba, void* depth);
+/* Host copy + quantisation, nerf_render.cu:345-359 (saturating, row-major). */
+int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
+/* Host copy of the float buffers (row-major; single-shard frames only).      */
+int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
+/* Rearranges gathered tile-major shards ([shard][n_tiles_max][64][C] floats,
+ * as produced by an all-gather of every rank's nrf_frame buffer) into a
+ * row-major [H][W][C] image on the device.  Replaces the de-interleave loop
+ * nerf_render.cu:352-359.                                                    */
+int nrf_untile(nrf_context* ctx, const void* gathered, int shard_count,
+               int tiles_per_shard, int channels, void* out_rowmajor,
+               void* stream);
+int nrf_tiles_per_shard(int width, int height, int shard_count, int* n);
+int nrf_get_stats(nrf_context* ctx, nrf_stats* s);
+
+/* ---- stage entry points (unit parity against the oracle) -----------------
+ * All pointers are DEVICE pointers, n = number of samples / rays.            */
+/* kernel_grid<half,3,2>, grid.h:139-268.  pos01 [n][3] in [0,1];
+ * out fp16 [n][2L]                                                           */
+int nrf_encode_grid(nrf_context* ctx, const void* pos01, uint32_t n, void* out_f16,
+                    void* stream);
+/* kernel_sh / frequency_encoding.  dir01 [n][3] in [0,1]; out fp16 [n][16]   */
+int nrf_encode_dir(nrf_context* ctx, const void* dir01, uint32_t n, void* out_f16,
+                   void* stream);
+/* kernel_mlp_fused x2 + extract_density (nerf_network.h:148-196) on
+ * pre-encoded inputs: feat fp16 [n][32], dirfeat fp16 [n][16] ->
+ * out fp16 [n][4] = (r,g,b,sigma)                                            */
+int nrf_mlp_forward(nrf_context* ctx, const void* feat_f16, const void* dirfeat_f16,
+                    uint32_t n, void* out_f16, void* stream);
+/* Whole network on raw march output (world-space xyz in [-bound,bound], unit
+ * dirs), including the two affine maps nerf_render.cu:311-314 and
+ * decompose (render_utils.h:308-334): -> sigma f32 [n], rgb f32 [n][3]       */
+int nrf_network(nrf_context* ctx, const void* xyz, const void* dir, uint32_t n,
+                void* sigma_f32, void* rgb_f32, void* stream);
+/* set_rays_o/d + kernel_near_far_from_aabb for every pixel (row-major):
+ * rays_o [n][3], rays_d [n][3], nears [n], fars [n]                          */
+int nrf_generate_rays(nrf_context* ctx, const float cam[4], const float pose[16],
+                      void* rays_o, void* rays_d, void* nears, void* fars,
+                      void* stream);
+/* kernel_march_rays (render_utils.h:524-655) for n rays with explicit start
+ * t: xyzs [n][n_step][3], dirs likewise, deltas [n][n_step][2]; unused slots
+ * are zero-filled (DESIGN.md deviation D-1).                                 */
+int nrf_march(nrf_context* ctx, const void* rays_o, const void* rays_d,
+              const void* rays_t, const void* fars, uint32_t n, uint32_t n_step,
+              void* xyzs, void* dirs, void* deltas, void* stream);
+/* kernel_composite_rays (render_utils.h:658-751): state [n][5] =
+ * (weight_sum, depth, r, g, b) updated in place; rays_t in/out               */
+int nrf_composite(nrf_context* ctx, const void* sigmas, const void* rgbs,
+                  const void* deltas, uint32_t n, uint32_t n_step, void* rays_t,
+                  void* state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFHIP_H_ */

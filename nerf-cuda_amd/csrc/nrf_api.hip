@@ -1,0 +1,627 @@
+// nrf_api.hip -- the C ABI of include/nerfhip.h on top of the gfx950 kernels.
+//
+// Host-side mirror of what ngp::NerfRender does around its kernels
+// (R/src/nerf_render.cu): model upload (load_snapshot + reset_network +
+// NerfNetwork::deserialize), buffer allocation (set_resolution) and one
+// kernel launch per frame (render_frame).  No CPU compute path exists here:
+// without a gfx950 device nrf_create fails.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "nrf_device.h"
+#include "nrf_launch.h"
+
+using namespace nrf;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return NRF_E_HIP;
+}
+#define HIP_TRY(expr)                            \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) return hip_fail(_e, #expr); \
+  } while (0)
+
+inline uint32_t next_multiple(uint32_t v, uint32_t d) { return (v + d - 1) / d * d; }
+
+// T/include/tiny-cuda-nn/encodings/grid.h:899-931 (ctor) and :186-190 (kernel): the level geometry is
+// computed once, on the host, with libm's exp2f/log2f, and handed to every kernel as constants.
+int compute_level_table(const nrf_model_desc& d, nrf_level_table& t) {
+  if (d.n_levels == 0 || d.n_levels > 16) return fail(NRF_E_UNSUPPORTED, "n_levels must be 1..16");
+  if (d.log2_hashmap_size > 31) return fail(NRF_E_INVALID, "log2_hashmap_size must be <= 31");
+  std::memset(&t, 0, sizeof(t));
+  t.n_levels = d.n_levels;
+  const float log2_pls = std::log2(d.per_level_scale);
+  uint32_t offset = 0;
+  for (uint32_t i = 0; i < d.n_levels; ++i) {
+    const float scale = exp2f((float)i * log2_pls) * (float)d.base_resolution - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const uint32_t max_params = std::numeric_limits<uint32_t>::max() / 2;
+    uint32_t params = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+    params = next_multiple(params, 8u);
+    if (d.grid_type == NRF_GRID_TILED) {
+      const uint32_t b3 = d.base_resolution * d.base_resolution * d.base_resolution;
+      params = params < b3 ? params : b3;
+    } else if (d.grid_type == NRF_GRID_HASH) {
+      const uint32_t T = 1u << d.log2_hashmap_size;
+      params = params < T ? params : T;
+    } else if (d.grid_type != NRF_GRID_DENSE) {
+      return fail(NRF_E_INVALID, "GridEncoding: invalid grid type");
+    }
+    t.offset[i] = offset;
+    t.resolution[i] = res;
+    t.scale[i] = scale;
+    offset += params;
+  }
+  t.offset[d.n_levels] = offset;
+  return NRF_OK;
+}
+
+uint32_t dir_raw_width(const nrf_model_desc& d) {
+  switch (d.dir_encoding) {
+    case NRF_DIR_SH: return d.sh_degree * d.sh_degree;
+    case NRF_DIR_FREQUENCY: return 6 * d.n_frequencies;
+    case NRF_DIR_IDENTITY: return 3;
+    default: return 0;
+  }
+}
+
+// n_params of NerfNetwork (nerf_network.h:273-291): density MLP | rgb MLP | grid | dir enc (0)
+int expected_params(const nrf_model_desc& d, const nrf_level_table& t, uint64_t& n) {
+  const uint32_t raw = dir_raw_width(d);
+  if (raw == 0) return fail(NRF_E_UNSUPPORTED, "unknown dir encoding");
+  const uint64_t Wn = d.n_neurons;
+  const uint64_t feat = next_multiple(d.n_levels * d.n_features_per_level, 16u);
+  const uint64_t rgb_in = next_multiple(next_multiple(raw, 16u) + 16u, 16u);
+  if (d.density_hidden_layers < 1 || d.rgb_hidden_layers < 1)
+    return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer");  // fully_fused_mlp.cu:654
+  auto mlp = [&](uint64_t in, uint64_t hidden) { return in * Wn + (hidden - 1) * Wn * Wn + Wn * 16; };
+  n = mlp(feat, d.density_hidden_layers) + mlp(rgb_in, d.rgb_hidden_layers) +
+      (uint64_t)t.offset[d.n_levels] * d.n_features_per_level;
+  return NRF_OK;
+}
+
+// fp16 weight fragments for v_mfma_f32_16x16x32_f16 (see nrf_device.h mlp_tiles):
+// fragment f, lane l, element j  =  W[16m + (l&15)][kmap(s, l>>4, j)]
+//   input layers   kmap(g,j) = 8g + j                      (density: hash features)
+//                  kmap(g,j) = j<4 ? 4g+j : 16+4g+(j-4)    (rgb: [density out | dir enc])
+//   hidden->next   kmap(s,g,j) = 16(2s + (j>>2)) + 4g + (j&3)   (a D fragment re-used in-lane as B)
+void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& frags) {
+  frags.assign((size_t)N_FRAGS * 64 * 8, (_Float16)0.0f);
+  const _Float16* D0 = w16.data();              // [64][32]
+  const _Float16* D1 = D0 + 64 * 32;            // [16][64]
+  const _Float16* R0 = D1 + 16 * 64;            // [64][32]
+  const _Float16* R1 = R0 + 64 * 32;            // [64][64]
+  const _Float16* R2 = R1 + 64 * 64;            // [16][64]
+  auto khid = [](int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); };
+  auto put = [&](int f, const _Float16* Wm, int in, int m, auto kmap) {
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 8; ++j) frags[((size_t)f * 64 + l) * 8 + j] = Wm[(size_t)(16 * m + (l & 15)) * in + kmap(l >> 4, j)];
+  };
+  for (int m = 0; m < 4; ++m) put(FRAG_D0 + m, D0, 32, m, [](int g, int j) { return 8 * g + j; });
+  for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+  for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int m = 0; m < 4; ++m)
+    for (int s = 0; s < 2; ++s) put(FRAG_R1 + 2 * m + s, R1, 64, m, [&](int g, int j) { return khid(s, g, j); });
+  for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+}
+
+// R/include/nerf-cuda/render_utils.h:68-77
+void nerf_matrix_to_ngp(const float p[16], float s, float R[9], float org[3]) {
+  const int rows[3] = {1, 2, 0};
+  for (int r = 0; r < 3; ++r) {
+    const float* src = p + 4 * rows[r];
+    R[3 * r + 0] = src[0];
+    R[3 * r + 1] = -src[1];
+    R[3 * r + 2] = -src[2];
+    org[r] = src[3] * s + 0.0f;
+  }
+}
+
+}  // namespace
+
+struct nrf_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool model_loaded = false;
+  nrf_model_desc desc{};
+  nrf_level_table lv{};
+  DevModel dm{};
+  void* d_grid = nullptr;
+  void* d_occ = nullptr;
+  void* d_wfrag = nullptr;
+  void* d_lv = nullptr;
+  nrf_options opt{};
+  int W = 0, H = 0;
+  int n_local_tiles = 0;
+  size_t n_out_px = 0;  // pixels in the frame buffers
+  void* d_rgba = nullptr;
+  void* d_depth = nullptr;
+  void* d_counters = nullptr;
+  void* d_rgb8 = nullptr;
+  void* d_depth8 = nullptr;
+  void* bound_rgba = nullptr;  // caller-owned targets (nrf_bind_output)
+  void* bound_depth = nullptr;
+  void* last_rgba = nullptr;
+  void* last_depth = nullptr;
+  bool rendered = false;
+  hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+int set_device(nrf_context* c) {
+  HIP_TRY(hipSetDevice(c->device));
+  return NRF_OK;
+}
+
+void free_model(nrf_context* c) {
+  if (c->d_grid) (void)hipFree(c->d_grid);
+  if (c->d_occ) (void)hipFree(c->d_occ);
+  if (c->d_wfrag) (void)hipFree(c->d_wfrag);
+  if (c->d_lv) (void)hipFree(c->d_lv);
+  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = nullptr;
+  c->model_loaded = false;
+}
+
+void free_frame(nrf_context* c) {
+  if (c->d_rgba) (void)hipFree(c->d_rgba);
+  if (c->d_depth) (void)hipFree(c->d_depth);
+  if (c->d_rgb8) (void)hipFree(c->d_rgb8);
+  if (c->d_depth8) (void)hipFree(c->d_depth8);
+  c->d_rgba = c->d_depth = c->d_rgb8 = c->d_depth8 = nullptr;
+  c->n_out_px = 0;
+  c->rendered = false;
+}
+
+int local_tiles(int W, int H, int shard_index, int shard_count) {
+  const int total = ((W + 7) / 8) * ((H + 7) / 8);
+  if (shard_index >= total) return 0;
+  return (total - shard_index + shard_count - 1) / shard_count;
+}
+
+int alloc_frame(nrf_context* c) {
+  if (c->W <= 0 || c->H <= 0) return NRF_OK;
+  const bool tiled = c->opt.shard_count > 1;
+  c->n_local_tiles = local_tiles(c->W, c->H, c->opt.shard_index, c->opt.shard_count);
+  int tps = 0;
+  nrf_tiles_per_shard(c->W, c->H, c->opt.shard_count, &tps);
+  const size_t need = tiled ? (size_t)tps * 64 : (size_t)c->W * c->H;
+  if (need == c->n_out_px && c->d_rgba) return NRF_OK;
+  free_frame(c);
+  HIP_TRY(hipMalloc(&c->d_rgba, need * 16));
+  HIP_TRY(hipMalloc(&c->d_depth, need * 4));
+  HIP_TRY(hipMemset(c->d_rgba, 0, need * 16));
+  HIP_TRY(hipMemset(c->d_depth, 0, need * 4));
+  c->n_out_px = need;
+  return NRF_OK;
+}
+
+int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], FrameParams& P) {
+  std::memset(&P, 0, sizeof(P));
+  nerf_matrix_to_ngp(pose, c->desc.scale, P.R, P.org);
+  for (int i = 0; i < 4; ++i) P.cam[i] = cam[i];
+  P.W = c->W;
+  P.H = c->H;
+  P.tiles_x = (c->W + 7) / 8;
+  P.tiles_y = (c->H + 7) / 8;
+  P.shard_index = c->opt.shard_index;
+  P.shard_count = c->opt.shard_count;
+  P.n_local_tiles = c->n_local_tiles;
+  P.tile_major = c->opt.shard_count > 1;
+  P.bg_color = c->opt.bg_color;
+  P.min_near = c->opt.min_near;
+  P.dt_gamma = c->opt.dt_gamma;
+  P.density_scale = c->opt.density_scale;
+  P.max_steps = c->opt.max_steps;
+  return NRF_OK;
+}
+
+int need_model(nrf_context* c) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if (!c->model_loaded) return fail(NRF_E_STATE, "no model loaded (call nrf_load_model first)");
+  return set_device(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nrf_last_error(void) { return g_err.c_str(); }
+int nrf_abi_version(void) { return NRF_ABI_VERSION; }
+
+void nrf_default_options(nrf_options* o) {
+  if (!o) return;
+  o->bg_color = 1.0f;
+  o->min_near = 0.2f;
+  o->dt_gamma = 1.0f / 128.0f;
+  o->max_steps = 1024;
+  o->density_scale = 1.0f;
+  o->perturb = 0;
+  o->shard_index = 0;
+  o->shard_count = 1;
+}
+
+int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t) {
+  if (!d || !t) return fail(NRF_E_INVALID, "null argument");
+  return compute_level_table(*d, *t);
+}
+
+int nrf_expected_n_params(const nrf_model_desc* d, uint64_t* n) {
+  if (!d || !n) return fail(NRF_E_INVALID, "null argument");
+  nrf_level_table t;
+  int rc = compute_level_table(*d, t);
+  if (rc) return rc;
+  return expected_params(*d, t, *n);
+}
+
+int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t n_levels, float* out) {
+  if (!out || n_levels < 2 || base_resolution == 0) return fail(NRF_E_INVALID, "bad argument");
+  const float desired_resolution = 2048.0f;  // R/src/nerf_render.cu:154-165
+  *out = std::exp(std::log(desired_resolution * bound / (float)base_resolution) / (float)(n_levels - 1));
+  return NRF_OK;
+}
+
+int nrf_tiles_per_shard(int width, int height, int shard_count, int* n) {
+  if (!n || width <= 0 || height <= 0 || shard_count <= 0) return fail(NRF_E_INVALID, "bad argument");
+  const int total = ((width + 7) / 8) * ((height + 7) / 8);
+  *n = (total + shard_count - 1) / shard_count;
+  return NRF_OK;
+}
+
+int nrf_create(int device, nrf_context** out) {
+  if (!out) return fail(NRF_E_INVALID, "null argument");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(NRF_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(NRF_E_NODEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NRF_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  nrf_context* c = new nrf_context;
+  c->device = device;
+  nrf_default_options(&c->opt);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc(&c->d_counters, 16));
+  HIP_TRY(hipMemset(c->d_counters, 0, 16));
+  *out = c;
+  return NRF_OK;
+}
+
+int nrf_destroy(nrf_context* c) {
+  if (!c) return NRF_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  free_model(c);
+  free_frame(c);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return NRF_OK;
+}
+
+int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
+  if (!c || !d || !d->params || !d->density_grid) return fail(NRF_E_INVALID, "null argument");
+  if (d->abi_version != NRF_ABI_VERSION) return fail(NRF_E_INVALID, "abi_version mismatch");
+  int rc = set_device(c);
+  if (rc) return rc;
+  // what the HIP path implements (everything else is refused loudly, never emulated on the CPU)
+  if (d->n_features_per_level != 2) return fail(NRF_E_UNSUPPORTED, "HIP path: n_features_per_level must be 2");
+  if (d->n_levels != 16) return fail(NRF_E_UNSUPPORTED, "HIP path: n_levels must be 16");
+  if (d->n_neurons != 64) return fail(NRF_E_UNSUPPORTED, "HIP path: n_neurons must be 64");
+  if (d->density_hidden_layers != 1 || d->rgb_hidden_layers != 2)
+    return fail(NRF_E_UNSUPPORTED, "HIP path: density MLP must have 1 and rgb MLP 2 hidden layers");
+  if (d->density_n_output != 16) return fail(NRF_E_UNSUPPORTED, "HIP path: density n_output_dims must be 16");
+  const uint32_t raw = dir_raw_width(*d);
+  if (raw == 0 || raw > 16) return fail(NRF_E_UNSUPPORTED, "HIP path: direction encoding must fit 16 outputs");
+  if (d->dir_encoding == NRF_DIR_SH && (d->sh_degree < 1 || d->sh_degree > 4))
+    return fail(NRF_E_UNSUPPORTED, "HIP path: SH degree must be 1..4");
+  if (d->density_grid_size < 2 || d->density_grid_size >= (1u << 24) || d->cascade < 1)
+    return fail(NRF_E_INVALID, "bad density grid geometry");
+  if (!(d->bound > 0.0f)) return fail(NRF_E_INVALID, "bound must be positive");
+
+  nrf_level_table lv;
+  rc = compute_level_table(*d, lv);
+  if (rc) return rc;
+  uint64_t expect = 0;
+  rc = expected_params(*d, lv, expect);
+  if (rc) return rc;
+  if (d->n_params != expect)  // R/include/nerf-cuda/nerf_network.h:425-427
+    return fail(NRF_E_PARAMS, "Can't set params because number of parameters and model size do not match with each other.");
+  const uint64_t Hh = d->density_grid_size;
+  const uint64_t cells = Hh * Hh * Hh * d->cascade;
+  if (d->n_density_grid != cells)  // R/src/nerf_render.cu:467-469
+    return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
+  if (cells >= (1ull << 32)) return fail(NRF_E_UNSUPPORTED, "density grid too large");
+
+  free_model(c);
+  // fp32 -> fp16 cast of every parameter (nerf_network.h:434-436), order: density MLP | rgb MLP | grid
+  const size_t n_mlp = 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64;
+  std::vector<_Float16> w16(n_mlp);
+  for (size_t i = 0; i < n_mlp; ++i) w16[i] = (_Float16)d->params[i];
+  std::vector<_Float16> frags;
+  pack_fragments(w16, frags);
+  const size_t n_grid = (size_t)lv.offset[16] * 2;
+  std::vector<_Float16> grid16(n_grid);
+  const float* gp = d->params + n_mlp;
+  for (size_t i = 0; i < n_grid; ++i) grid16[i] = (_Float16)gp[i];
+  // occupancy bitfield: grid[cell] > min(0.01, mean_density) (render_utils.h:560,619), decided once
+  const float thresh = fminf(0.01f, d->mean_density);
+  std::vector<uint32_t> occ((cells + 31) / 32 + 1, 0u);
+  for (uint64_t i = 0; i < cells; ++i)
+    if (d->density_grid[i] > thresh) occ[i >> 5] |= 1u << (i & 31);
+
+  std::vector<LevelParams> lp(16);
+  for (uint32_t l = 0; l < 16; ++l) {
+    LevelParams& L = lp[l];
+    std::memset(&L, 0, sizeof(L));
+    L.scale = lv.scale[l];
+    L.res = lv.resolution[l];
+    L.offset = lv.offset[l];
+    L.size = lv.offset[l + 1] - lv.offset[l];
+    L.hashed = d->grid_type == NRF_GRID_HASH;
+    // replay grid_index's stride loop (grid.h:106-114) in uint32 to classify the level
+    uint32_t stride = 1;
+    int dims = 0;
+    for (; dims < 3 && stride <= L.size; ++dims) stride *= L.res;
+    const bool uses_hash = L.hashed && L.size < stride;
+    if (uses_hash && (L.size & (L.size - 1)) == 0) L.mode = LV_HASH_POW2;
+    else if (!uses_hash && dims == 3 && L.res >= 2 && (uint64_t)L.res * L.res * L.res <= L.size) L.mode = LV_DENSE;
+    else L.mode = LV_GENERIC;
+  }
+
+  HIP_TRY(hipMalloc(&c->d_grid, n_grid * 2));
+  HIP_TRY(hipMemcpy(c->d_grid, grid16.data(), n_grid * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&c->d_occ, occ.size() * 4));
+  HIP_TRY(hipMemcpy(c->d_occ, occ.data(), occ.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&c->d_wfrag, frags.size() * 2));
+  HIP_TRY(hipMemcpy(c->d_wfrag, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&c->d_lv, lp.size() * sizeof(LevelParams)));
+  HIP_TRY(hipMemcpy(c->d_lv, lp.data(), lp.size() * sizeof(LevelParams), hipMemcpyHostToDevice));
+
+  c->desc = *d;
+  c->desc.params = nullptr;
+  c->desc.density_grid = nullptr;
+  c->lv = lv;
+  DevModel& M = c->dm;
+  std::memset(&M, 0, sizeof(M));
+  M.grid = (const uint32_t*)c->d_grid;
+  M.occ_bits = (const uint32_t*)c->d_occ;
+  M.wfrag = (const uint4*)c->d_wfrag;
+  M.lv = (const LevelParams*)c->d_lv;
+  for (int i = 0; i < 6; ++i) M.aabb[i] = d->aabb[i];
+  M.bound = d->bound;
+  M.pos_w = (float)(1.0 / (2 * (double)d->bound));
+  M.cascade = d->cascade;
+  M.H = d->density_grid_size;
+  M.n_levels = d->n_levels;
+  M.dir_encoding = d->dir_encoding;
+  M.sh_degree = d->sh_degree;
+  M.n_frequencies = d->n_frequencies;
+  M.density_activation = d->density_activation;
+  M.density_output_activation = d->density_output_activation;
+  M.sigma_activation = d->sigma_activation;
+  M.rgb_activation = d->rgb_activation;
+  M.rgb_output_activation = d->rgb_output_activation;
+  c->model_loaded = true;
+  return NRF_OK;
+}
+
+int nrf_set_resolution(nrf_context* c, int width, int height) {
+  if (!c || width <= 0 || height <= 0) return fail(NRF_E_INVALID, "bad resolution");
+  int rc = set_device(c);
+  if (rc) return rc;
+  c->W = width;
+  c->H = height;
+  return alloc_frame(c);
+}
+
+int nrf_set_options(nrf_context* c, const nrf_options* o) {
+  if (!c || !o) return fail(NRF_E_INVALID, "null argument");
+  if (o->shard_count < 1 || o->shard_index < 0 || o->shard_index >= o->shard_count)
+    return fail(NRF_E_INVALID, "bad shard");
+  if (o->perturb) return fail(NRF_E_UNSUPPORTED, "perturb is not implemented (m_perturb=false in the reference)");
+  if (o->max_steps < 1) return fail(NRF_E_INVALID, "max_steps must be >= 1");
+  int rc = set_device(c);
+  if (rc) return rc;
+  c->opt = *o;
+  return alloc_frame(c);
+}
+
+int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* stream, nrf_frame* out) {
+  int rc = need_model(c);
+  if (rc) return rc;
+  if (!cam || !pose) return fail(NRF_E_INVALID, "null argument");
+  if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
+  FrameParams P;
+  fill_frame_params(c, cam, pose, P);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16, st));
+  HIP_TRY(hipEventRecord(c->ev0, st));
+  void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
+  void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
+  HIP_TRY(launch_render(c->dm, P, rgba, depth, c->d_counters, st));
+  c->last_rgba = rgba;
+  c->last_depth = depth;
+  HIP_TRY(hipEventRecord(c->ev1, st));
+  c->last_stream = st;
+  c->rendered = true;
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  if (out) {
+    out->width = c->W;
+    out->height = c->H;
+    out->n_tiles = c->n_local_tiles;
+    out->rgba = rgba;
+    out->depth = depth;
+    out->tile_major = P.tile_major;
+  }
+  return NRF_OK;
+}
+
+int nrf_bind_output(nrf_context* c, void* rgba, void* depth) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if ((rgba == nullptr) != (depth == nullptr)) return fail(NRF_E_INVALID, "bind both planes or neither");
+  c->bound_rgba = rgba;
+  c->bound_depth = depth;
+  return NRF_OK;
+}
+
+int nrf_get_stats(nrf_context* c, nrf_stats* s) {
+  if (!c || !s) return fail(NRF_E_INVALID, "null argument");
+  if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  int rc = set_device(c);
+  if (rc) return rc;
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  unsigned long long cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpy(cnt, c->d_counters, 16, hipMemcpyDeviceToHost));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  s->n_rays = (uint64_t)c->n_local_tiles * 64;
+  s->n_samples = cnt[0];
+  s->n_rounds = cnt[1];
+  s->render_ms = ms;
+  return NRF_OK;
+}
+
+int nrf_read_f32(nrf_context* c, float* rgba, float* depth) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_f32 needs a single-shard (row-major) frame");
+  int rc = set_device(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  const size_t n = (size_t)c->W * c->H;
+  if (rgba) HIP_TRY(hipMemcpy(rgba, c->last_rgba, n * 16, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(hipMemcpy(depth, c->last_depth, n * 4, hipMemcpyDeviceToHost));
+  return NRF_OK;
+}
+
+int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_u8 needs a single-shard (row-major) frame");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const size_t n = (size_t)c->W * c->H;
+  if (!c->d_rgb8) {
+    HIP_TRY(hipMalloc(&c->d_rgb8, n * 3));
+    HIP_TRY(hipMalloc(&c->d_depth8, n));
+  }
+  hipStream_t st = c->last_stream;
+  HIP_TRY(launch_quantize(c->last_rgba, c->last_depth, (int)n, c->d_rgb8, c->d_depth8, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (rgb) HIP_TRY(hipMemcpy(rgb, c->d_rgb8, n * 3, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(hipMemcpy(depth, c->d_depth8, n, hipMemcpyDeviceToHost));
+  return NRF_OK;
+}
+
+int nrf_untile(nrf_context* c, const void* gathered, int shard_count, int tiles_per_shard, int channels, void* out,
+               void* stream) {
+  if (!c || !gathered || !out || shard_count < 1 || tiles_per_shard < 1 || channels < 1)
+    return fail(NRF_E_INVALID, "bad argument");
+  if (c->W <= 0) return fail(NRF_E_STATE, "set_resolution has not been called");
+  int rc = set_device(c);
+  if (rc) return rc;
+  int tps = 0;
+  nrf_tiles_per_shard(c->W, c->H, shard_count, &tps);
+  if (tps != tiles_per_shard) return fail(NRF_E_INVALID, "tiles_per_shard does not match the resolution");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(launch_untile(gathered, shard_count, tiles_per_shard, channels, c->W, c->H, out, st));
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
+// ---- stage entry points ----
+#define STAGE_PROLOGUE()                                         \
+  int rc = need_model(c);                                        \
+  if (rc) return rc;                                             \
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+
+#define STAGE_EPILOGUE() \
+  if (!stream) HIP_TRY(hipStreamSynchronize(st)); \
+  return NRF_OK;
+
+int nrf_encode_grid(nrf_context* c, const void* pos01, uint32_t n, void* out, void* stream) {
+  STAGE_PROLOGUE();
+  if (n && (!pos01 || !out)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_encode_grid(c->dm, pos01, n, out, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_encode_dir(nrf_context* c, const void* dir01, uint32_t n, void* out, void* stream) {
+  STAGE_PROLOGUE();
+  if (n && (!dir01 || !out)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_encode_dir(c->dm, dir01, n, out, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_mlp_forward(nrf_context* c, const void* feat, const void* dirfeat, uint32_t n, void* out, void* stream) {
+  STAGE_PROLOGUE();
+  if (n && (!feat || !dirfeat || !out)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_mlp_forward(c->dm, feat, dirfeat, n, out, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_network(nrf_context* c, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, void* stream) {
+  STAGE_PROLOGUE();
+  if (n && (!xyz || !dir || !sigma || !rgb)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_network(c->dm, xyz, dir, n, sigma, rgb, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_generate_rays(nrf_context* c, const float cam[4], const float pose[16], void* rays_o, void* rays_d, void* nears,
+                      void* fars, void* stream) {
+  STAGE_PROLOGUE();
+  if (!cam || !pose) return fail(NRF_E_INVALID, "null argument");
+  if (c->W <= 0) return fail(NRF_E_STATE, "set_resolution has not been called");
+  FrameParams P;
+  fill_frame_params(c, cam, pose, P);
+  HIP_TRY(launch_generate_rays(c->dm, P, rays_o, rays_d, nears, fars, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_march(nrf_context* c, const void* rays_o, const void* rays_d, const void* rays_t, const void* fars, uint32_t n,
+              uint32_t n_step, void* xyzs, void* dirs, void* deltas, void* stream) {
+  STAGE_PROLOGUE();
+  if (n_step < 1 || n_step > 8) return fail(NRF_E_INVALID, "n_step must be 1..8");
+  if (n && (!rays_o || !rays_d || !rays_t || !fars || !xyzs || !dirs || !deltas)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_march(c->dm, c->opt.dt_gamma, rays_o, rays_d, rays_t, fars, n, n_step, xyzs, dirs, deltas, st));
+  STAGE_EPILOGUE();
+}
+
+int nrf_composite(nrf_context* c, const void* sigmas, const void* rgbs, const void* deltas, uint32_t n, uint32_t n_step,
+                  void* rays_t, void* state, void* stream) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  int rc = set_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (n_step < 1 || n_step > 8) return fail(NRF_E_INVALID, "n_step must be 1..8");
+  if (n && (!sigmas || !rgbs || !deltas || !rays_t || !state)) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(launch_composite(sigmas, rgbs, deltas, n, n_step, rays_t, state, st));
+  STAGE_EPILOGUE();
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// nrf_device.h -- device-side building blocks of the gfx950 render path.
+//
+// Everything here is written for CDNA4 only: 64-lane wavefronts, MFMA
+// 16x16x32 f16 tiles, ballot/mbcnt compaction.  Compiled with
+// -ffp-contract=off so that every fp32 operation of ray generation, marching
+// and the hash-grid address math is individually rounded -- the same contract
+// as the CPU oracle, which makes those stages bit-exact against it.
+//
+// Reference behaviour restated here (R/ = reference repo, T/ = its tiny-cuda-nn):
+//   raygen        R/include/nerf-cuda/render_utils.h:31-66
+//   near/far      R/include/nerf-cuda/render_utils.h:338-392
+//   march         R/include/nerf-cuda/render_utils.h:524-655
+//   hash grid     T/include/tiny-cuda-nn/encodings/grid.h:81-117,139-268
+//   SH / freq     T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:46-96, frequency.h:46-93
+//   fused MLP     T/src/fully_fused_mlp.cu:500-558 (semantics: y = act(W x), no bias)
+//   composite     R/include/nerf-cuda/render_utils.h:658-751
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nerfhip.h"
+
+namespace nrf {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// index modes of one grid level (T/.../grid.h:100-117)
+enum : uint32_t {
+  LV_DENSE = 0,    // x + y*res + z*res^2, then one conditional subtract (index < 2*size always)
+  LV_HASH_POW2 = 1,  // fast_hash & (size-1)
+  LV_GENERIC = 2   // literal restatement with integer modulo (tiled grids, non-pow2 hash sizes)
+};
+
+struct LevelParams {
+  float scale;      // exp2f(l*log2f(b))*Nmin - 1, computed on the host
+  uint32_t res;     // ceil(scale)+1
+  uint32_t offset;  // first entry of the level (in half2 entries)
+  uint32_t size;    // entries in the level ("hashmap_size")
+  uint32_t mode;    // LV_*
+  uint32_t hashed;  // grid_type == Hash (for LV_GENERIC)
+  uint32_t pad0, pad1;
+};
+
+// MFMA weight fragments, packed on the host (nrf_model.cpp: pack_fragments):
+// one fragment = 64 lanes x 8 halves (1 KiB), lane l, element j holds
+// W[16*m + (l&15)][kmap(s, l>>4, j)].
+enum : int {
+  FRAG_D0 = 0,   // density 32->64 : m = 0..3
+  FRAG_D1 = 4,   // density 64->16 : s = 0..1
+  FRAG_R0 = 6,   // rgb 32->64     : m = 0..3
+  FRAG_R1 = 10,  // rgb 64->64     : (m,s) -> 10 + 2*m + s
+  FRAG_R2 = 18,  // rgb 64->16     : s = 0..1
+  N_FRAGS = 20
+};
+
+struct DevModel {
+  const uint32_t* grid;      // half2 entries
+  const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
+  const uint4* wfrag;        // N_FRAGS * 64 uint4
+  const LevelParams* lv;     // 16 entries (device memory)
+  float aabb[6];
+  float bound;
+  float pos_w;  // (float)(1.0/(2*bound)), R/src/nerf_render.cu:311-312
+  uint32_t cascade;
+  uint32_t H;
+  uint32_t n_levels;
+  uint32_t dir_encoding, sh_degree, n_frequencies;
+  uint32_t density_activation, density_output_activation, sigma_activation;
+  uint32_t rgb_activation, rgb_output_activation;
+};
+
+struct FrameParams {
+  float R[9];    // rotation of nerf_matrix_to_ngp(pose)
+  float org[3];  // translation
+  float cam[4];  // fl_x, fl_y, cx, cy
+  int W, H;
+  int tiles_x, tiles_y;
+  int shard_index, shard_count;
+  int n_local_tiles;
+  int tile_major;
+  float bg_color, min_near, dt_gamma, density_scale;
+  int max_steps;
+};
+
+// ------------------------------------------------------------------ misc ----
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ uint32_t h2_bits(half2_t v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ half2_t bits_h2(uint32_t v) { return __builtin_bit_cast(half2_t, v); }
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  half2_t v;
+  v.x = (half_t)a;  // v_cvt_f16_f32: round-to-nearest-even
+  v.y = (half_t)b;
+  return h2_bits(v);
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// tcnn activations on an fp32 pre-activation (T/include/tiny-cuda-nn/common_device.h:68-114)
+__device__ __forceinline__ float activate(uint32_t act, float v) {
+  switch (act) {
+    case NRF_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case NRF_ACT_EXPONENTIAL: return expf(v);
+    case NRF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case NRF_ACT_SQUAREPLUS: {
+      const float x = v * 10.0f;
+      return 0.5f * (x + sqrtf(x * x + 4)) / 10.0f;
+    }
+    case NRF_ACT_SOFTPLUS: return logf(expf(v * 10.0f) + 1.0f) / 10.0f;
+    case NRF_ACT_SINE: return sinf(v);
+    default: return v;
+  }
+}
+
+// ------------------------------------------------------------- ray setup ----
+// set_rays_d: the fixed-size Eigen reductions are a + (b + c).
+__device__ __forceinline__ void ray_dir(const float* R, const float* cam, int px, int py, float d[3]) {
+  const float i = (float)((double)px + 0.5);
+  const float j = (float)((double)py + 0.5);
+  const float zs = 1.0f;
+  const float xs = (i - cam[2]) / cam[0] * zs;
+  const float ys = (j - cam[3]) / cam[1] * zs;
+  const float n = sqrtf(xs * xs + (ys * ys + zs * zs));
+  const float v0 = xs / n, v1 = ys / n, v2 = zs / n;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = R[3 * r + 0] * v0 + (R[3 * r + 1] * v1 + R[3 * r + 2] * v2);
+}
+
+__device__ __forceinline__ void near_far(const float* aabb, const float o[3], const float d[3], float min_near,
+                                         float& near_out, float& far_out) {
+  const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+  float nr = (aabb[0] - o[0]) * rdx, fr = (aabb[3] - o[0]) * rdx;
+  if (nr > fr) { const float c = nr; nr = fr; fr = c; }
+  float ny = (aabb[1] - o[1]) * rdy, fy = (aabb[4] - o[1]) * rdy;
+  if (ny > fy) { const float c = ny; ny = fy; fy = c; }
+  bool miss = (nr > fy) || (ny > fr);
+  if (ny > nr) nr = ny;
+  if (fy < fr) fr = fy;
+  float nz = (aabb[2] - o[2]) * rdz, fz = (aabb[5] - o[2]) * rdz;
+  if (nz > fz) { const float c = nz; nz = fz; fz = c; }
+  miss = miss || (nr > fz) || (nz > fr);
+  if (nz > nr) nr = nz;
+  if (fz < fr) fr = fz;
+  if (nr < min_near) nr = min_near;
+  near_out = miss ? 3.402823466e+38f : nr;
+  far_out = miss ? 3.402823466e+38f : fr;
+}
+
+// ----------------------------------------------------------------- march ----
+struct MarchConst {
+  float bound, dt_gamma, dt_min, dt_max, Hf, Hm1;
+  uint32_t H, C;
+};
+
+__device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_gamma) {
+  MarchConst c;
+  c.bound = M.bound;
+  c.dt_gamma = dt_gamma;
+  c.dt_min = 2 * 1.7320508075688772f / 1024;  // MIN_STEPSIZE, render_utils.h:181-183
+  c.dt_max = 2 * M.bound / (float)M.H;
+  c.H = M.H;
+  c.C = M.cascade;
+  c.Hf = (float)M.H;
+  c.Hm1 = (float)(M.H - 1);
+  return c;
+}
+
+// Advances t until the next occupied sample (returns true; x,y,z = clamped
+// position, dt = its step, t already advanced by dt) or until t >= far.
+// One loop trip = one trip of the `while (t < far && step < n_step)` loop of
+// render_utils.h:593-653.
+__device__ __forceinline__ bool march_next(const MarchConst& c, const uint32_t* __restrict__ occ, float ox, float oy,
+                                           float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz,
+                                           float far, float& t, float& x, float& y, float& z, float& dt_out) {
+  while (t < far) {
+    x = clampf(ox + t * dx, -c.bound, c.bound);
+    y = clampf(oy + t * dy, -c.bound, c.bound);
+    z = clampf(oz + t * dz, -c.bound, c.bound);
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    (void)frexpf(mx, &exponent);
+    const int level = (int)fminf((float)c.C - 1, fmaxf(0.0f, (float)exponent));
+    const float mip_bound = fminf(ldexpf(1.0f, level), c.bound);
+    const float mip_rbound = 1 / mip_bound;
+    // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic in the reference; for H < 2^24 the
+    // double product is exact, so its narrowing to float equals the fp32 product (0.5f*v)*H.
+    const int nx = (int)clampf((0.5f * (x * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
+    const int ny = (int)clampf((0.5f * (y * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
+    const int nz = (int)clampf((0.5f * (z * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
+    const uint32_t cell = (uint32_t)level * c.H * c.H * c.H + (uint32_t)nx * c.H * c.H + (uint32_t)ny * c.H + (uint32_t)nz;
+    const bool occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+    if (occupied) {
+      const float dt = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+      t += dt;
+      dt_out = dt;
+      return true;
+    }
+    const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / c.Hm1 * 2 - 1) * mip_bound - x) * rdx;
+    const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / c.Hm1 * 2 - 1) * mip_bound - y) * rdy;
+    const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / c.Hm1 * 2 - 1) * mip_bound - z) * rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+      t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+    } while (t < tt);
+  }
+  return false;
+}
+
+// ------------------------------------------------------------- hash grid ----
+// One (sample, level) of kernel_grid<half,3,2>: 8 corner gathers of a half2,
+// fp16 accumulation in corner order (grid.h:236-262).  Returns the packed
+// half2 (feature 0 in the low half).
+__device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
+                                                 float py, float pz) {
+  float fx = px * L.scale; fx = fx + 0.5f;
+  float fy = py * L.scale; fy = fy + 0.5f;
+  float fz = pz * L.scale; fz = fz + 0.5f;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  const uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
+  fx -= flx; fy -= fly; fz -= flz;
+  const float wx[2] = {1 - fx, fx};
+  const float wy[2] = {1 - fy, fy};
+  const float wz[2] = {1 - fz, fz};
+  const uint32_t* table = grid + L.offset;
+
+  uint32_t idx[8];
+  if (L.mode == LV_GENERIC) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t p0 = gx + (c & 1), p1 = gy + ((c >> 1) & 1), p2 = gz + ((c >> 2) & 1);
+      // the loop `for dim < 3 && stride <= size` stops at the first failing dim; stride then
+      // stays put, so three sequential tests are equivalent
+      uint32_t stride = 1, index = 0;
+      if (stride <= L.size) { index += p0 * stride; stride *= L.res; }
+      if (stride <= L.size) { index += p1 * stride; stride *= L.res; }
+      if (stride <= L.size) { index += p2 * stride; stride *= L.res; }
+      if (L.hashed && L.size < stride) index = p0 ^ (p1 * 2654435761u) ^ (p2 * 805459861u);
+      idx[c] = index % L.size;
+    }
+  } else {
+    // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
+    const bool hashed = L.mode == LV_HASH_POW2;
+    const uint32_t my = hashed ? 2654435761u : L.res;
+    const uint32_t mz = hashed ? 805459861u : L.res * L.res;
+    const uint32_t ax[2] = {gx, gx + 1};
+    const uint32_t ay0 = gy * my, az0 = gz * mz;
+    const uint32_t ay[2] = {ay0, ay0 + my};
+    const uint32_t az[2] = {az0, az0 + mz};
+    const uint32_t mask = L.size - 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
+      const uint32_t hsh = (a ^ b ^ d) & mask;
+      uint32_t dns = a + b + d;
+      dns = dns >= L.size ? dns - L.size : dns;
+      idx[c] = hashed ? hsh : dns;
+    }
+  }
+  uint32_t v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = table[idx[c]];
+
+  half2_t acc = {(half_t)0.0f, (half_t)0.0f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    // weight = ((1 * wx) * wy) * wz in dimension order (grid.h:240-252)
+    const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
+    const half2_t val = bits_h2(v[c]);
+    half2_t p;
+    p.x = (half_t)(w * (float)val.x);
+    p.y = (half_t)(w * (float)val.y);
+    acc = acc + p;  // v_pk_add_f16, RNE: result += (T)(weight * data)
+  }
+  return h2_bits(acc);
+}
+
+// ------------------------------------------------------ direction encoding ----
+// 16 fp16 values per direction (the padded width the rgb network expects).
+// d01 = 0.5*d + 0.5 (R/src/nerf_render.cu:313-314).
+__device__ __forceinline__ void encode_dir16(const DevModel& M, float d01x, float d01y, float d01z, half_t out[16]) {
+  if (M.dir_encoding == NRF_DIR_SH) {
+    const float x = d01x * 2.f - 1.f, y = d01y * 2.f - 1.f, z = d01z * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float c[16];
+    c[0] = 0.28209479177387814f;
+    c[1] = -0.48860251190291987f * y;
+    c[2] = 0.48860251190291987f * z;
+    c[3] = -0.48860251190291987f * x;
+    c[4] = 1.0925484305920792f * xy;
+    c[5] = -1.0925484305920792f * yz;
+    c[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    c[7] = -1.0925484305920792f * xz;
+    c[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    c[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    c[10] = 2.8906114426405538f * xy * z;
+    c[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    c[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    c[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    c[14] = 1.4453057213202769f * z * (x2 - y2);
+    c[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    // SH pads with LEADING ones up to the alignment of 16 (spherical_harmonics.h:57-64)
+#define NRF_SH_CASE(DEG)                                                        \
+  case DEG: {                                                                   \
+    constexpr int n = DEG * DEG, pad = 16 - n;                                  \
+    _Pragma("unroll") for (int j = 0; j < pad; ++j) out[j] = (half_t)1.0f;      \
+    _Pragma("unroll") for (int j = 0; j < n; ++j) out[pad + j] = (half_t)c[j];  \
+  } break;
+    switch (M.sh_degree) {
+      NRF_SH_CASE(1)
+      NRF_SH_CASE(2)
+      NRF_SH_CASE(3)
+      default:
+      NRF_SH_CASE(4)
+    }
+#undef NRF_SH_CASE
+  } else if (M.dir_encoding == NRF_DIR_FREQUENCY) {
+    const float PI = 3.14159265358979323846f;
+    const uint32_t nf = M.n_frequencies, raw = 6 * nf;
+    const float in[3] = {d01x, d01y, d01z};
+#pragma unroll
+    for (uint32_t j = 0; j < 16; ++j) {
+      float v = 1.0f;  // trailing pad (frequency.h:72-74)
+      if (j < raw) {
+        const uint32_t feat = j / (nf * 2);
+        const uint32_t log2_frequency = (j / 2) % nf;
+        const float phase_shift = (float)(j % 2) * (PI / 2);
+        const float xin = feat == 0 ? in[0] : (feat == 1 ? in[1] : in[2]);
+        const float xs = ldexpf(xin, (int)log2_frequency);
+        v = __sinf(xs * PI + phase_shift);
+      }
+      out[j] = (half_t)v;
+    }
+  } else {  // Identity: scale 1, offset 0, trailing ones
+    out[0] = (half_t)d01x;
+    out[1] = (half_t)d01y;
+    out[2] = (half_t)d01z;
+#pragma unroll
+    for (uint32_t j = 3; j < 16; ++j) out[j] = (half_t)1.0f;
+  }
+}
+
+// ------------------------------------------------------------- fused MLP ----
+// Both MLPs of NerfNetwork::inference_mixed_precision_impl (nerf_network.h:148-196)
+// for NT tiles of 16 samples held by ONE wavefront, entirely in registers:
+//   Y[out][sample] = W[out][k] X[k][sample]  on v_mfma_f32_16x16x32_f16,
+//   A = weight fragment (from LDS), B = activations, D = 16 outs x 16 samples.
+// Lane l = (g = l>>4, c = l&15) holds sample c of each tile.  A layer's D
+// fragment (lane holds outs 16m+4g+r) is re-packed in-lane as the next
+// layer's B fragment; the K permutation this implies is baked into the weight
+// fragments (pack_fragments), so no activation ever crosses lanes or LDS.
+__device__ __forceinline__ float4_t mfma16(half8_t a, half8_t b, float4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ half8_t frag_load(const uint4* wl, int f, int lane) {
+  const uint4 v = wl[f * 64 + lane];
+  return __builtin_bit_cast(half8_t, v);
+}
+
+// pack two D fragments (after activation, rounded to fp16) into one B fragment
+__device__ __forceinline__ half8_t pack_acc(uint32_t act, float4_t lo, float4_t hi) {
+  half8_t r;
+  r[0] = (half_t)activate(act, lo[0]);
+  r[1] = (half_t)activate(act, lo[1]);
+  r[2] = (half_t)activate(act, lo[2]);
+  r[3] = (half_t)activate(act, lo[3]);
+  r[4] = (half_t)activate(act, hi[0]);
+  r[5] = (half_t)activate(act, hi[1]);
+  r[6] = (half_t)activate(act, hi[2]);
+  r[7] = (half_t)activate(act, hi[3]);
+  return r;
+}
+
+// feat[n]  : B fragment of the density MLP input  (hash features 8g..8g+7 of sample c, tile n)
+// dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
+// out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
+template <int NT>
+__device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, int lane, const half8_t (&feat)[NT],
+                                          const half4_t (&dirf)[NT], float4_t (&out)[NT]) {
+  const float4_t zero = {0.f, 0.f, 0.f, 0.f};
+  float4_t acc[NT][4];
+  half8_t hb[NT][2];
+  // ---- density layer 0: 32 -> 64
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const half8_t a = frag_load(wl, FRAG_D0 + m, lane);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, feat[n], zero);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    hb[n][0] = pack_acc(M.density_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(M.density_activation, acc[n][2], acc[n][3]);
+  }
+  // ---- density layer 1: 64 -> 16
+  float4_t dacc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) dacc[n] = zero;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const half8_t a = frag_load(wl, FRAG_D1 + s, lane);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
+  }
+  // density output (fp16), rows 4g..4g+3; rgb input = [density out | dir encoding]
+  half8_t rin[NT];
+  float sig_pre[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    half8_t r;
+    r[0] = (half_t)activate(M.density_output_activation, dacc[n][0]);
+    r[1] = (half_t)activate(M.density_output_activation, dacc[n][1]);
+    r[2] = (half_t)activate(M.density_output_activation, dacc[n][2]);
+    r[3] = (half_t)activate(M.density_output_activation, dacc[n][3]);
+    r[4] = dirf[n][0];
+    r[5] = dirf[n][1];
+    r[6] = dirf[n][2];
+    r[7] = dirf[n][3];
+    rin[n] = r;
+    sig_pre[n] = (float)r[0];  // density row 0 lives in lanes g == 0
+  }
+  // ---- rgb layer 0: 32 -> 64
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const half8_t a = frag_load(wl, FRAG_R0 + m, lane);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, rin[n], zero);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    hb[n][0] = pack_acc(M.rgb_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(M.rgb_activation, acc[n][2], acc[n][3]);
+  }
+  // ---- rgb layer 1: 64 -> 64
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n][m] = zero;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const half8_t a = frag_load(wl, FRAG_R1 + 2 * m + s, lane);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, hb[n][s], acc[n][m]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    hb[n][0] = pack_acc(M.rgb_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(M.rgb_activation, acc[n][2], acc[n][3]);
+  }
+  // ---- rgb layer 2: 64 -> 16 (3 used)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) dacc[n] = zero;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const half8_t a = frag_load(wl, FRAG_R2 + s, lane);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    // network_output rows 0..2 (fp16) and extract_density row 3 (nerf_network.h:49-61):
+    // fp32 activation of the fp16 density output, stored as fp16.
+    float s = sig_pre[n];
+    switch (M.sigma_activation) {
+      case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
+      case NRF_ACT_EXPONENTIAL: s = expf(s); break;
+      case NRF_ACT_SIGMOID: s = 1.0f / (1.0f + expf(-s)); break;
+      default: break;
+    }
+    float4_t o;
+    o[0] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][0]);
+    o[1] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][1]);
+    o[2] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][2]);
+    o[3] = (float)(half_t)s;
+    out[n] = o;
+  }
+}
+
+}  // namespace nrf

@@ -1,0 +1,549 @@
+// nrf_kernels.hip -- gfx950 kernels of the render hot path and their launchers.
+//
+// render_kernel is the product: ONE launch per frame replaces the reference's
+// host-driven loop of ~15 launches + a blocking D2H copy per march iteration
+// (R/src/nerf_render.cu:269-338).  One wavefront owns one 8x8 pixel tile (64
+// rays) for the tile's whole life:
+//     raygen -> near/far -> { march (ballot/mbcnt sample compaction into LDS)
+//                             -> hash-grid gather + SH -> both MLPs on MFMA
+//                             -> alpha compositing } until every ray is dead
+//     -> background blend -> RGBA / depth store.
+// Nothing but the final pixels ever goes to HBM; the only global reads are the
+// hash table, the occupancy bitfield and 20 KiB of weight fragments per
+// workgroup (kept in LDS).
+// The stage kernels below it expose the same device functions one stage at a
+// time for the parity tests (include/nerfhip.h "stage entry points").
+
+#include "nrf_device.h"
+#include "nrf_launch.h"
+
+namespace nrf {
+
+// ---------------------------------------------------------------- LDS map ----
+struct WaveLds {
+  float4 pos[64];        // sample slot: x, y, z (world, clamped), dt
+  float2 aux[64];        // sample slot: t - last_t, ray lane (bit pattern)
+  float4 out[64];        // sample slot: r, g, b, sigma
+  uint32_t dirf[64][8];  // ray lane: 16 fp16 direction-encoding values
+};
+static_assert(sizeof(WaveLds) == 4608, "WaveLds layout");
+
+constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
+constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
+constexpr int LDS_TOTAL_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);
+
+// cross-lane hand-off through LDS inside ONE wavefront: LDS operations of a
+// wave execute in order, so only the compiler has to be kept from reordering
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, LevelParams* lvs) {
+  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+  __syncthreads();
+}
+
+// Encodes and evaluates the S (<= 16*NT) samples queued in the wave's LDS
+// slots; results go to W->out[slot].  Lane (g, c): sample c of each tile,
+// hash levels 4g..4g+3, direction entries 4g..4g+3.
+template <int NT>
+__device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
+                                                 int S, int lane, float density_scale) {
+  const int g = lane >> 4, c = lane & 15;
+  half8_t feat[NT];
+  half4_t dirf[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int slot = 16 * n + c;
+    uint32_t fb[4] = {0u, 0u, 0u, 0u};
+    uint2 db = make_uint2(0u, 0u);
+    if (slot < S) {
+      const float4 p = W->pos[slot];
+      // xyz -> [0,1]: linear_transformer(1/(2 bound), 0.5), R/src/nerf_render.cu:311-312
+      float px = M.pos_w * p.x; px = px + 0.5f;
+      float py = M.pos_w * p.y; py = py + 0.5f;
+      float pz = M.pos_w * p.z; pz = pz + 0.5f;
+#pragma unroll
+      for (int jl = 0; jl < 4; ++jl) fb[jl] = encode_level(M.grid, lvs[4 * g + jl], px, py, pz);
+      const int ray = __builtin_bit_cast(int, W->aux[slot].y);
+      db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
+    }
+    const uint4 fv = make_uint4(fb[0], fb[1], fb[2], fb[3]);
+    feat[n] = __builtin_bit_cast(half8_t, fv);
+    dirf[n] = __builtin_bit_cast(half4_t, db);
+  }
+  float4_t o[NT];
+  mlp_tiles<NT>(M, wl, lane, feat, dirf, o);
+  if (g == 0) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int slot = 16 * n + c;
+      float sigma = o[n][3];
+      if (density_scale != 1.0f) sigma = density_scale * sigma;  // R/src/nerf_render.cu:328 (float multiply)
+      if (slot < S) W->out[slot] = make_float4(o[n][0], o[n][1], o[n][2], sigma);
+    }
+  }
+}
+
+__device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
+                                                 int S, int lane, float density_scale) {
+  const int ntile = (S + 15) >> 4;  // wave-uniform
+  if (ntile <= 1) network_from_lds<1>(M, wl, lvs, W, S, lane, density_scale);
+  else if (ntile == 2) network_from_lds<2>(M, wl, lvs, W, S, lane, density_scale);
+  else network_from_lds<4>(M, wl, lvs, W, S, lane, density_scale);
+}
+
+// ------------------------------------------------------- the render kernel ----
+__global__ __launch_bounds__(256, 2) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
+                                                     float* __restrict__ depth, unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = reinterpret_cast<uint4*>(smem);
+  LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
+  stage_weights(M, wl, lvs);
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  WaveLds* W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+
+  // XCD-aware block order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each
+  // XCD one contiguous band of tile strips -> neighbouring tiles share that XCD's L2 (bijective remap).
+  const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int k_local = swz * 4 + wave;
+  if (k_local >= P.n_local_tiles) return;  // no barrier after this point
+  const int tile = k_local * P.shard_count + P.shard_index;
+  const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+  const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+  const bool in_img = px < P.W && py < P.H;
+
+  // ---- ray generation + aabb
+  const float o[3] = {P.org[0], P.org[1], P.org[2]};
+  float d[3];
+  ray_dir(P.R, P.cam, px, py, d);
+  float near, far;
+  near_far(M.aabb, o, d, P.min_near, near, far);
+  const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+  {
+    half_t e[16];
+    float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
+    float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
+    float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
+    encode_dir16(M, u0, u1, u2, e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      half2_t h;
+      h.x = e[2 * j];
+      h.y = e[2 * j + 1];
+      W->dirf[lane][j] = h2_bits(h);
+    }
+  }
+  const MarchConst mc = march_const(M, P.dt_gamma);
+
+  float t = near;
+  bool alive = in_img && (near < far);
+  float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  int steps_done = 0;
+  unsigned n_samples = 0, n_rounds = 0;
+
+  while (true) {
+    const unsigned long long am = __ballot(alive);
+    if (am == 0ull || steps_done >= P.max_steps) break;
+    const int A = __popcll(am);
+    int n_step = 64 / A;  // R/src/nerf_render.cu:300 with N = 64 rays per wave tile
+    n_step = n_step > 8 ? 8 : n_step;
+
+    // ---- march: up to n_step samples per alive ray, compacted k-major into LDS slots
+    const float t_start = t;
+    float last_t = t;
+    unsigned long long slots = 0ull;
+    int cnt = 0, S = 0;
+    bool marching = alive;
+    for (int k = 0; k < n_step; ++k) {
+      float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
+      bool found = false;
+      if (marching) found = march_next(mc, M.occ_bits, o[0], o[1], o[2], d[0], d[1], d[2], rdx, rdy, rdz, far, t, x, y, z, dt);
+      marching = found;
+      const unsigned long long fm = __ballot(found);
+      if (fm == 0ull) break;
+      if (found) {
+        const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        W->pos[slot] = make_float4(x, y, z, dt);
+        W->aux[slot] = make_float2(t - last_t, __builtin_bit_cast(float, lane));
+        last_t = t;
+        slots |= (unsigned long long)slot << (8 * k);
+        cnt++;
+      }
+      S += __popcll(fm);
+    }
+    wave_sync();
+
+    // ---- network on the S queued samples (sample-major MFMA tiles)
+    if (S > 0) network_dispatch(M, wl, lvs, W, S, lane, P.density_scale);
+    wave_sync();
+
+    // ---- alpha compositing, R/include/nerf-cuda/render_utils.h:699-743
+    if (alive) {
+      float tc = t_start;
+      int step = 0;
+      for (int k = 0; k < n_step; ++k) {
+        if (k >= cnt) break;  // deltas == 0: the ray ran out of samples
+        const int slot = (int)((slots >> (8 * k)) & 0xffull);
+        const float4 so = W->out[slot];
+        const float dt = W->pos[slot].w;
+        const float alpha = 1.0f - __expf(-so.w * dt);
+        const float T = 1 - ws;
+        const float wgt = alpha * T;
+        ws += wgt;
+        tc += W->aux[slot].x;
+        dep += wgt * tc;
+        cr += wgt * so.x;
+        cg += wgt * so.y;
+        cb += wgt * so.z;
+        // `T < 1e-4` against a double literal: true exactly for T <= 9.99999974737875e-05f
+        if (T <= 9.99999974737875e-05f) break;
+        step++;
+      }
+      alive = step == n_step;
+      t = tc;
+    }
+    wave_sync();
+    n_samples += (unsigned)S;
+    n_rounds++;
+    steps_done += n_step;
+  }
+
+  // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
+  if (in_img) {
+    const float bgw = (1 - ws) * P.bg_color;
+    const float span = far - near;
+    const float dn = span > 0.0f ? fmaxf(dep - near, 0.0f) / span : 0.0f;
+    const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
+    rgba[idx] = make_float4(cr + bgw, cg + bgw, cb + bgw, ws);
+    depth[idx] = dn;
+  } else if (P.tile_major) {
+    const size_t idx = (size_t)k_local * 64 + lane;
+    rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    depth[idx] = 0.f;
+  }
+  if (lane == 0) {
+    atomicAdd(&counters[0], (unsigned long long)n_samples);
+    atomicAdd(&counters[1], (unsigned long long)n_rounds);
+  }
+}
+
+// ------------------------------------------------------------ stage kernels ----
+__global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, const float* __restrict__ pos01, uint32_t n,
+                                                          uint32_t* __restrict__ out) {
+  __shared__ LevelParams lvs[16];
+  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+  __syncthreads();
+  // one thread per (sample, level): out[sample][level] as packed half2
+  const uint64_t total = (uint64_t)n * 16u;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
+    out[i] = encode_level(M.grid, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
+  }
+}
+
+__global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const float* __restrict__ dir01, uint32_t n,
+                                                         uint32_t* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    half_t e[16];
+    encode_dir16(M, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      half2_t h;
+      h.x = e[2 * j];
+      h.y = e[2 * j + 1];
+      out[(size_t)i * 8 + j] = h2_bits(h);
+    }
+  }
+}
+
+// Both MLPs on pre-encoded inputs: one wave = 64 samples per trip.
+// feat fp16 [n][32], dirfeat fp16 [n][16] -> out fp16 [n][4] = (r, g, b, sigma)
+__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
+                                                          const uint2* __restrict__ dirfeat, uint32_t n,
+                                                          uint2* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = reinterpret_cast<uint4*>(smem);
+  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  __syncthreads();
+  const int lane = lane_id(), g = lane >> 4, c = lane & 15;
+  const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t n_chunks = (n + 63u) >> 6;
+  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
+    const uint32_t base = chunk << 6;
+    half8_t f[4];
+    half4_t df[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t s = base + 16u * t + c;
+      uint4 fv = make_uint4(0u, 0u, 0u, 0u);
+      uint2 dv = make_uint2(0u, 0u);
+      if (s < n) {
+        fv = feat[(size_t)s * 4 + g];     // features 8g..8g+7: 16 B, fully coalesced across the wave
+        dv = dirfeat[(size_t)s * 4 + g];  // entries 4g..4g+3
+      }
+      f[t] = __builtin_bit_cast(half8_t, fv);
+      df[t] = __builtin_bit_cast(half4_t, dv);
+    }
+    float4_t o[4];
+    mlp_tiles<4>(M, wl, lane, f, df, o);
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t s = base + 16u * t + c;
+        if (s < n) out[s] = make_uint2(pack_h2(o[t][0], o[t][1]), pack_h2(o[t][2], o[t][3]));
+      }
+    }
+  }
+}
+
+// Whole network on raw march output through the SAME code path as render_kernel.
+__global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const float* __restrict__ xyz,
+                                                      const float* __restrict__ dir, uint32_t n, float* __restrict__ sigma,
+                                                      float* __restrict__ rgb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = reinterpret_cast<uint4*>(smem);
+  LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
+  stage_weights(M, wl, lvs);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  WaveLds* W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+  const uint32_t wave_global = blockIdx.x * 4 + wave;
+  const uint32_t n_waves = gridDim.x * 4;
+  const uint32_t n_chunks = (n + 63u) >> 6;
+  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
+    const uint32_t i = (chunk << 6) + lane;
+    const int S = (int)min(64u, n - (chunk << 6));
+    if (i < n) {
+      W->pos[lane] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+      W->aux[lane] = make_float2(0.f, __builtin_bit_cast(float, lane));
+      half_t e[16];
+      float u0 = 0.5f * dir[3 * (size_t)i]; u0 = u0 + 0.5f;
+      float u1 = 0.5f * dir[3 * (size_t)i + 1]; u1 = u1 + 0.5f;
+      float u2 = 0.5f * dir[3 * (size_t)i + 2]; u2 = u2 + 0.5f;
+      encode_dir16(M, u0, u1, u2, e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        half2_t h;
+        h.x = e[2 * j];
+        h.y = e[2 * j + 1];
+        W->dirf[lane][j] = h2_bits(h);
+      }
+    }
+    wave_sync();
+    network_dispatch(M, wl, lvs, W, S, lane, 1.0f);
+    wave_sync();
+    if (i < n) {
+      const float4 so = W->out[lane];
+      sigma[i] = so.w;
+      rgb[3 * (size_t)i] = so.x;
+      rgb[3 * (size_t)i + 1] = so.y;
+      rgb[3 * (size_t)i + 2] = so.z;
+    }
+    wave_sync();
+  }
+}
+
+__global__ __launch_bounds__(256) void generate_rays_kernel(const DevModel M, const FrameParams P, float* __restrict__ rays_o,
+                                                            float* __restrict__ rays_d, float* __restrict__ nears,
+                                                            float* __restrict__ fars) {
+  const int n = P.W * P.H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int px = i % P.W, py = i / P.W;
+    const float o[3] = {P.org[0], P.org[1], P.org[2]};
+    float d[3], nr, fr;
+    ray_dir(P.R, P.cam, px, py, d);
+    near_far(M.aabb, o, d, P.min_near, nr, fr);
+    if (rays_o) { rays_o[3 * (size_t)i] = o[0]; rays_o[3 * (size_t)i + 1] = o[1]; rays_o[3 * (size_t)i + 2] = o[2]; }
+    if (rays_d) { rays_d[3 * (size_t)i] = d[0]; rays_d[3 * (size_t)i + 1] = d[1]; rays_d[3 * (size_t)i + 2] = d[2]; }
+    if (nears) nears[i] = nr;
+    if (fars) fars[i] = fr;
+  }
+}
+
+__global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_gamma, const float* __restrict__ rays_o,
+                                                    const float* __restrict__ rays_d, const float* __restrict__ rays_t,
+                                                    const float* __restrict__ fars, uint32_t n, uint32_t n_step,
+                                                    float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                    float* __restrict__ deltas) {
+  const MarchConst mc = march_const(M, dt_gamma);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float ox = rays_o[3 * (size_t)i], oy = rays_o[3 * (size_t)i + 1], oz = rays_o[3 * (size_t)i + 2];
+    const float dx = rays_d[3 * (size_t)i], dy = rays_d[3 * (size_t)i + 1], dz = rays_d[3 * (size_t)i + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float far = fars[i];
+    float t = rays_t[i], last_t = t;
+    bool marching = true;
+    for (uint32_t k = 0; k < n_step; ++k) {
+      const size_t s = (size_t)i * n_step + k;
+      float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
+      bool found = false;
+      if (marching) found = march_next(mc, M.occ_bits, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, t, x, y, z, dt);
+      marching = found;
+      // unused slots are zero-filled (deviation D-1)
+      xyzs[3 * s] = found ? x : 0.f;
+      xyzs[3 * s + 1] = found ? y : 0.f;
+      xyzs[3 * s + 2] = found ? z : 0.f;
+      dirs[3 * s] = found ? dx : 0.f;
+      dirs[3 * s + 1] = found ? dy : 0.f;
+      dirs[3 * s + 2] = found ? dz : 0.f;
+      deltas[2 * s] = found ? dt : 0.f;
+      deltas[2 * s + 1] = found ? t - last_t : 0.f;
+      if (found) last_t = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                        const float* __restrict__ deltas, uint32_t n, uint32_t n_step,
+                                                        float* __restrict__ rays_t, float* __restrict__ state) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float* st = state + 5 * (size_t)i;
+    float ws = st[0], dep = st[1], cr = st[2], cg = st[3], cb = st[4];
+    float t = rays_t[i];
+    uint32_t step = 0;
+    while (step < n_step) {
+      const size_t s = (size_t)i * n_step + step;
+      const float dt = deltas[2 * s];
+      if (dt == 0) break;
+      const float alpha = 1.0f - __expf(-sigmas[s] * dt);
+      const float T = 1 - ws;
+      const float wgt = alpha * T;
+      ws += wgt;
+      t += deltas[2 * s + 1];
+      dep += wgt * t;
+      cr += wgt * rgbs[3 * s];
+      cg += wgt * rgbs[3 * s + 1];
+      cb += wgt * rgbs[3 * s + 2];
+      if (T <= 9.99999974737875e-05f) break;
+      step++;
+    }
+    rays_t[i] = step < n_step ? -1.0f : t;
+    st[0] = ws; st[1] = dep; st[2] = cr; st[3] = cg; st[4] = cb;
+  }
+}
+
+// gathered [shard][tiles_per_shard][64][C] -> row-major [H][W][C]
+__global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ gathered, int shard_count, int tiles_per_shard,
+                                                     int C, int W, int H, int tiles_x, float* __restrict__ out) {
+  const size_t total = (size_t)W * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)(i / W);
+    const int tile = (py >> 3) * tiles_x + (px >> 3);
+    const int shard = tile % shard_count, k = tile / shard_count;
+    const int l = (py & 7) * 8 + (px & 7);
+    const float* src = gathered + (((size_t)shard * tiles_per_shard + k) * 64 + l) * C;
+    for (int ch = 0; ch < C; ++ch) out[i * C + ch] = src[ch];
+  }
+}
+
+// (unsigned char)(255.0 * x), saturating, NaN -> 0 (R/src/nerf_render.cu:352-359, deviation D-2)
+__device__ __forceinline__ unsigned char quant_u8(float v) {
+  const double s = 255.0 * (double)v;
+  if (!(s > 0.0)) return 0;
+  if (s >= 255.0) return 255;
+  return (unsigned char)s;
+}
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ rgba, const float* __restrict__ depth, int n,
+                                                       unsigned char* __restrict__ rgb8, unsigned char* __restrict__ depth8) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 v = rgba[i];
+    rgb8[3 * (size_t)i] = quant_u8(v.x);
+    rgb8[3 * (size_t)i + 1] = quant_u8(v.y);
+    rgb8[3 * (size_t)i + 2] = quant_u8(v.z);
+    depth8[i] = quant_u8(depth[i]);
+  }
+}
+
+// ---------------------------------------------------------------- launchers ----
+static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
+  uint64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (uint64_t)cap) g = cap;
+  return (int)g;
+}
+
+hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st) {
+  const int blocks = (P.n_local_tiles + 3) / 4;
+  if (blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
+                     (unsigned long long*)counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(encode_grid_kernel, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+                     (uint32_t*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(encode_dir_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, (const float*)dir01, n, (uint32_t*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  const uint64_t chunks = ((uint64_t)n + 63) / 64;
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
+                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_network(const DevModel& M, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, hipStream_t st) {
+  if (!n) return hipSuccess;
+  const uint64_t chunks = ((uint64_t)n + 63) / 64;
+  hipLaunchKernelGGL(network_kernel, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M, (const float*)xyz,
+                     (const float*)dir, n, (float*)sigma, (float*)rgb);
+  return hipGetLastError();
+}
+
+hipError_t launch_generate_rays(const DevModel& M, const FrameParams& P, void* rays_o, void* rays_d, void* nears, void* fars,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(generate_rays_kernel, dim3(grid_for((uint64_t)P.W * P.H)), dim3(256), 0, st, M, P, (float*)rays_o,
+                     (float*)rays_d, (float*)nears, (float*)fars);
+  return hipGetLastError();
+}
+
+hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, const void* rays_d, const void* rays_t,
+                        const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(march_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o, (const float*)rays_d,
+                     (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs, (float*)deltas);
+  return hipGetLastError();
+}
+
+hipError_t launch_composite(const void* sigmas, const void* rgbs, const void* deltas, uint32_t n, uint32_t n_step, void* rays_t,
+                            void* state, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float*)sigmas, (const float*)rgbs,
+                     (const float*)deltas, n, n_step, (float*)rays_t, (float*)state);
+  return hipGetLastError();
+}
+
+hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, void* out, hipStream_t st) {
+  hipLaunchKernelGGL(untile_kernel, dim3(grid_for((uint64_t)W * H)), dim3(256), 0, st, (const float*)gathered, shard_count,
+                     tiles_per_shard, C, W, H, (W + 7) / 8, (float*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st) {
+  hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((uint64_t)n)), dim3(256), 0, st, (const float4*)rgba, (const float*)depth, n,
+                     (unsigned char*)rgb8, (unsigned char*)depth8);
+  return hipGetLastError();
+}
+
+int render_lds_bytes() { return LDS_TOTAL_BYTES; }
+
+}  // namespace nrf

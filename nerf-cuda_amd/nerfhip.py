@@ -1,0 +1,420 @@
+"""ctypes binding of include/nerfhip.h (the C ABI of the HIP render path).
+
+Host-side mirror, in Python, of what ngp::NerfRender does above its kernels:
+  * `desc_from_config`  -- NerfRender::load_snapshot + reset_network
+    (reference src/nerf_render.cu:431-473, 111-184) and the NerfNetwork ctor's
+    defaulting (include/nerf-cuda/nerf_network.h:95-135): snapshot dict ->
+    nrf_model_desc.
+  * `NerfHip`           -- thin object over nrf_create / nrf_load_model /
+    nrf_set_resolution / nrf_render ... used by tests, bench.py and smoke().
+
+There is no CPU fallback here: if libnerfhip.so is missing or no gfx950 device
+is present, construction raises.  The oracle (oracle/) is never imported from
+this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libnerfhip.so"
+
+NRF_ABI_VERSION = 1
+NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
+
+ACT = {"none": 0, "relu": 1, "exponential": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5, "sine": 6}
+DIR_SH, DIR_FREQUENCY, DIR_IDENTITY = 0, 1, 2
+GRID_HASH, GRID_DENSE, GRID_TILED = 0, 1, 2
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("grid_type", C.c_uint32),
+        ("n_levels", C.c_uint32),
+        ("n_features_per_level", C.c_uint32),
+        ("log2_hashmap_size", C.c_uint32),
+        ("base_resolution", C.c_uint32),
+        ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_uint32),
+        ("density_hidden_layers", C.c_uint32),
+        ("density_activation", C.c_uint32),
+        ("density_output_activation", C.c_uint32),
+        ("density_n_output", C.c_uint32),
+        ("sigma_activation", C.c_uint32),
+        ("rgb_hidden_layers", C.c_uint32),
+        ("rgb_activation", C.c_uint32),
+        ("rgb_output_activation", C.c_uint32),
+        ("dir_encoding", C.c_uint32),
+        ("sh_degree", C.c_uint32),
+        ("n_frequencies", C.c_uint32),
+        ("aabb", C.c_float * 6),
+        ("bound", C.c_float),
+        ("scale", C.c_float),
+        ("cascade", C.c_uint32),
+        ("density_grid_size", C.c_uint32),
+        ("mean_density", C.c_float),
+        ("params", C.POINTER(C.c_float)),
+        ("n_params", C.c_uint64),
+        ("density_grid", C.POINTER(C.c_float)),
+        ("n_density_grid", C.c_uint64),
+    ]
+
+
+class LevelTable(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32),
+        ("offset", C.c_uint32 * 17),
+        ("resolution", C.c_uint32 * 16),
+        ("scale", C.c_float * 16),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("bg_color", C.c_float),
+        ("min_near", C.c_float),
+        ("dt_gamma", C.c_float),
+        ("max_steps", C.c_int32),
+        ("density_scale", C.c_float),
+        ("perturb", C.c_int32),
+        ("shard_index", C.c_int32),
+        ("shard_count", C.c_int32),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("n_tiles", C.c_int32),
+        ("rgba", C.c_void_p),
+        ("depth", C.c_void_p),
+        ("tile_major", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_uint64),
+        ("n_samples", C.c_uint64),
+        ("n_rounds", C.c_uint64),
+        ("render_ms", C.c_float),
+    ]
+
+
+def default_options() -> Options:
+    """Private member defaults of NerfRender (include/nerf-cuda/nerf_render.h:55-78)."""
+    return Options(1.0, 0.2, 1.0 / 128.0, 1024, 1.0, 0, 0, 1)
+
+
+class NerfHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nerfhip error {code}: {msg}")
+        self.code = code
+
+
+# --------------------------------------------------------------------------
+# library loading
+# --------------------------------------------------------------------------
+_lib = None
+
+_SIGS = {
+    "nrf_last_error": (C.c_char_p, []),
+    "nrf_abi_version": (C.c_int, []),
+    "nrf_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nrf_destroy": (C.c_int, [C.c_void_p]),
+    "nrf_default_options": (None, [C.POINTER(Options)]),
+    "nrf_level_table_compute": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(LevelTable)]),
+    "nrf_expected_n_params": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_uint64)]),
+    "nrf_default_per_level_scale": (C.c_int, [C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "nrf_load_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
+    "nrf_set_resolution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nrf_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "nrf_render": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(Frame)]),
+    "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_read_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_read_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "nrf_encode_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nrf_encode_dir": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nrf_network": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_generate_rays": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_march": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names include/nerfhip.h declares (checked against the .so by the CPU tests)."""
+    return sorted(_SIGS)
+
+
+def load_library(path: os.PathLike | None = None):
+    """dlopen libnerfhip.so and attach signatures.  Fails loudly when missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing from the .so
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != NRF_OK:
+        raise NerfHipError(rc, load_library().nrf_last_error().decode("utf-8", "replace"))
+
+
+# --------------------------------------------------------------------------
+# snapshot dict -> nrf_model_desc  (load_snapshot + reset_network + NerfNetwork ctor)
+# --------------------------------------------------------------------------
+def _act(name, default):
+    s = (name if name is not None else default).lower()
+    if s not in ACT:
+        raise ValueError(f"Invalid activation name: {name}")  # T/src/network.cu:41-60
+    return ACT[s]
+
+
+def default_per_level_scale(bound: float, base_resolution: int, n_levels: int) -> float:
+    """fp32 exp(log(2048*bound/base)/(L-1)), reference src/nerf_render.cu:158-165.
+    Evaluated by the C library so that libm's expf/logf are used."""
+    out = C.c_float()
+    _check(load_library().nrf_default_per_level_scale(C.c_float(bound), base_resolution, n_levels, C.byref(out)))
+    return float(out.value)
+
+
+def desc_from_config(config: dict, params: np.ndarray | None = None, density_grid: np.ndarray | None = None):
+    """Build a nrf_model_desc from a snapshot dict in the reference's format
+    (SURVEY.md Appendix B).  Returns (desc, keepalive)."""
+    if "snapshot" not in config:
+        raise RuntimeError("File does not contain a snapshot.")  # nerf_render.cu:434-436
+    snap = config["snapshot"]
+    enc = dict(config.get("encoding", {}))
+    net = dict(config.get("network", {}))
+    rgb = dict(config.get("rgb_network", {}))
+    dire = dict(config.get("dir_encoding", {}))
+
+    d = ModelDesc()
+    d.abi_version = NRF_ABI_VERSION
+    # snapshot block, nerf_render.cu:441-453 with member defaults nerf_render.h:55-67
+    aabb = [float(v) for v in snap["aabb"]]
+    d.aabb = (C.c_float * 6)(*aabb)
+    d.bound = float(snap.get("bound", 1))
+    d.scale = float(snap.get("scale", 0.33))
+    d.cascade = int(snap.get("cascade", 1))
+    d.density_grid_size = int(snap.get("density_grid_size", 128))
+    d.mean_density = float(snap.get("mean_density", 1e-4))
+
+    # encoding block, nerf_render.cu:125-165 and grid.h:1365-1386
+    otype = enc.get("otype", "OneBlob").lower()
+    if "grid" not in otype:
+        raise NotImplementedError(f"position encoding '{otype}' is outside the hot path (hash grid only)")
+    default_type = "tiled" if otype == "tiledgrid" else ("dense" if otype == "densegrid" else "hash")
+    d.grid_type = {"hash": GRID_HASH, "dense": GRID_DENSE, "tiled": GRID_TILED}[enc.get("type", default_type).lower()]
+    F = int(enc.get("n_features_per_level", 2))
+    d.n_features_per_level = F
+    if enc.get("n_features", 0) and enc["n_features"] > 0:
+        if "n_levels" in enc:
+            raise RuntimeError("GridEncoding: may not specify n_features and n_levels simultaneously")
+        d.n_levels = int(enc["n_features"]) // F
+    else:
+        d.n_levels = int(enc.get("n_levels", 16))
+    d.log2_hashmap_size = int(enc.get("log2_hashmap_size", 15))  # the reference's default, nerf_render.cu:144-145
+    base = int(enc.get("base_resolution", 0))
+    if not base:
+        base = 1 << (d.log2_hashmap_size // 3)
+    d.base_resolution = base
+    pls = float(enc.get("per_level_scale", 0.0))
+    if pls <= 0.0 and d.n_levels > 1:
+        pls = default_per_level_scale(d.bound, base, d.n_levels)
+    if pls <= 0.0:
+        pls = 2.0
+    d.per_level_scale = pls
+    if enc.get("interpolation", "Linear").lower() != "linear":
+        raise NotImplementedError("only Linear grid interpolation is on the hot path")
+
+    # network blocks, T/src/network.cu:127-143 + nerf_network.h:117-135
+    def mlp(cfg):
+        ot = cfg.get("otype", "FullyFusedMLP").lower()
+        if ot not in ("fullyfusedmlp", "megakernelmlp", "mlp", "cutlassmlp"):
+            raise RuntimeError(f"Invalid network type: {ot}")
+        return int(cfg.get("n_neurons", 128)), int(cfg.get("n_hidden_layers", 5)), \
+            _act(cfg.get("activation"), "ReLU"), _act(cfg.get("output_activation"), "None")
+
+    n1, h1, a1, o1 = mlp(net)
+    n2, h2, a2, o2 = mlp(rgb)
+    if n1 != n2:
+        raise NotImplementedError("density and rgb networks must share n_neurons")
+    d.n_neurons = n1
+    d.density_hidden_layers, d.density_activation, d.density_output_activation = h1, a1, o1
+    d.density_n_output = int(net.get("n_output_dims", 16))
+    d.sigma_activation = _act(net.get("sigma_activation"), "Exponential")
+    d.rgb_hidden_layers, d.rgb_activation, d.rgb_output_activation = h2, a2, o2
+
+    # dir_encoding: Composite{nested[0] on 3 dims, Identity on the remaining 0 dims (dropped)}
+    # T/include/tiny-cuda-nn/encodings/composite.h:139-216
+    node = dire
+    if node.get("otype", "Composite").lower() == "composite":
+        # a nested encoding without n_dims_to_encode takes the remaining dims; with all 3
+        # consumed by the first, the rest encode 0 dims and are dropped (composite.h:182-185)
+        covering = [n for n in node.get("nested", []) if int(n.get("n_dims_to_encode", 0)) == 3]
+        if not covering and len(node.get("nested", [])) == 1 and "n_dims_to_encode" not in node["nested"][0]:
+            covering = [node["nested"][0]]
+        if not covering:
+            raise NotImplementedError("dir_encoding must encode all 3 direction dims with one nested encoding")
+        node = covering[0]
+    ot = node.get("otype", "").lower()
+    if ot == "sphericalharmonics":
+        d.dir_encoding, d.sh_degree = DIR_SH, int(node.get("degree", 4))
+    elif ot == "frequency":
+        d.dir_encoding, d.n_frequencies = DIR_FREQUENCY, int(node.get("n_frequencies", 12))
+    elif ot == "identity":
+        d.dir_encoding = DIR_IDENTITY
+    else:
+        raise NotImplementedError(f"dir encoding '{ot}' is outside the hot path")
+
+    p = np.ascontiguousarray(params if params is not None else np.asarray(snap["params"], dtype=np.float32),
+                             dtype=np.float32)
+    g = np.ascontiguousarray(
+        density_grid if density_grid is not None else np.asarray(snap["density_grid"], dtype=np.float32),
+        dtype=np.float32)
+    d.params = p.ctypes.data_as(C.POINTER(C.c_float))
+    d.n_params = p.size
+    d.density_grid = g.ctypes.data_as(C.POINTER(C.c_float))
+    d.n_density_grid = g.size
+    return d, (p, g)
+
+
+def level_table(desc: ModelDesc) -> LevelTable:
+    t = LevelTable()
+    _check(load_library().nrf_level_table_compute(C.byref(desc), C.byref(t)))
+    return t
+
+
+def expected_n_params(desc: ModelDesc) -> int:
+    n = C.c_uint64()
+    _check(load_library().nrf_expected_n_params(C.byref(desc), C.byref(n)))
+    return int(n.value)
+
+
+def tiles_per_shard(width: int, height: int, shard_count: int) -> int:
+    n = C.c_int()
+    _check(load_library().nrf_tiles_per_shard(width, height, shard_count, C.byref(n)))
+    return int(n.value)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class NerfHip:
+    """One context on one device (nrf_context)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.nrf_create(device, C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nrf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_model(self, desc: ModelDesc):
+        _check(self.lib.nrf_load_model(self.h, C.byref(desc)))
+
+    def set_resolution(self, width: int, height: int):
+        _check(self.lib.nrf_set_resolution(self.h, width, height))
+        self.width, self.height = width, height
+
+    def set_options(self, opts: Options):
+        _check(self.lib.nrf_set_options(self.h, C.byref(opts)))
+
+    def render(self, cam, pose, stream=None) -> Frame:
+        cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(4)
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        f = Frame()
+        _check(self.lib.nrf_render(self.h, _fptr(cam), _fptr(pose), C.c_void_p(stream or 0), C.byref(f)))
+        return f
+
+    def bind_output(self, rgba_ptr, depth_ptr):
+        _check(self.lib.nrf_bind_output(self.h, C.c_void_p(rgba_ptr or 0), C.c_void_p(depth_ptr or 0)))
+
+    def read_f32(self):
+        rgba = np.empty((self.height, self.width, 4), np.float32)
+        depth = np.empty((self.height, self.width), np.float32)
+        _check(self.lib.nrf_read_f32(self.h, rgba.ctypes.data, depth.ctypes.data))
+        return rgba, depth
+
+    def read_u8(self):
+        rgb = np.empty((self.height, self.width, 3), np.uint8)
+        depth = np.empty((self.height, self.width), np.uint8)
+        _check(self.lib.nrf_read_u8(self.h, rgb.ctypes.data, depth.ctypes.data))
+        return rgb, depth
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(self.lib.nrf_get_stats(self.h, C.byref(s)))
+        return s
+
+    def untile(self, gathered_ptr, shard_count, tiles, channels, out_ptr, stream=None):
+        _check(self.lib.nrf_untile(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels,
+                                   C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    # ---- stage entry points; arguments are device pointers (ints) ----
+    def encode_grid(self, pos01, n, out, stream=None):
+        _check(self.lib.nrf_encode_grid(self.h, C.c_void_p(pos01), n, C.c_void_p(out), C.c_void_p(stream or 0)))
+
+    def encode_dir(self, dir01, n, out, stream=None):
+        _check(self.lib.nrf_encode_dir(self.h, C.c_void_p(dir01), n, C.c_void_p(out), C.c_void_p(stream or 0)))
+
+    def mlp_forward(self, feat, dirfeat, n, out, stream=None):
+        _check(self.lib.nrf_mlp_forward(self.h, C.c_void_p(feat), C.c_void_p(dirfeat), n, C.c_void_p(out),
+                                        C.c_void_p(stream or 0)))
+
+    def network(self, xyz, dirs, n, sigma, rgb, stream=None):
+        _check(self.lib.nrf_network(self.h, C.c_void_p(xyz), C.c_void_p(dirs), n, C.c_void_p(sigma), C.c_void_p(rgb),
+                                    C.c_void_p(stream or 0)))
+
+    def generate_rays(self, cam, pose, rays_o, rays_d, nears, fars, stream=None):
+        cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(4)
+        pose = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        _check(self.lib.nrf_generate_rays(self.h, _fptr(cam), _fptr(pose), C.c_void_p(rays_o), C.c_void_p(rays_d),
+                                          C.c_void_p(nears), C.c_void_p(fars), C.c_void_p(stream or 0)))
+
+    def march(self, rays_o, rays_d, rays_t, fars, n, n_step, xyzs, dirs, deltas, stream=None):
+        _check(self.lib.nrf_march(self.h, C.c_void_p(rays_o), C.c_void_p(rays_d), C.c_void_p(rays_t), C.c_void_p(fars),
+                                  n, n_step, C.c_void_p(xyzs), C.c_void_p(dirs), C.c_void_p(deltas),
+                                  C.c_void_p(stream or 0)))
+
+    def composite(self, sigmas, rgbs, deltas, n, n_step, rays_t, state, stream=None):
+        _check(self.lib.nrf_composite(self.h, C.c_void_p(sigmas), C.c_void_p(rgbs), C.c_void_p(deltas), n, n_step,
+                                      C.c_void_p(rays_t), C.c_void_p(state), C.c_void_p(stream or 0)))

@@ -1,0 +1,175 @@
+"""Deterministic synthetic snapshots and cameras for tests and bench.py.
+
+The reference ships neither weights (`freality.msgpack` is absent) nor a
+dataset, and there is no network, so every measurement in this repository runs
+on a seeded synthetic scene in the reference's own snapshot format
+(reference src/nerf_render.cu:431-473,
+include/nerf-cuda/nerf_network.h:424-433):
+
+  * density grid: analytic "Lego-like" occupancy (union of boxes, cylinders
+    and a sphere inside +-0.5 of the unit scene), value 1 inside, 0 outside;
+  * hash table: U(-0.5, 0.5) (tcnn's +-1e-4 init would give a blank scene);
+  * MLP weights: seeded normal weights, with the density row and the three
+    colour rows made positive and rescaled so that sigma = exp(g0) has a
+    median of ~36 (rays saturate after ~10-25 samples, like a trained solid)
+    and rgb lands in [0, 1].
+
+Cameras follow the Blender-synthetic convention the reference's `main` uses
+(camera-to-world, OpenGL axes, radius 4.0311, scene scale 0.33).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# n_params layout (reference nerf_network.h:273-291; fully_fused_mlp.cu:636-687)
+N_D0, N_D1, N_R0, N_R1, N_R2 = 64 * 32, 16 * 64, 64 * 32, 64 * 64, 16 * 64
+N_MLP = N_D0 + N_D1 + N_R0 + N_R1 + N_R2  # 10240
+
+
+def base_config(log2_hashmap_size=19, n_levels=16, base_resolution=16, sh_degree=4, rgb_output_activation="None",
+                dir_otype="SphericalHarmonics", n_frequencies=2):
+    """The four network blocks of reference configs/nerf/base.json."""
+    if dir_otype == "SphericalHarmonics":
+        dir_nested = {"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": sh_degree}
+    elif dir_otype == "Frequency":
+        dir_nested = {"n_dims_to_encode": 3, "otype": "Frequency", "n_frequencies": n_frequencies}
+    else:
+        dir_nested = {"n_dims_to_encode": 3, "otype": "Identity"}
+    return {
+        "encoding": {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+                     "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                    "n_hidden_layers": 1},
+        "dir_encoding": {"otype": "Composite", "nested": [dir_nested, {"otype": "Identity", "n_bins": 4, "degree": 4}]},
+        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": rgb_output_activation,
+                        "n_neurons": 64, "n_hidden_layers": 2},
+    }
+
+
+def _occupancy(x, y, z):
+    """Analytic occupancy in NGP coordinates (y is up)."""
+    def box(x0, x1, y0, y1, z0, z1):
+        return (x >= x0) & (x <= x1) & (y >= y0) & (y <= y1) & (z >= z0) & (z <= z1)
+
+    occ = box(-0.42, 0.42, -0.22, -0.10, -0.25, 0.25)       # chassis slab
+    occ |= box(-0.20, 0.15, -0.10, 0.15, -0.18, 0.18)       # cabin
+    occ |= box(0.42, 0.50, -0.25, 0.00, -0.30, 0.30)        # blade
+    occ |= box(-0.36, -0.30, -0.10, 0.26, -0.03, 0.03)      # exhaust / mast
+    for cx in (-0.25, 0.25):                                 # wheels: cylinders along z
+        r2 = (x - cx) ** 2 + (y + 0.25) ** 2
+        occ |= (r2 <= 0.1 ** 2) & (np.abs(z) >= 0.2) & (np.abs(z) <= 0.3)
+    occ |= ((x + 0.05) ** 2 + (y - 0.22) ** 2 + z ** 2) <= 0.09 ** 2  # beacon sphere
+    return occ
+
+
+def density_grid(H=128, cascade=1, bound=1.0):
+    """Float grid [C*H^3], index level*H^3 + x*H^2 + y*H + z (reference nerf_render.h:64-65)."""
+    out = np.zeros((cascade, H, H, H), np.float32)
+    for c in range(cascade):
+        mip_bound = min(float(2 ** c), float(bound))
+        centers = ((np.arange(H, dtype=np.float64) + 0.5) / H * 2.0 - 1.0) * mip_bound
+        half = mip_bound / H
+        occ = np.zeros((H, H, H), bool)
+        # conservative: a cell is occupied if its centre or any corner is inside
+        for ox in (-half, 0.0, half):
+            for oy in (-half, 0.0, half):
+                for oz in (-half, 0.0, half):
+                    X, Y, Z = np.meshgrid(centers + ox, centers + oy, centers + oz, indexing="ij", sparse=True)
+                    occ |= _occupancy(X, Y, Z)
+        out[c][occ] = 1.0
+    return out.reshape(-1)
+
+
+def _simulate_features(rng, n, table_amp=0.5):
+    """Marginal distribution of hash-grid features: sum_8 w_c v_c, v ~ U(+-amp), trilinear w."""
+    f = rng.random((n, 32, 3))
+    v = rng.uniform(-table_amp, table_amp, (n, 32, 8))
+    w = np.ones((n, 32, 8))
+    for c in range(8):
+        for d in range(3):
+            w[:, :, c] *= np.where((c >> d) & 1, f[:, :, d], 1.0 - f[:, :, d])
+    return (w * v).sum(-1).astype(np.float32)
+
+
+def _sh4(d):
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return np.stack([
+        np.full_like(x, 0.28209479177387814), -0.48860251190291987 * y, 0.48860251190291987 * z,
+        -0.48860251190291987 * x, 1.0925484305920792 * xy, -1.0925484305920792 * yz,
+        0.94617469575755997 * z2 - 0.31539156525251999, -1.0925484305920792 * xz,
+        0.54627421529603959 * x2 - 0.54627421529603959 * y2, 0.59004358992664352 * y * (-3.0 * x2 + y2),
+        2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2)], axis=1).astype(np.float32)
+
+
+def mlp_weights(seed=1337, sigma_log_median=3.6, rgb_mean=0.5):
+    """The 10240 MLP parameters, calibrated on simulated inputs (fp32 numpy)."""
+    rng = np.random.default_rng(seed)
+    D0 = rng.normal(0.0, 0.5, (64, 32)).astype(np.float32)
+    D1 = rng.normal(0.0, 0.3, (16, 64)).astype(np.float32)
+    D1[0] = rng.uniform(0.0, 1.0, 64)                      # density row: positive -> g0 > 0
+    R0 = rng.normal(0.0, 0.25, (64, 32)).astype(np.float32)
+    R1 = rng.normal(0.0, 0.2, (64, 64)).astype(np.float32)
+    R2 = rng.normal(0.0, 0.2, (16, 64)).astype(np.float32)
+    R2[:3] = np.abs(rng.normal(0.0, 0.2, (3, 64)))         # colour rows: positive
+    feat = _simulate_features(rng, 4096)
+    h = np.maximum(feat @ D0.T, 0.0)
+    D1[0] *= sigma_log_median / float((h @ D1[0]).mean())
+    g = h @ D1.T
+    dirs = rng.normal(size=(4096, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    rin = np.concatenate([g, _sh4(dirs)], axis=1).astype(np.float32)
+    h2 = np.maximum(np.maximum(rin @ R0.T, 0.0) @ R1.T, 0.0)
+    for c in range(3):
+        R2[c] *= rgb_mean / float((h2 @ R2[c]).mean())
+    return np.concatenate([m.reshape(-1) for m in (D0, D1, R0, R1, R2)]).astype(np.float32)
+
+
+def make_scene(n_grid_params, seed=1337, H=128, cascade=1, bound=1.0, scale=0.33, config=None):
+    """Returns (config dict with a `snapshot` block but without the two big arrays,
+    params float32 [n_params], density_grid float32 [C*H^3]).  `n_grid_params` is the
+    number of hash-table values (2 * total entries), which depends on the level table."""
+    cfg = dict(config or base_config())
+    rng = np.random.default_rng(seed + 1)
+    table = rng.uniform(-0.5, 0.5, n_grid_params).astype(np.float32)
+    params = np.concatenate([mlp_weights(seed), table])
+    grid = density_grid(H, cascade, bound)
+    cfg["snapshot"] = {
+        "aabb": [-bound, -bound, -bound, bound, bound, bound],
+        "bound": float(bound), "scale": float(scale), "cascade": int(cascade), "density_grid_size": int(H),
+        "mean_density": float(grid.mean()),
+    }
+    return cfg, params, grid
+
+
+# --------------------------------------------------------------------------- cameras
+def orbit_pose(azimuth_deg, elevation_deg=30.0, radius=4.0311):
+    """Blender/NeRF camera-to-world (OpenGL axes: x right, y up, z backward), z-up world,
+    looking at the origin.  Row-major 4x4."""
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    pos = np.array([radius * math.cos(el) * math.cos(az), radius * math.cos(el) * math.sin(az), radius * math.sin(el)])
+    zc = pos / np.linalg.norm(pos)                       # camera backward axis
+    xc = np.cross(np.array([0.0, 0.0, 1.0]), zc)
+    xc /= np.linalg.norm(xc)
+    yc = np.cross(zc, xc)
+    m = np.eye(4, dtype=np.float64)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = xc, yc, zc, pos
+    return m.astype(np.float32)
+
+
+def default_camera(width, height, fov_x=0.6911112070083618):
+    """{fl_x, fl_y, cx, cy} (reference common.h:68-74).  Blender-synthetic field of view applied
+    to the SHORTER image side so the object stays in frame at 16:9."""
+    fl = 0.5 * min(width, height) / math.tan(0.5 * fov_x)
+    return np.array([fl, fl, width * 0.5, height * 0.5], np.float32)
+
+
+REFERENCE_MAIN_POSE = np.array([  # the hard-coded pose of reference src/main.cu:152-155 / render_server.cu:53-56
+    [-0.5575427361517304, -0.11682263918046752, 0.8218871992959822, 3.9673954052389253],
+    [0.8300327085486383, -0.094966079921629, 0.5495699649760266, 2.667431152445114],
+    [0.013849191732089516, 0.9886020001326434, 0.14991425965987268, 0.45955395816033995],
+    [0.0, 0.0, 0.0, 1.0]], np.float32)

@@ -1,0 +1,821 @@
+// nerf_oracle.cpp -- CPU restatement of the reference hot path (see nerf_oracle.h).
+// TEST INFRASTRUCTURE ONLY; parity unpinned (no reference fixtures exist).
+//
+// Every function cites the reference file:line it follows.  R/ = the
+// reference repo, T/ = R/dependencies/tiny-cuda-nn.
+// Build: oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
+
+#include "nerf_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+// ---------------------------------------------------------------- fp16 ----
+// IEEE binary16 <-> binary32, round-to-nearest-even, subnormals kept.
+inline uint16_t f2h(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) {  // inf / nan
+    return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? (0x0200u | ((x >> 13) & 0x3ffu)) : 0u));
+  }
+  if (x >= 0x477ff000u) {  // >= 65520 rounds to inf
+    return (uint16_t)(sign | 0x7c00u);
+  }
+  if (x < 0x38800000u) {  // below the smallest normal half (2^-14): subnormal or zero
+    if (x < 0x33000000u) return (uint16_t)sign;  // < 2^-25 -> 0 (2^-25 itself ties to even = 0)
+    const int e = (int)(x >> 23);                // biased exponent, 102..112
+    uint32_t mant = (x & 0x7fffffu) | 0x800000u; // 24-bit significand
+    const int shift = 126 - e;                   // 14..24: value = mant * 2^(e-150); half sub unit 2^-24
+    const uint32_t q = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    uint32_t r = q;
+    if (rem > half || (rem == half && (q & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  // normal
+  uint32_t mant = x & 0x7fffffu;
+  uint32_t e = (x >> 23) - 112u;  // half biased exponent
+  uint32_t r = (e << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;  // carries into exponent correctly
+  return (uint16_t)(sign | r);
+}
+
+inline float h2f(uint16_t h) {
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1fu;
+  const uint32_t m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) {
+      x = sign;
+    } else {  // subnormal: m * 2^-24
+      float f = (float)m * 5.9604644775390625e-08f;
+      std::memcpy(&x, &f, 4);
+      x |= sign;
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+// fp16 addition: exact via fp32 (24 >= 2*11+2 bits, so double rounding is innocuous).
+inline uint16_t hadd(uint16_t a, uint16_t b) { return f2h(h2f(a) + h2f(b)); }
+
+// ---------------------------------------------------------- activations ----
+// T/include/tiny-cuda-nn/common_device.h:68-114 (warp_activation), applied to
+// an fp32 pre-activation; the caller rounds the result to fp16.
+inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+inline float activate(uint32_t act, float v) {
+  switch (act) {
+    case NRF_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case NRF_ACT_EXPONENTIAL: return expf(v);
+    case NRF_ACT_SIGMOID: return logistic(v);
+    case NRF_ACT_SQUAREPLUS: {
+      const float x = v * 10.0f;
+      return 0.5f * (x + sqrtf(x * x + 4)) / 10.0f;
+    }
+    case NRF_ACT_SOFTPLUS: return logf(expf(v * 10.0f) + 1.0f) / 10.0f;
+    case NRF_ACT_SINE: return sinf(v);
+    default: return v;
+  }
+}
+
+inline uint32_t next_multiple(uint32_t v, uint32_t d) { return (v + d - 1) / d * d; }
+
+}  // namespace
+
+// ------------------------------------------------------------ the model ----
+struct nrfo_model {
+  nrf_model_desc d;
+  nrf_level_table lv;
+  uint32_t feat_width;     // 2L padded to 16 (nerf_network.h:103-111)
+  uint32_t dir_width;      // padded dir encoding width (alignment 16)
+  uint32_t dir_raw;        // unpadded
+  uint32_t rgb_in;         // nerf_network.h:127-130
+  uint32_t W;              // n_neurons
+  std::vector<std::vector<float>> dens_w;  // per layer, fp16-rounded values as float, [out][in]
+  std::vector<std::vector<float>> rgb_w;
+  std::vector<uint32_t> dens_dims, rgb_dims;  // layer widths: in, W, ..., 16
+  std::vector<uint16_t> grid;                 // fp16 table
+  std::vector<float> density_grid;
+};
+
+extern "C" {
+
+const char* nrfo_last_error(void) { return g_err.c_str(); }
+uint16_t nrfo_f32_to_f16(float f) { return f2h(f); }
+float nrfo_f16_to_f32(uint16_t h) { return h2f(h); }
+int nrfo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// R/include/nerf-cuda/render_utils.h:68-77
+void nrfo_nerf_matrix_to_ngp(const float p[16], float s, float o[16]) {
+  // rows (1,2,0) of the input, columns 1 and 2 negated, translation scaled (+ offset 0)
+  const int rows[3] = {1, 2, 0};
+  for (int r = 0; r < 3; ++r) {
+    const float* src = p + 4 * rows[r];
+    o[4 * r + 0] = src[0];
+    o[4 * r + 1] = -src[1];
+    o[4 * r + 2] = -src[2];
+    o[4 * r + 3] = src[3] * s + 0.0f;
+  }
+  o[12] = 0;
+  o[13] = 0;
+  o[14] = 0;
+  o[15] = 1;
+}
+
+// T/include/tiny-cuda-nn/encodings/grid.h:81-98 for N_DIMS = 3
+uint32_t nrfo_fast_hash3(uint32_t x, uint32_t y, uint32_t z) {
+  return (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+}
+
+}  // extern "C"
+
+namespace {
+
+// T/include/tiny-cuda-nn/encodings/grid.h:899-931 (ctor) and :186-190 (kernel)
+int level_table(const nrf_model_desc& d, nrf_level_table& t) {
+  if (d.n_levels == 0 || d.n_levels > 16) return fail(NRF_E_UNSUPPORTED, "n_levels must be 1..16");
+  t.n_levels = d.n_levels;
+  const float log2_pls = std::log2(d.per_level_scale);  // float overload, as std::log2(float)
+  uint32_t offset = 0;
+  for (uint32_t i = 0; i < d.n_levels; ++i) {
+    const float scale = exp2f((float)i * log2_pls) * (float)d.base_resolution - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const uint32_t max_params = std::numeric_limits<uint32_t>::max() / 2;
+    uint32_t params = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+    params = next_multiple(params, 8u);
+    if (d.grid_type == NRF_GRID_TILED) {
+      params = std::min(params, d.base_resolution * d.base_resolution * d.base_resolution);
+    } else if (d.grid_type == NRF_GRID_HASH) {
+      params = std::min(params, 1u << d.log2_hashmap_size);
+    }
+    t.offset[i] = offset;
+    t.resolution[i] = res;
+    t.scale[i] = scale;
+    offset += params;
+  }
+  t.offset[d.n_levels] = offset;
+  return NRF_OK;
+}
+
+// T/src/fully_fused_mlp.cu:636-687: first [W x in], (h-1) x [W x W], last [padded_out x W]
+void mlp_dims(uint32_t in, uint32_t W, uint32_t hidden, std::vector<uint32_t>& dims) {
+  dims.clear();
+  dims.push_back(in);
+  for (uint32_t i = 0; i < hidden; ++i) dims.push_back(W);
+  dims.push_back(16);
+}
+uint64_t mlp_params(const std::vector<uint32_t>& dims) {
+  uint64_t n = 0;
+  for (size_t i = 0; i + 1 < dims.size(); ++i) n += (uint64_t)dims[i] * dims[i + 1];
+  return n;
+}
+
+int dir_widths(const nrf_model_desc& d, uint32_t& raw, uint32_t& padded) {
+  switch (d.dir_encoding) {
+    case NRF_DIR_SH:
+      if (d.sh_degree < 1 || d.sh_degree > 4) return fail(NRF_E_UNSUPPORTED, "oracle: SH degree must be 1..4");
+      raw = d.sh_degree * d.sh_degree;
+      break;
+    case NRF_DIR_FREQUENCY: raw = 3 * d.n_frequencies * 2; break;
+    case NRF_DIR_IDENTITY: raw = 3; break;
+    default: return fail(NRF_E_UNSUPPORTED, "unknown dir encoding");
+  }
+  padded = next_multiple(raw, 16u);  // T/src/encoding.cu:97-117 with alignment 16
+  return NRF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
+  if (!d || !out || !d->params || !d->density_grid) return fail(NRF_E_INVALID, "null argument");
+  if (d->n_features_per_level != 2) return fail(NRF_E_UNSUPPORTED, "oracle: n_features_per_level must be 2");
+  nrfo_model* m = new nrfo_model;
+  m->d = *d;
+  int rc = level_table(*d, m->lv);
+  if (rc) { delete m; return rc; }
+  rc = dir_widths(*d, m->dir_raw, m->dir_width);
+  if (rc) { delete m; return rc; }
+  m->W = d->n_neurons;
+  m->feat_width = next_multiple(d->n_levels * 2, 16u);
+  m->rgb_in = next_multiple(m->dir_width + 16u, 16u);
+  mlp_dims(m->feat_width, m->W, d->density_hidden_layers, m->dens_dims);
+  mlp_dims(m->rgb_in, m->W, d->rgb_hidden_layers, m->rgb_dims);
+  const uint64_t n_grid = (uint64_t)m->lv.offset[d->n_levels] * 2;
+  const uint64_t expect = mlp_params(m->dens_dims) + mlp_params(m->rgb_dims) + n_grid;
+  if (d->n_params != expect) {  // R/include/nerf-cuda/nerf_network.h:425-427
+    delete m;
+    return fail(NRF_E_PARAMS, "Can't set params because number of parameters and model size do not match");
+  }
+  const uint64_t H = d->density_grid_size;
+  if (d->n_density_grid != H * H * H * d->cascade) {  // R/src/nerf_render.cu:467-469
+    delete m;
+    return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
+  }
+  // deserialize: fp32 -> fp16 cast of every parameter (nerf_network.h:434-436),
+  // order density MLP | rgb MLP | grid (nerf_network.h:273-291)
+  const float* p = d->params;
+  auto take = [&](const std::vector<uint32_t>& dims, std::vector<std::vector<float>>& w) {
+    w.resize(dims.size() - 1);
+    for (size_t l = 0; l + 1 < dims.size(); ++l) {
+      const size_t n = (size_t)dims[l] * dims[l + 1];
+      w[l].resize(n);
+      for (size_t i = 0; i < n; ++i) w[l][i] = h2f(f2h(p[i]));
+      p += n;
+    }
+  };
+  take(m->dens_dims, m->dens_w);
+  take(m->rgb_dims, m->rgb_w);
+  m->grid.resize(n_grid);
+  for (uint64_t i = 0; i < n_grid; ++i) m->grid[i] = f2h(p[i]);
+  m->density_grid.assign(d->density_grid, d->density_grid + d->n_density_grid);
+  m->d.params = nullptr;
+  m->d.density_grid = nullptr;
+  *out = m;
+  return NRF_OK;
+}
+
+void nrfo_destroy(nrfo_model* m) { delete m; }
+
+// T/include/tiny-cuda-nn/encodings/grid.h:100-117
+uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32_t y, uint32_t z) {
+  const uint32_t hashmap_size = m->lv.offset[level + 1] - m->lv.offset[level];
+  const uint32_t res = m->lv.resolution[level];
+  const uint32_t pg[3] = {x, y, z};
+  uint32_t stride = 1, index = 0;
+  for (uint32_t dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
+    index += pg[dim] * stride;
+    stride *= res;
+  }
+  if (m->d.grid_type == NRF_GRID_HASH && hashmap_size < stride) index = nrfo_fast_hash3(x, y, z);
+  return index % hashmap_size;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One sample of kernel_grid<half,3,2>: T/include/tiny-cuda-nn/encodings/grid.h:186-267,
+// pos_fract: T/include/tiny-cuda-nn/common_device.h:414-422 (Linear interpolation).
+void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
+  const uint32_t L = m->d.n_levels;
+  for (uint32_t level = 0; level < L; ++level) {
+    const float scale = m->lv.scale[level];
+    float pos[3];
+    uint32_t pg[3];
+    for (int dim = 0; dim < 3; ++dim) {
+      float v = p01[dim] * scale;
+      v = v + 0.5f;
+      const int tmp = (int)floorf(v);
+      pg[dim] = (uint32_t)tmp;
+      pos[dim] = v - (float)tmp;
+    }
+    const uint16_t* table = m->grid.data() + (size_t)m->lv.offset[level] * 2;
+    uint16_t r0 = 0, r1 = 0;  // fp16 accumulators, grid.h:236
+    for (uint32_t idx = 0; idx < 8; ++idx) {
+      float weight = 1;
+      uint32_t pl[3];
+      for (int dim = 0; dim < 3; ++dim) {
+        if ((idx & (1u << dim)) == 0) {
+          weight *= 1 - pos[dim];
+          pl[dim] = pg[dim];
+        } else {
+          weight *= pos[dim];
+          pl[dim] = pg[dim] + 1;
+        }
+      }
+      const uint32_t e = nrfo_grid_index(m, level, pl[0], pl[1], pl[2]);
+      const float d0 = h2f(table[2 * e + 0]);
+      const float d1 = h2f(table[2 * e + 1]);
+      r0 = hadd(r0, f2h(weight * d0));  // grid.h:260: result += (T)(weight * data)
+      r1 = hadd(r1, f2h(weight * d1));
+    }
+    out[2 * level + 0] = r0;
+    out[2 * level + 1] = r1;
+  }
+  for (uint32_t j = 2 * L; j < m->feat_width; ++j) out[j] = f2h(1.0f);  // alignment padding
+}
+
+// T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:57-96 (degree <= 4),
+// T/include/tiny-cuda-nn/encodings/frequency.h:56-92, identity.h:64-65.
+void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
+  const nrf_model_desc& d = m->d;
+  const uint32_t pad = m->dir_width - m->dir_raw;
+  if (d.dir_encoding == NRF_DIR_SH) {
+    uint16_t* o = out;
+    for (uint32_t j = 0; j < pad; ++j) *o++ = f2h(1.0f);  // SH pads in FRONT (:57-64)
+    const float x = d01[0] * 2.f - 1.f, y = d01[1] * 2.f - 1.f, z = d01[2] * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float c[16];
+    c[0] = 0.28209479177387814f;
+    c[1] = -0.48860251190291987f * y;
+    c[2] = 0.48860251190291987f * z;
+    c[3] = -0.48860251190291987f * x;
+    c[4] = 1.0925484305920792f * xy;
+    c[5] = -1.0925484305920792f * yz;
+    c[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    c[7] = -1.0925484305920792f * xz;
+    c[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    c[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    c[10] = 2.8906114426405538f * xy * z;
+    c[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    c[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    c[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    c[14] = 1.4453057213202769f * z * (x2 - y2);
+    c[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    for (uint32_t j = 0; j < m->dir_raw; ++j) o[j] = f2h(c[j]);
+  } else if (d.dir_encoding == NRF_DIR_FREQUENCY) {
+    const float PI = 3.14159265358979323846f;
+    const uint32_t nf = d.n_frequencies;
+    for (uint32_t j = 0; j < m->dir_raw; ++j) {
+      const uint32_t feat = j / (nf * 2);
+      const uint32_t log2_frequency = (j / 2) % nf;
+      const float phase_shift = (float)(j % 2) * (PI / 2);
+      const float x = scalbnf(d01[feat], (int)log2_frequency);
+      const float input = x * PI + phase_shift;
+      out[j] = f2h(sinf(input));  // reference uses __sinf (approximate); tolerance applies
+    }
+    for (uint32_t j = m->dir_raw; j < m->dir_width; ++j) out[j] = f2h(1.0f);  // trailing pad
+  } else {  // Identity, scale 1 offset 0
+    for (uint32_t j = 0; j < 3; ++j) out[j] = f2h(d01[j]);
+    for (uint32_t j = 3; j < m->dir_width; ++j) out[j] = f2h(1.0f);
+  }
+}
+
+// y = act(W x) chains, T/src/fully_fused_mlp.cu:500-558.  fp16 in, fp32
+// accumulate in ascending k, activation on the fp32 sum, fp16 store per layer.
+void mlp_one(const std::vector<std::vector<float>>& w, const std::vector<uint32_t>& dims,
+             uint32_t act, uint32_t out_act, const float* in, float* out /*16, fp16-rounded*/) {
+  float buf0[128], buf1[128];
+  const float* cur = in;
+  float* nxt = buf0;
+  const size_t nl = dims.size() - 1;
+  for (size_t l = 0; l < nl; ++l) {
+    const uint32_t K = dims[l], N = dims[l + 1];
+    const float* W = w[l].data();
+    const bool last = (l + 1 == nl);
+    float* dst = last ? out : nxt;
+    for (uint32_t o = 0; o < N; ++o) {
+      float acc = 0.0f;
+      const float* row = W + (size_t)o * K;
+      for (uint32_t k = 0; k < K; ++k) acc += row[k] * cur[k];
+      dst[o] = h2f(f2h(activate(last ? out_act : act, acc)));
+    }
+    cur = dst;
+    nxt = (dst == buf0) ? buf1 : buf0;
+  }
+}
+
+// R/include/nerf-cuda/nerf_network.h:148-196 for one sample on encoded inputs.
+// out4 = (r, g, b, sigma) as fp16 bits: rows 0..2 and 3 of network_output.
+void network_encoded_one(const nrfo_model* m, const uint16_t* feat, const uint16_t* dirfeat,
+                         uint16_t* out4) {
+  float in[128], dens[16], rgbin[128], rgb[16];
+  for (uint32_t j = 0; j < m->feat_width; ++j) in[j] = h2f(feat[j]);
+  mlp_one(m->dens_w, m->dens_dims, m->d.density_activation, m->d.density_output_activation, in, dens);
+  for (uint32_t j = 0; j < 16; ++j) rgbin[j] = dens[j];  // rows 0..15 (nerf_network.h:162-164)
+  for (uint32_t j = 0; j < m->dir_width; ++j) rgbin[16 + j] = h2f(dirfeat[j]);  // rows 16.. (:177-182)
+  mlp_one(m->rgb_w, m->rgb_dims, m->d.rgb_activation, m->d.rgb_output_activation, rgbin, rgb);
+  out4[0] = f2h(rgb[0]);
+  out4[1] = f2h(rgb[1]);
+  out4[2] = f2h(rgb[2]);
+  // extract_density, nerf_network.h:49-61 + wrap_a_activation :32-47: fp32 math, fp16 store
+  float s = dens[0];
+  switch (m->d.sigma_activation) {
+    case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
+    case NRF_ACT_EXPONENTIAL: s = expf(s); break;
+    case NRF_ACT_SIGMOID: s = logistic(s); break;
+    default: break;  // wrap_a_activation returns the value unchanged otherwise
+  }
+  out4[3] = f2h(s);
+}
+
+// Affine maps R/src/nerf_render.cu:311-314 + network + decompose (render_utils.h:308-334)
+// (+ density scale nerf_render.cu:328, as a float multiply: DESIGN.md deviation D-8).
+void network_one(const nrfo_model* m, float density_scale, const float xyz[3], const float dir[3],
+                 float* sigma, float* rgb) {
+  const float wpos = (float)(1.0 / (2 * (double)m->d.bound));  // `1.0/(2 * m_bound)` -> float arg
+  float p01[3], d01[3];
+  for (int c = 0; c < 3; ++c) {
+    float v = wpos * xyz[c];
+    p01[c] = v + 0.5f;
+    float u = 0.5f * dir[c];
+    d01[c] = u + 0.5f;
+  }
+  uint16_t feat[64], dirfeat[64], out4[4];
+  encode_grid_one(m, p01, feat);
+  encode_dir_one(m, d01, dirfeat);
+  network_encoded_one(m, feat, dirfeat, out4);
+  rgb[0] = h2f(out4[0]);
+  rgb[1] = h2f(out4[1]);
+  rgb[2] = h2f(out4[2]);
+  float s = h2f(out4[3]);
+  if (density_scale != 1.0f) s = density_scale * s;
+  *sigma = s;
+}
+
+inline float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// set_rays_d (render_utils.h:31-52): Eigen's fixed-size reductions are
+// unrolled as a + (b + c) (redux_novec_unroller splits [0,1) | [1,3)).
+inline void ray_dir(const float R[9], const float cam[4], int px, int py, float d[3]) {
+  const float i = (float)((double)px + 0.5);
+  const float j = (float)((double)py + 0.5);
+  const float zs = 1;
+  const float xs = (i - cam[2]) / cam[0] * zs;
+  const float ys = (j - cam[3]) / cam[1] * zs;
+  const float n = sqrtf(xs * xs + (ys * ys + zs * zs));
+  const float v[3] = {xs / n, ys / n, zs / n};
+  for (int r = 0; r < 3; ++r) d[r] = R[3 * r + 0] * v[0] + (R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2]);
+}
+
+// kernel_near_far_from_aabb, render_utils.h:353-391
+inline void near_far(const float* aabb, const float o[3], const float d[3], float min_near,
+                     float* near_out, float* far_out) {
+  const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+  float near = (aabb[0] - o[0]) * rdx, far = (aabb[3] - o[0]) * rdx;
+  if (near > far) std::swap(near, far);
+  float near_y = (aabb[1] - o[1]) * rdy, far_y = (aabb[4] - o[1]) * rdy;
+  if (near_y > far_y) std::swap(near_y, far_y);
+  if (near > far_y || near_y > far) {
+    *near_out = *far_out = FLT_MAX;
+    return;
+  }
+  if (near_y > near) near = near_y;
+  if (far_y < far) far = far_y;
+  float near_z = (aabb[2] - o[2]) * rdz, far_z = (aabb[5] - o[2]) * rdz;
+  if (near_z > far_z) std::swap(near_z, far_z);
+  if (near > far_z || near_z > far) {
+    *near_out = *far_out = FLT_MAX;
+    return;
+  }
+  if (near_z > near) near = near_z;
+  if (far_z < far) far = far_z;
+  if (near < min_near) near = min_near;
+  *near_out = near;
+  *far_out = far;
+}
+
+// kernel_march_rays for one ray, render_utils.h:556-653.  Returns the number
+// of emitted samples; xyz[k][3], delta[k][2].  *t_io is the march's own t.
+inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3], const float d[3],
+                          float far, float t, uint32_t n_step, float* xyz, float* delta) {
+  const float bound = m->d.bound;
+  const uint32_t C = m->d.cascade, H = m->d.density_grid_size;
+  const float* grid = m->density_grid.data();
+  const float density_thresh = fminf(0.01f, m->d.mean_density);  // :560
+  const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+  const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+  const float dt_min = 2 * 1.7320508075688772f / 1024;  // MIN_STEPSIZE :181-183
+  const float dt_max = 2 * bound / (float)H;
+  const float Hm1 = (float)(H - 1);
+  uint32_t step = 0;
+  float last_t = t;
+  while (t < far && step < n_step) {
+    const float x = clampf(ox + t * dx, -bound, bound);
+    const float y = clampf(oy + t * dy, -bound, bound);
+    const float z = clampf(oz + t * dz, -bound, bound);
+    // mip_from_pos :148-155
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    const int level = (int)fminf((float)C - 1, fmaxf(0, (float)exponent));
+    const float mip_bound = fminf(exp2f((float)level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic on a float operand, narrowed to float
+    const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const uint32_t index = (uint32_t)level * H * H * H + (uint32_t)nx * H * H + (uint32_t)ny * H + (uint32_t)nz;
+    const float density = grid[index];
+    if (density > density_thresh) {
+      xyz[3 * step + 0] = x;
+      xyz[3 * step + 1] = y;
+      xyz[3 * step + 2] = z;
+      const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+      t += dt;
+      delta[2 * step + 0] = dt;
+      delta[2 * step + 1] = t - last_t;
+      last_t = t;
+      step++;
+    } else {
+      const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / Hm1 * 2 - 1) * mip_bound - x) * rdx;
+      const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / Hm1 * 2 - 1) * mip_bound - y) * rdy;
+      const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / Hm1 * 2 - 1) * mip_bound - z) * rdz;
+      const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+      do {
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        t += dt;
+      } while (t < tt);
+    }
+  }
+  return step;
+}
+
+// kernel_composite_rays for one ray, render_utils.h:679-749.  st = (ws, depth, r, g, b).
+// Returns the new rays_t (-1 = dead).
+inline float composite_one(const float* sigmas, const float* rgbs, const float* deltas,
+                           uint32_t n_step, float t, float* st) {
+  float weight_sum = st[0], dd = st[1], r = st[2], g = st[3], b = st[4];
+  uint32_t step = 0;
+  while (step < n_step) {
+    if (deltas[2 * step] == 0) break;
+    const float alpha = 1.0f - expf(-sigmas[step] * deltas[2 * step]);  // reference: __expf
+    const float T = 1 - weight_sum;
+    const float weight = alpha * T;
+    weight_sum += weight;
+    t += deltas[2 * step + 1];
+    dd += weight * t;
+    r += weight * rgbs[3 * step + 0];
+    g += weight * rgbs[3 * step + 1];
+    b += weight * rgbs[3 * step + 2];
+    if ((double)T < 1e-4) break;  // `T < 1e-4` compares against a double literal
+    step++;
+  }
+  st[0] = weight_sum;
+  st[1] = dd;
+  st[2] = r;
+  st[3] = g;
+  st[4] = b;
+  return step < n_step ? -1.0f : t;
+}
+
+struct RayState {
+  float o[3], d[3], near, far;
+  float st[5];
+  float t;
+};
+
+// The loop of R/src/nerf_render.cu:269-338 over one group of rays.
+// n_total plays the role of N (n_step = clamp(N/num_alive,1,8)).
+// skip_missed (TILE64 schedule only): rays with near >= far never enter the
+// alive list; they would emit no sample and die in their first composite, so
+// the image is unchanged.
+void render_group(const nrfo_model* m, const nrf_options* opt, std::vector<RayState>& rays,
+                  bool parallel, bool skip_missed, uint64_t* n_samples, uint64_t* n_rounds) {
+  const int N = (int)rays.size();
+  std::vector<int> alive, next;
+  alive.reserve(N);
+  for (int i = 0; i < N; ++i) {
+    rays[i].t = rays[i].near;   // init_step0, render_utils.h:221-239
+    if (!skip_missed || rays[i].near < rays[i].far) alive.push_back(i);
+  }
+  next.reserve(N);
+  int step = 0;
+  uint64_t samples = 0, rounds = 0;
+  bool first = true;
+  while (true) {
+    if (step >= opt->max_steps) break;  // :270
+    if (!first) {  // kernel_compact_rays :394-415 (stable order here; order is immaterial)
+      next.clear();
+      for (int id : alive)
+        if (rays[id].t >= 0) next.push_back(id);
+      alive.swap(next);
+    }
+    first = false;
+    const int num_alive = (int)alive.size();
+    if (num_alive <= 0) break;  // :294
+    const int n_step = std::max(std::min(N / num_alive, 8), 1);  // :300
+    uint64_t round_samples = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : round_samples) if (parallel)
+    for (int a = 0; a < num_alive; ++a) {
+      RayState& r = rays[alive[a]];
+      float xyz[8 * 3], delta[8 * 2], sig[8], rgb[8 * 3];
+      for (int k = 0; k < n_step; ++k) delta[2 * k] = delta[2 * k + 1] = 0.0f;  // deviation D-1
+      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, (uint32_t)n_step, xyz, delta);
+      for (uint32_t k = 0; k < cnt; ++k) network_one(m, opt->density_scale, xyz + 3 * k, r.d, sig + k, rgb + 3 * k);
+      for (uint32_t k = cnt; k < (uint32_t)n_step; ++k) sig[k] = rgb[3 * k] = rgb[3 * k + 1] = rgb[3 * k + 2] = 0.0f;
+      r.t = composite_one(sig, rgb, delta, (uint32_t)n_step, r.t, r.st);
+      round_samples += cnt;
+    }
+    samples += round_samples;
+    rounds++;
+    step += n_step;  // :336
+  }
+  *n_samples += samples;
+  *n_rounds += rounds;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrfo_encode_grid(const nrfo_model* m, const float* pos01, uint32_t n, uint16_t* out) {
+  if (!m || !pos01 || !out) return fail(NRF_E_INVALID, "null argument");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) encode_grid_one(m, pos01 + 3 * i, out + (size_t)m->feat_width * i);
+  return NRF_OK;
+}
+
+int nrfo_encode_dir(const nrfo_model* m, const float* dir01, uint32_t n, uint16_t* out) {
+  if (!m || !dir01 || !out) return fail(NRF_E_INVALID, "null argument");
+  for (uint32_t i = 0; i < n; ++i) encode_dir_one(m, dir01 + 3 * i, out + (size_t)m->dir_width * i);
+  return NRF_OK;
+}
+
+int nrfo_mlp_forward(const nrfo_model* m, const uint16_t* feat, const uint16_t* dirfeat, uint32_t n,
+                     uint16_t* out4) {
+  if (!m || !feat || !dirfeat || !out4) return fail(NRF_E_INVALID, "null argument");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i)
+    network_encoded_one(m, feat + (size_t)m->feat_width * i, dirfeat + (size_t)m->dir_width * i, out4 + 4 * i);
+  return NRF_OK;
+}
+
+int nrfo_network(const nrfo_model* m, const float* xyz, const float* dir, uint32_t n, float* sigma,
+                 float* rgb) {
+  if (!m || !xyz || !dir || !sigma || !rgb) return fail(NRF_E_INVALID, "null argument");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) network_one(m, 1.0f, xyz + 3 * i, dir + 3 * i, sigma + i, rgb + 3 * i);
+  return NRF_OK;
+}
+
+int nrfo_generate_rays(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H,
+                       const nrf_options* o, float* rays_o, float* rays_d, float* nears, float* fars) {
+  if (!m || !cam || !pose || !o) return fail(NRF_E_INVALID, "null argument");
+  float np[16];
+  nrfo_nerf_matrix_to_ngp(pose, m->d.scale, np);
+  const float R[9] = {np[0], np[1], np[2], np[4], np[5], np[6], np[8], np[9], np[10]};
+  const float org[3] = {np[3], np[7], np[11]};
+  for (int py = 0; py < H; ++py)
+    for (int px = 0; px < W; ++px) {
+      const size_t i = (size_t)py * W + px;
+      float d[3], nr, fr;
+      ray_dir(R, cam, px, py, d);
+      near_far(m->d.aabb, org, d, o->min_near, &nr, &fr);
+      if (rays_o) { rays_o[3 * i] = org[0]; rays_o[3 * i + 1] = org[1]; rays_o[3 * i + 2] = org[2]; }
+      if (rays_d) { rays_d[3 * i] = d[0]; rays_d[3 * i + 1] = d[1]; rays_d[3 * i + 2] = d[2]; }
+      if (nears) nears[i] = nr;
+      if (fars) fars[i] = fr;
+    }
+  return NRF_OK;
+}
+
+int nrfo_march(const nrfo_model* m, const nrf_options* o, const float* rays_o, const float* rays_d,
+               const float* rays_t, const float* fars, uint32_t n, uint32_t n_step, float* xyzs,
+               float* dirs, float* deltas) {
+  if (!m || !o || n_step < 1 || n_step > 8) return fail(NRF_E_INVALID, "bad argument");
+  for (uint32_t i = 0; i < n; ++i) {
+    float* xyz = xyzs + (size_t)i * n_step * 3;
+    float* dl = deltas + (size_t)i * n_step * 2;
+    float* dr = dirs + (size_t)i * n_step * 3;
+    std::fill(xyz, xyz + n_step * 3, 0.0f);
+    std::fill(dl, dl + n_step * 2, 0.0f);
+    std::fill(dr, dr + n_step * 3, 0.0f);
+    const uint32_t cnt = march_one(m, o->dt_gamma, rays_o + 3 * i, rays_d + 3 * i, fars[i], rays_t[i], n_step, xyz, dl);
+    for (uint32_t k = 0; k < cnt; ++k)
+      for (int c = 0; c < 3; ++c) dr[3 * k + c] = rays_d[3 * i + c];
+  }
+  return NRF_OK;
+}
+
+int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, uint32_t n,
+                   uint32_t n_step, float* rays_t, float* state) {
+  for (uint32_t i = 0; i < n; ++i)
+    rays_t[i] = composite_one(sigmas + (size_t)i * n_step, rgbs + (size_t)i * n_step * 3,
+                              deltas + (size_t)i * n_step * 2, n_step, rays_t[i], state + 5 * (size_t)i);
+  return NRF_OK;
+}
+
+int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H,
+                const nrf_options* o, int schedule, int n_threads, float* rgba, float* depth,
+                nrf_stats* stats) {
+  if (!m || !cam || !pose || !o || !rgba || !depth || W <= 0 || H <= 0) return fail(NRF_E_INVALID, "bad argument");
+  if (o->perturb) return fail(NRF_E_UNSUPPORTED, "perturb not implemented");
+#ifdef _OPENMP
+  const int saved = omp_get_max_threads();
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+  (void)n_threads;
+#endif
+  float np[16];
+  nrfo_nerf_matrix_to_ngp(pose, m->d.scale, np);
+  const float R[9] = {np[0], np[1], np[2], np[4], np[5], np[6], np[8], np[9], np[10]};
+  const float org[3] = {np[3], np[7], np[11]};
+  uint64_t n_samples = 0, n_rounds = 0;
+
+  auto init_ray = [&](RayState& r, int px, int py) {
+    r.o[0] = org[0]; r.o[1] = org[1]; r.o[2] = org[2];
+    ray_dir(R, cam, px, py, r.d);
+    near_far(m->d.aabb, r.o, r.d, o->min_near, &r.near, &r.far);
+    for (float& v : r.st) v = 0.0f;  // zero fills nerf_render.cu:262-264
+  };
+  // get_image_and_depth, render_utils.h:257-264; deviation D-3: a ray that
+  // misses the aabb (near == far) gets depth 0 instead of 0/0.
+  auto finish = [&](const RayState& r, int px, int py) {
+    const size_t i = (size_t)py * W + px;
+    const float bg = o->bg_color;
+    rgba[4 * i + 0] = r.st[2] + (1 - r.st[0]) * bg;
+    rgba[4 * i + 1] = r.st[3] + (1 - r.st[0]) * bg;
+    rgba[4 * i + 2] = r.st[4] + (1 - r.st[0]) * bg;
+    rgba[4 * i + 3] = r.st[0];
+    const float span = r.far - r.near;
+    depth[i] = span > 0.0f ? fmaxf(r.st[1] - r.near, 0.0f) / span : 0.0f;
+  };
+
+  if (schedule == NRFO_SCHED_REFERENCE) {
+    std::vector<RayState> rays((size_t)W * H);
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < H; ++py)
+      for (int px = 0; px < W; ++px) init_ray(rays[(size_t)py * W + px], px, py);
+    render_group(m, o, rays, true, false, &n_samples, &n_rounds);
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < H; ++py)
+      for (int px = 0; px < W; ++px) finish(rays[(size_t)py * W + px], px, py);
+  } else {
+    const int tx_n = (W + 7) / 8, ty_n = (H + 7) / 8;
+    uint64_t s_acc = 0, r_acc = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : s_acc, r_acc)
+    for (int tile = 0; tile < tx_n * ty_n; ++tile) {
+      const int tx = tile % tx_n, ty = tile / tx_n;
+      // a wave tile always has 64 lanes; lanes outside the image are rays that never start
+      std::vector<RayState> rays(64);
+      for (int l = 0; l < 64; ++l) {
+        const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        if (px < W && py < H) {
+          init_ray(rays[l], px, py);
+        } else {
+          std::memset(&rays[l], 0, sizeof(RayState));
+          rays[l].near = rays[l].far = FLT_MAX;
+        }
+      }
+      uint64_t s = 0, r = 0;
+      render_group(m, o, rays, false, true, &s, &r);
+      s_acc += s;
+      r_acc += r;
+      for (int l = 0; l < 64; ++l) {
+        const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        if (px < W && py < H) finish(rays[l], px, py);
+      }
+    }
+    n_samples = s_acc;
+    n_rounds = r_acc;
+  }
+  if (stats) {
+    stats->n_rays = (uint64_t)W * H;
+    stats->n_samples = n_samples;
+    stats->n_rounds = n_rounds;
+    stats->render_ms = 0.0f;
+  }
+#ifdef _OPENMP
+  omp_set_num_threads(saved);
+#endif
+  return NRF_OK;
+}
+
+// R/src/nerf_render.cu:352-359: (unsigned char)(255.0 * x), here saturating and
+// NaN -> 0 (deviation D-2).
+void nrfo_quantize_u8(const float* rgba, const float* depth, int n_px, uint8_t* rgb, uint8_t* depth_u8) {
+  auto q = [](float v) -> uint8_t {
+    const double s = 255.0 * (double)v;
+    if (!(s > 0.0)) return 0;
+    if (s >= 255.0) return 255;
+    return (uint8_t)s;
+  };
+  for (int i = 0; i < n_px; ++i) {
+    if (rgb) {
+      rgb[3 * i + 0] = q(rgba[4 * i + 0]);
+      rgb[3 * i + 1] = q(rgba[4 * i + 1]);
+      rgb[3 * i + 2] = q(rgba[4 * i + 2]);
+    }
+    if (depth_u8) depth_u8[i] = q(depth[i]);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+/*
+ * nerf_oracle.h -- CPU restatement of the reference render hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (nerf-cuda_amd/,
+ * include/) links, loads or calls this library.  It is used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker /
+ * reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or weights for
+ * this path and cannot be built here (CUDA-only), so
+ * this oracle is pinned only by the source-derived known answers of
+ * SURVEY.md Appendix C (tests/test_oracle_kat.py).
+ *
+ * Arithmetic contract (what "the reference's algorithm" means here): every
+ * fp32 operation individually rounded (no FMA contraction), fp16 storage with
+ * round-to-nearest-even, hash-grid interpolation accumulated in fp16
+ * (grid.h:236,260), MLP products accumulated in fp32 in ascending-k order and
+ * rounded to fp16 after the activation of every layer (the reference
+ * accumulates in fp16 inside tensor cores, which is not specified bit-wise).
+ */
+#ifndef NERF_ORACLE_H_
+#define NERF_ORACLE_H_
+
+#include "../include/nerfhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nrfo_model nrfo_model;
+
+/* schedule of the march/eval/composite loop */
+enum {
+  NRFO_SCHED_REFERENCE = 0, /* nerf_render.cu:269-338: one global alive list,
+                               n_step = clamp(N/num_alive,1,8)               */
+  NRFO_SCHED_TILE64 = 1     /* the HIP kernel's schedule: independent 8x8
+                               pixel tiles, n_step = clamp(64/alive,1,8)     */
+};
+
+const char* nrfo_last_error(void);
+int nrfo_create(const nrf_model_desc* d, nrfo_model** out);
+void nrfo_destroy(nrfo_model* m);
+
+/* fp16 helpers (round-to-nearest-even, IEEE binary16) */
+uint16_t nrfo_f32_to_f16(float f);
+float nrfo_f16_to_f32(uint16_t h);
+
+/* render_utils.h:68-77 */
+void nrfo_nerf_matrix_to_ngp(const float pose[16], float scale, float out[16]);
+/* grid.h:81-117 (3-D) */
+uint32_t nrfo_fast_hash3(uint32_t x, uint32_t y, uint32_t z);
+uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32_t y,
+                         uint32_t z);
+
+/* stage functions; all pointers are host pointers, layouts as in nerfhip.h  */
+int nrfo_encode_grid(const nrfo_model* m, const float* pos01, uint32_t n, uint16_t* out);
+int nrfo_encode_dir(const nrfo_model* m, const float* dir01, uint32_t n, uint16_t* out);
+int nrfo_mlp_forward(const nrfo_model* m, const uint16_t* feat, const uint16_t* dirfeat,
+                     uint32_t n, uint16_t* out4);
+int nrfo_network(const nrfo_model* m, const float* xyz, const float* dir, uint32_t n,
+                 float* sigma, float* rgb);
+int nrfo_generate_rays(const nrfo_model* m, const float cam[4], const float pose[16],
+                       int W, int H, const nrf_options* o, float* rays_o, float* rays_d,
+                       float* nears, float* fars);
+int nrfo_march(const nrfo_model* m, const nrf_options* o, const float* rays_o,
+               const float* rays_d, const float* rays_t, const float* fars, uint32_t n,
+               uint32_t n_step, float* xyzs, float* dirs, float* deltas);
+int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, uint32_t n,
+                   uint32_t n_step, float* rays_t, float* state);
+
+/* NerfRender::render_frame.  rgba [H][W][4], depth [H][W] row-major.
+ * n_threads <= 0 -> all cores.                                              */
+int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W,
+                int H, const nrf_options* o, int schedule, int n_threads, float* rgba,
+                float* depth, nrf_stats* stats);
+/* nerf_render.cu:352-359 with saturation (DESIGN.md deviation D-2)          */
+void nrfo_quantize_u8(const float* rgba, const float* depth, int n_px, uint8_t* rgb,
+                      uint8_t* depth_u8);
+int nrfo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""The C-ABI library builds, loads and exports everything include/nerfhip.h
+declares; host-only entry points work; and without a GPU the product path
+fails loudly instead of falling back to any CPU path."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import synthetic as syn
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "nerfhip.h").read_text()
+    declared = set(re.findall(r"\b(nrf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = nh.load_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", str(nh.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(nrf_[a-z0-9_]+)\b", out))
+    assert declared <= exported, f"missing from the .so: {sorted(declared - exported)}"
+    assert declared == set(nh.exported_symbols()), "python binding out of sync with the header"
+    assert lib.nrf_abi_version() == nh.NRF_ABI_VERSION
+
+
+def test_product_library_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", str(nh.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", str(nh.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "nrfo_" not in syms
+    for f in (ROOT / "nerf-cuda_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".h", ".cpp"):
+            assert "oracle_py" not in f.read_text() and "nerf_oracle" not in f.read_text(), f
+
+
+def test_struct_layout_matches_header():
+    # sizes the C compiler produced for the same structs (guards ctypes field drift)
+    src = '#include "nerfhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(nrf_model_desc),' \
+          ' sizeof(nrf_level_table), sizeof(nrf_options), sizeof(nrf_frame), sizeof(nrf_stats));return 0;}'
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        c = Path(td) / "s.c"
+        c.write_text(src)
+        exe = Path(td) / "s"
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
+        sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(nh.ModelDesc), C.sizeof(nh.LevelTable), C.sizeof(nh.Options), C.sizeof(nh.Frame),
+                     C.sizeof(nh.Stats)]
+
+
+def test_host_helpers():
+    assert nh.default_per_level_scale(1.0, 16, 16) == pytest.approx(1.3819129, abs=1e-6)
+    assert nh.tiles_per_shard(1920, 1080, 8) == 4050
+    assert nh.tiles_per_shard(1920, 1080, 1) == 32400
+    assert nh.tiles_per_shard(20, 12, 4) == 2  # 3x2 ragged tiles over 4 shards
+    o = nh.Options()
+    nh.load_library().nrf_default_options(C.byref(o))
+    d = nh.default_options()
+    assert (o.bg_color, o.min_near, o.dt_gamma, o.max_steps, o.density_scale, o.perturb, o.shard_index, o.shard_count) == \
+           (d.bg_color, d.min_near, d.dt_gamma, d.max_steps, d.density_scale, d.perturb, d.shard_index, d.shard_count)
+
+
+def test_config_defaults_follow_the_reference():
+    cfg = syn.base_config()
+    del cfg["encoding"]["base_resolution"], cfg["encoding"]["log2_hashmap_size"]
+    cfg["snapshot"] = {"aabb": [-1, -1, -1, 1, 1, 1], "params": [0.0], "density_grid": [0.0]}
+    d, _ = nh.desc_from_config(cfg)
+    # nerf_render.cu:144-152: log2_hashmap_size defaults to 15, base_resolution to 1 << (15/3)
+    assert (d.log2_hashmap_size, d.base_resolution) == (15, 32)
+    # nerf_render.h:55-67 member defaults
+    assert (d.bound, d.cascade, d.density_grid_size) == (1.0, 1, 128)
+    assert d.scale == pytest.approx(0.33) and d.mean_density == pytest.approx(1e-4)
+    assert d.sigma_activation == nh.ACT["exponential"] and d.density_n_output == 16
+    with pytest.raises(RuntimeError):
+        nh.desc_from_config({"encoding": {}})  # no snapshot block (nerf_render.cu:434-436)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    with pytest.raises(nh.NerfHipError) as e:
+        nh.NerfHip(0)
+    assert e.value.code == nh.NRF_E_NODEVICE

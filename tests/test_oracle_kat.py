@@ -1,0 +1,173 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference has no golden vectors for this path ("parity unpinned"); these
+answers are derived from its source text, not from running it."""
+import math
+
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import oracle_py as op
+import synthetic as syn
+
+
+@pytest.fixture(scope="module")
+def base():
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19)
+    return desc, keep, op.Oracle(desc)
+
+
+def test_f16_conversion_matches_ieee():
+    # every half -> float -> half round-trips, and float -> half equals numpy's RNE conversion
+    L = op.lib()
+    allh = np.arange(65536, dtype=np.uint16)
+    asf = allh.view(np.float16).astype(np.float32)
+    for h in (0, 1, 0x03ff, 0x0400, 0x3c00, 0x7bff, 0x7c00, 0x8000, 0xfbff, 0xfc00):
+        assert L.nrfo_f16_to_f32(h) == asf[h] or (math.isnan(asf[h]))
+        assert L.nrfo_f32_to_f16(float(asf[h])) == h
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(0, 1, 2000), rng.normal(0, 1e-5, 2000), rng.normal(0, 3e4, 2000),
+                         [65504.0, 65519.9, 65520.0, 1e9, 5.9604645e-08, 2.98e-08, 2.9802322e-08, 6.1e-05]]).astype(np.float32)
+    want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([L.nrfo_f32_to_f16(float(x)) for x in xs], np.uint16)
+    np.testing.assert_array_equal(got, want)
+    got_back = np.array([L.nrfo_f16_to_f32(int(h)) for h in want], np.float32)
+    np.testing.assert_array_equal(got_back, want.view(np.float16).astype(np.float32))
+
+
+def test_param_count_and_level_table(base):
+    desc, _, _ = base
+    # nerf_network.h:425 hard check: 3072 + 7168 + 12196240
+    assert desc.n_params == 12206480 == nh.expected_n_params(desc)
+    lt = nh.level_table(desc)
+    assert list(lt.resolution) == [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+    sizes = [lt.offset[i + 1] - lt.offset[i] for i in range(16)]
+    assert sizes == [4096, 12168, 29792, 79512, 205384] + [524288] * 11
+    assert lt.offset[16] == 6098120
+    assert abs(desc.per_level_scale - 1.3819129) < 1e-6
+
+
+@pytest.mark.parametrize("bound,entries", [(2.0, 6299960), (16.0, 6811592)])
+def test_grid_entries_other_bounds(bound, entries):
+    cfg = syn.base_config()
+    cfg["snapshot"] = {"aabb": [-bound] * 3 + [bound] * 3, "bound": bound, "params": [0.0], "density_grid": [0.0]}
+    d, _ = nh.desc_from_config(cfg)
+    assert nh.level_table(d).offset[16] == entries
+
+
+def test_fast_hash_and_dense_index(base):
+    _, _, o = base
+    L = op.lib()
+    assert L.nrfo_fast_hash3(1, 1, 1) == 2922720805
+    assert L.nrfo_fast_hash3(3, 5, 7) == 1191511397
+    assert L.nrfo_fast_hash3(100, 200, 300) == 3655970992
+    assert L.nrfo_fast_hash3(2047, 2047, 2047) == 4281096667
+    assert o.grid_index(15, 1, 1, 1) == 339493
+    assert o.grid_index(15, 3, 5, 7) == 329061
+    assert o.grid_index(15, 100, 200, 300) == 110768
+    assert o.grid_index(15, 2047, 2047, 2047) == 285147
+    assert o.grid_index(0, 3, 5, 7) == 3 + 5 * 16 + 7 * 256  # level 0 is dense (res 16)
+    assert o.grid_index(0, 16, 15, 15) == (16 + 15 * 16 + 15 * 256) % 4096  # +1 corner at x=1 wraps by modulo
+
+
+def test_sh4_known_answers(base):
+    _, _, o = base
+    def sh(d):
+        d01 = (np.asarray(d, np.float32) * 0.5 + 0.5)[None]
+        return o.encode_dir(d01)[0].view(np.float16).astype(np.float32)
+    want1 = [0.282095, 0, 0.488603, 0, 0, 0, 0.630783, 0, 0, 0, 0, 0, 0.746353, 0, 0, 0]
+    want2 = [0.282095, 0, 0.390882, -0.293162, 0, 0, 0.290160, -0.524423, 0.196659, 0, 0, 0, 0.059708, -0.603300,
+             0.416248, -0.127449]
+    np.testing.assert_allclose(sh([0, 0, 1]), want1, atol=6e-4)
+    np.testing.assert_allclose(sh([0.6, 0, 0.8]), want2, atol=6e-4)
+
+
+def test_nerf_matrix_to_ngp_main_pose():
+    out = np.zeros(16, np.float32)
+    pose = np.ascontiguousarray(syn.REFERENCE_MAIN_POSE.reshape(-1))
+    fp = lambda a: a.ctypes.data_as(op.C.POINTER(op.C.c_float))
+    op.lib().nrfo_nerf_matrix_to_ngp(fp(pose), 0.33, fp(out))
+    want = [[0.83003, 0.09497, -0.54957, 0.88025], [0.01385, -0.98860, -0.14991, 0.15165],
+            [-0.55754, 0.11682, -0.82189, 1.30924], [0, 0, 0, 1]]
+    np.testing.assert_allclose(out.reshape(4, 4), want, atol=1e-5)
+
+
+def test_step_sizes_and_constant_sigma_ray(base):
+    desc, _, o = base
+    # dt_min = 2*sqrt(3)/1024, dt_max = 2*bound/H
+    rays_o = np.array([[0.0, -0.16, -1.5]], np.float32)   # through the chassis slab along +z
+    rays_d = np.array([[0.0, 0.0, 1.0]], np.float32)
+    xyzs, dirs, deltas = o.march(rays_o, rays_d, np.array([0.2], np.float32), np.array([2.5], np.float32), 8)
+    dts = deltas[0, :, 0]
+    assert np.all(dts > 0)
+    assert np.all(dts >= np.float32(0.00338291) - 1e-9) and np.all(dts <= 0.015625 + 1e-9)
+    np.testing.assert_allclose(dts[0], np.clip(np.float32(1.25) / 128, 0.00338291, 0.015625), rtol=2e-2)
+    # samples start in the first occupied cell of the slab (cells are 1/64 wide, marked conservatively)
+    assert -0.27 <= xyzs[0, 0, 2] <= -0.23
+    # telescoping: constant sigma => weight_sum = 1 - exp(-sigma * sum dt)
+    sig = np.full((1, 8), 3.0, np.float32)
+    rgb = np.full((1, 8, 3), 0.5, np.float32)
+    t, st = o.composite(sig, rgb, deltas, np.array([0.2], np.float32), np.zeros((1, 5), np.float32))
+    assert abs(st[0, 0] - (1 - math.exp(-3.0 * float(dts.sum())))) < 1e-5
+    assert t[0] > 0  # still alive: all 8 samples consumed, T large
+
+
+def test_composite_termination_rules():
+    deltas = np.zeros((3, 4, 2), np.float32)
+    deltas[:, :, 0] = 0.01
+    deltas[:, :, 1] = 0.01
+    deltas[1, 2:, :] = 0  # ray 1 ran out of samples after 2
+    sig = np.full((3, 4), 1.0, np.float32)
+    sig[2, :] = 5000.0  # ray 2 saturates: T < 1e-4 after the first two samples
+    rgb = np.ones((3, 4, 3), np.float32)
+    t, st = op.composite(sig, rgb, deltas, np.full(3, 0.5, np.float32), np.zeros((3, 5), np.float32))
+    assert t[0] == pytest.approx(0.54) and t[1] == -1 and t[2] == -1
+    assert st[2, 0] == pytest.approx(1.0, abs=1e-6)
+
+
+def test_sigma_exp_saturates_to_fp16_inf():
+    # fp16(exp(x)) is +inf for x > 11.0899
+    assert op.f16(math.exp(11.08)) < 0x7c00
+    assert op.f16(math.exp(11.10)) == 0x7c00
+
+
+def test_param_and_grid_size_errors(base):
+    desc, keep, _ = base
+    import copy, ctypes
+    bad = nh.ModelDesc.from_buffer_copy(desc)
+    bad.n_params = desc.n_params - 1
+    with pytest.raises(op.OracleError) as e:
+        op.Oracle(bad)
+    assert e.value.code == nh.NRF_E_PARAMS
+    bad = nh.ModelDesc.from_buffer_copy(desc)
+    bad.cascade = 2
+    with pytest.raises(op.OracleError) as e:
+        op.Oracle(bad)
+    assert e.value.code == nh.NRF_E_PARAMS
+
+
+def test_reference_and_tile_schedules_agree():
+    """The image does not depend on how rays are batched (per-ray sequential compositing)."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    o = op.Oracle(desc)
+    W, H = 40, 24  # not a multiple of 8 on purpose: ragged tiles
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(70, 20)
+    a, da, sa = o.render(cam, pose, W, H, schedule=op.SCHED_REFERENCE)
+    b, db, sb = o.render(cam, pose, W, H, schedule=op.SCHED_TILE64)
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    np.testing.assert_allclose(da, db, atol=2e-6)
+    assert sa.n_samples > 0 and sb.n_samples > 0
+    # rays that miss the aabb: background, alpha 0, depth 0 (deviation D-3)
+    o2, d2, nr, fr = o.generate_rays(cam, pose, W, H)
+    miss = (nr >= fr).reshape(H, W)
+    assert np.all(a[miss][:, 3] == 0) and np.all(a[miss][:, :3] == 1.0) and np.all(da[miss] == 0)
+
+
+def test_quantize_u8_saturates():
+    rgba = np.array([[-0.5, 0.0, 0.5, 1.0], [1.0, 1.5, np.nan, 0.0], [0.999, 254.9 / 255, 1e9, 0]], np.float32)
+    depth = np.array([0.25, 2.0, -1.0], np.float32)
+    rgb8, d8 = op.quantize_u8(rgba, depth)
+    assert rgb8.tolist() == [[0, 0, 127], [255, 255, 0], [254, 254, 255]]
+    assert d8.tolist() == [63, 255, 0]
