@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megasamples/s (+ frames/s) of the nerf_render hot path at
+1920x1080 on the seeded synthetic Lego-like scene (BASELINE.json configs[1]:
+hash grid L=16 F=2 T=2^19, 64-wide MLPs, SH-4 directions).
+
+A "step" = one whole 1920x1080 frame: ray generation -> occupancy march ->
+hash-grid + SH encoding -> fused MLPs -> compositing -> RGBA/depth in HBM, all
+inside ONE launch of the fused gfx950 kernel per rank.  With N ranks the frame's
+8x8 tiles are dealt round-robin to the ranks (strong scaling of one frame) and
+the only exchange is one RCCL all-gather of the RGBA shards, followed by an
+untile kernel on rank 0 (BASELINE.json configs[2]).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (render_kernel), bound "hbm": algorithmic gather
+                bytes (512 B/sample = 16 levels x 8 corners x half2) over the
+                kernel's mean duration measured with HIP events on its stream.
+  cpu_baseline  the CPU oracle (a port, not the reference binary: the reference
+                is CUDA-only) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT / "nerf-cuda_amd", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+
+import numpy as np  # noqa: E402
+
+WIDTH, HEIGHT = 1920, 1080
+BYTES_PER_SAMPLE = 16 * 8 * 4      # hash-grid gather, the path's algorithmic traffic
+FLOP_PER_SAMPLE = 20480            # both MLPs, padded
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import models
+    import nerfhip as nh
+    import synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    W, H = args.width, args.height
+
+    # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits)
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    ctx = nh.NerfHip(dev.index)
+    ctx.load_model(desc)
+    opts = nh.default_options()
+    opts.shard_index, opts.shard_count = rank, world
+    ctx.set_options(opts)
+    ctx.set_resolution(W, H)
+    tps = nh.tiles_per_shard(W, H, world)
+    cam = syn.default_camera(W, H)
+    poses = [syn.orbit_pose(45.0 * i, 30.0) for i in range(8)]
+
+    # a real (non-NULL) stream: with the NULL stream the C ABI would fall back to its own
+    # stream and synchronise after every call
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    if world > 1:
+        shard = torch.zeros((tps * 64, 4), device=dev)
+        sdepth = torch.zeros((tps * 64,), device=dev)
+        gathered = torch.empty((world, tps * 64, 4), device=dev)
+        frame = torch.empty((H, W, 4), device=dev)
+        ctx.bind_output(shard.data_ptr(), sdepth.data_ptr())
+
+    def step(i):
+        ctx.render(cam, poses[i % len(poses)], stream=stream.cuda_stream)
+        if world > 1:
+            # the one exchange of the path: RGBA shards -> every rank (xGMI all-gather), untile on rank 0
+            dist.all_gather_into_tensor(gathered.view(-1), shard.view(-1))
+            if rank == 0:
+                ctx.untile(gathered.data_ptr(), world, tps, 4, frame.data_ptr(), stream=stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-pose sample counts and kernel durations (untimed replays; the counts are deterministic)
+    samples_pose, kern_ms = [], []
+    for p in poses:
+        ctx.render(cam, p, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        st = ctx.stats()
+        samples_pose.append(int(st.n_samples))
+        kern_ms.append(float(st.render_ms))
+    local_samples = sum(samples_pose[i % len(poses)] for i in range(args.steps))
+    if world > 1:
+        t = torch.tensor([local_samples], device=dev, dtype=torch.int64)
+        dist.all_reduce(t)
+        total_samples = int(t.item())
+    else:
+        total_samples = local_samples
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    msamples_s = total_samples / elapsed / 1e6
+    mean_kern_s = float(np.mean(kern_ms)) * 1e-3
+    mean_samples_launch = float(np.mean(samples_pose))
+    gather_gbs = mean_samples_launch * BYTES_PER_SAMPLE / mean_kern_s / 1e9
+    out = {
+        "metric": "megasamples/s (network-evaluated march samples), Lego-like NeRF render @1920x1080",
+        "value": round(msamples_s, 2),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "frames_per_s": round(1e3 / ms_per_step, 2),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic Lego-like scene {W}x{H}, hash grid L=16 F=2 T=2^19 base 16, "
+                               "density MLP 32-64-16 + rgb MLP 32-64-64-16, SH-4, 8 orbit cameras",
+                   "samples_per_frame": None,
+                   "parallelism": f"tile{world}"},
+        "roofline": {
+            "kernel": "render_kernel",
+            "bound": "hbm",
+            "achieved": round(gather_gbs, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(gather_gbs / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "kernel_ms": round(mean_kern_s * 1e3, 4),
+            "samples_per_launch": int(mean_samples_launch),
+            "mfma_tflops": round(mean_samples_launch * FLOP_PER_SAMPLE / mean_kern_s / 1e12, 3),
+            "mfma_frac": round(mean_samples_launch * FLOP_PER_SAMPLE / mean_kern_s / 1e12 / MFMA_PEAK_TFLOPS, 5),
+        },
+    }
+    if world == 1:
+        out["config"]["samples_per_frame"] = int(mean_samples_launch)
+        out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, cam, poses[0], W, H, args.cpu_sample_div)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def mlp_microbench(ctx, torch, dev):
+    """The fused-MLP stage kernel alone on resident fp16 inputs: the MFMA-roofline figure."""
+    n = 1 << 22
+    feat = (torch.rand((n, 32), device=dev) - 0.5).half()
+    dirf = (torch.rand((n, 16), device=dev) - 0.5).half()
+    out = torch.empty((n, 4), dtype=torch.float16, device=dev)
+    st = torch.cuda.current_stream(dev)
+    assert st.cuda_stream != 0
+    torch.cuda.synchronize(dev)
+    for _ in range(3):
+        ctx.mlp_forward(feat.data_ptr(), dirf.data_ptr(), n, out.data_ptr(), stream=st.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record(st)
+    for _ in range(reps):
+        ctx.mlp_forward(feat.data_ptr(), dirf.data_ptr(), n, out.data_ptr(), stream=st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    tflops = n * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12
+    gbs = n * (64 + 32 + 8) / (ms * 1e-3) / 1e9
+    return {"kernel": "mlp_forward_kernel", "samples": n, "ms": round(ms, 4), "bound": "mfma",
+            "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "hbm_gbs": round(gbs, 1)}
+
+
+def cpu_baseline(desc, cam, pose, W, H, div):
+    """The CPU oracle on this host's cores, on a (W/div)x(H/div) frame of the same view."""
+    import oracle_py as op
+
+    w, h = max(8, W // div), max(8, H // div)
+    c = np.array(cam, np.float32) / np.float32(div)
+    o = op.Oracle(desc)
+    threads = op.lib().nrfo_max_threads()
+    t0 = time.perf_counter()
+    _, _, st = o.render(c, pose, w, h, schedule=op.SCHED_REFERENCE)
+    dt = time.perf_counter() - t0
+    return {"value": round(st.n_samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
+            "sample": f"one {w}x{h} frame of the same camera ({st.n_samples} samples, {dt:.1f} s), reference schedule",
+            "frames_per_s_1080p_equiv": round(1.0 / (dt * div * div), 5)}
+
+
+if __name__ == "__main__":
+    main()

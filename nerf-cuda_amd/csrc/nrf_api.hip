@@ -204,11 +204,13 @@ int alloc_frame(nrf_context* c) {
   nrf_tiles_per_shard(c->W, c->H, c->opt.shard_count, &tps);
   const size_t need = tiled ? (size_t)tps * 64 : (size_t)c->W * c->H;
   if (need == c->n_out_px && c->d_rgba) return NRF_OK;
+  HIP_TRY(hipDeviceSynchronize());
   free_frame(c);
   HIP_TRY(hipMalloc(&c->d_rgba, need * 16));
   HIP_TRY(hipMalloc(&c->d_depth, need * 4));
-  HIP_TRY(hipMemset(c->d_rgba, 0, need * 16));
-  HIP_TRY(hipMemset(c->d_depth, 0, need * 4));
+  HIP_TRY(hipMemsetAsync(c->d_rgba, 0, need * 16, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_depth, 0, need * 4, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   c->n_out_px = need;
   return NRF_OK;
 }
@@ -357,6 +359,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
   if (cells >= (1ull << 32)) return fail(NRF_E_UNSUPPORTED, "density grid too large");
 
+  HIP_TRY(hipDeviceSynchronize());  // nothing may still be reading the old model
   free_model(c);
   // fp32 -> fp16 cast of every parameter (nerf_network.h:434-436), order: density MLP | rgb MLP | grid
   const size_t n_mlp = 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64;
@@ -393,14 +396,20 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     else L.mode = LV_GENERIC;
   }
 
-  HIP_TRY(hipMalloc(&c->d_grid, n_grid * 2));
-  HIP_TRY(hipMemcpy(c->d_grid, grid16.data(), n_grid * 2, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&c->d_occ, occ.size() * 4));
-  HIP_TRY(hipMemcpy(c->d_occ, occ.data(), occ.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&c->d_wfrag, frags.size() * 2));
-  HIP_TRY(hipMemcpy(c->d_wfrag, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&c->d_lv, lp.size() * sizeof(LevelParams)));
-  HIP_TRY(hipMemcpy(c->d_lv, lp.data(), lp.size() * sizeof(LevelParams), hipMemcpyHostToDevice));
+  // Uploads go through the context's own stream and the device is drained afterwards: the
+  // render stream is non-blocking, so a NULL-stream hipMemcpy gives no ordering against it
+  // (seen on MI355X as a few stale table entries in the first frame after a reload).
+  auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  HIP_TRY(upload(&c->d_grid, grid16.data(), n_grid * 2));
+  HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
+  HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
+  HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());
 
   c->desc = *d;
   c->desc.params = nullptr;
@@ -426,6 +435,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.sigma_activation = d->sigma_activation;
   M.rgb_activation = d->rgb_activation;
   M.rgb_output_activation = d->rgb_output_activation;
+  M.generic_act = !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+                    d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
+                    d->sigma_activation == NRF_ACT_EXPONENTIAL);
   c->model_loaded = true;
   return NRF_OK;
 }

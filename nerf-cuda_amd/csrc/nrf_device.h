@@ -73,6 +73,7 @@ struct DevModel {
   uint32_t dir_encoding, sh_degree, n_frequencies;
   uint32_t density_activation, density_output_activation, sigma_activation;
   uint32_t rgb_activation, rgb_output_activation;
+  uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential (compile-time fast path)
 };
 
 struct FrameParams {
@@ -361,24 +362,37 @@ __device__ __forceinline__ half8_t frag_load(const uint4* wl, int f, int lane) {
   return __builtin_bit_cast(half8_t, v);
 }
 
-// pack two D fragments (after activation, rounded to fp16) into one B fragment
+// Activation choice.  GEN == false is the hot-path configuration of the reference's base.json
+// (hidden ReLU, outputs None, sigma Exponential) with every activation a compile-time constant;
+// GEN == true evaluates the runtime enums (any tcnn activation) and is a separate kernel
+// instance, so the hot kernel never carries the if-converted exp/log/sin variants.
+template <bool GEN, uint32_t FAST>
+__device__ __forceinline__ float act_sel(uint32_t runtime_act, float v) {
+  if constexpr (GEN) return activate(runtime_act, v);
+  else if constexpr (FAST == NRF_ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (FAST == NRF_ACT_EXPONENTIAL) return expf(v);
+  else return v;
+}
+
+// pack two D fragments (after the hidden activation, rounded to fp16) into one B fragment
+template <bool GEN>
 __device__ __forceinline__ half8_t pack_acc(uint32_t act, float4_t lo, float4_t hi) {
   half8_t r;
-  r[0] = (half_t)activate(act, lo[0]);
-  r[1] = (half_t)activate(act, lo[1]);
-  r[2] = (half_t)activate(act, lo[2]);
-  r[3] = (half_t)activate(act, lo[3]);
-  r[4] = (half_t)activate(act, hi[0]);
-  r[5] = (half_t)activate(act, hi[1]);
-  r[6] = (half_t)activate(act, hi[2]);
-  r[7] = (half_t)activate(act, hi[3]);
+  r[0] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[0]);
+  r[1] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[1]);
+  r[2] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[2]);
+  r[3] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[3]);
+  r[4] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[0]);
+  r[5] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[1]);
+  r[6] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[2]);
+  r[7] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[3]);
   return r;
 }
 
 // feat[n]  : B fragment of the density MLP input  (hash features 8g..8g+7 of sample c, tile n)
 // dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
 // out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
-template <int NT>
+template <int NT, bool GEN>
 __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, int lane, const half8_t (&feat)[NT],
                                           const half4_t (&dirf)[NT], float4_t (&out)[NT]) {
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
@@ -393,8 +407,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(M.density_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(M.density_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc<GEN>(M.density_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc<GEN>(M.density_activation, acc[n][2], acc[n][3]);
   }
   // ---- density layer 1: 64 -> 16
   float4_t dacc[NT];
@@ -412,10 +426,10 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     half8_t r;
-    r[0] = (half_t)activate(M.density_output_activation, dacc[n][0]);
-    r[1] = (half_t)activate(M.density_output_activation, dacc[n][1]);
-    r[2] = (half_t)activate(M.density_output_activation, dacc[n][2]);
-    r[3] = (half_t)activate(M.density_output_activation, dacc[n][3]);
+    r[0] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][0]);
+    r[1] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][1]);
+    r[2] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][2]);
+    r[3] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][3]);
     r[4] = dirf[n][0];
     r[5] = dirf[n][1];
     r[6] = dirf[n][2];
@@ -432,8 +446,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(M.rgb_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(M.rgb_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc<GEN>(M.rgb_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc<GEN>(M.rgb_activation, acc[n][2], acc[n][3]);
   }
   // ---- rgb layer 1: 64 -> 64
 #pragma unroll
@@ -449,8 +463,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(M.rgb_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(M.rgb_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc<GEN>(M.rgb_activation, acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc<GEN>(M.rgb_activation, acc[n][2], acc[n][3]);
   }
   // ---- rgb layer 2: 64 -> 16 (3 used)
 #pragma unroll
@@ -466,16 +480,20 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
     // network_output rows 0..2 (fp16) and extract_density row 3 (nerf_network.h:49-61):
     // fp32 activation of the fp16 density output, stored as fp16.
     float s = sig_pre[n];
-    switch (M.sigma_activation) {
-      case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
-      case NRF_ACT_EXPONENTIAL: s = expf(s); break;
-      case NRF_ACT_SIGMOID: s = 1.0f / (1.0f + expf(-s)); break;
-      default: break;
+    if constexpr (GEN) {
+      switch (M.sigma_activation) {  // wrap_a_activation handles exactly these (nerf_network.h:32-47)
+        case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
+        case NRF_ACT_EXPONENTIAL: s = expf(s); break;
+        case NRF_ACT_SIGMOID: s = 1.0f / (1.0f + expf(-s)); break;
+        default: break;
+      }
+    } else {
+      s = expf(s);
     }
     float4_t o;
-    o[0] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][0]);
-    o[1] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][1]);
-    o[2] = (float)(half_t)activate(M.rgb_output_activation, dacc[n][2]);
+    o[0] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][0]);
+    o[1] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][1]);
+    o[2] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][2]);
     o[3] = (float)(half_t)s;
     out[n] = o;
   }

@@ -46,10 +46,11 @@ __device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, Leve
   __syncthreads();
 }
 
+
 // Encodes and evaluates the S (<= 16*NT) samples queued in the wave's LDS
 // slots; results go to W->out[slot].  Lane (g, c): sample c of each tile,
 // hash levels 4g..4g+3, direction entries 4g..4g+3.
-template <int NT>
+template <int NT, bool GEN>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  int S, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   float4_t o[NT];
-  mlp_tiles<NT>(M, wl, lane, feat, dirf, o);
+  mlp_tiles<NT, GEN>(M, wl, lane, feat, dirf, o);
   if (g == 0) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -88,16 +89,19 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
   }
 }
 
+template <bool GEN>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  int S, int lane, float density_scale) {
   const int ntile = (S + 15) >> 4;  // wave-uniform
-  if (ntile <= 1) network_from_lds<1>(M, wl, lvs, W, S, lane, density_scale);
-  else if (ntile == 2) network_from_lds<2>(M, wl, lvs, W, S, lane, density_scale);
-  else network_from_lds<4>(M, wl, lvs, W, S, lane, density_scale);
+  if (ntile <= 1) network_from_lds<1, GEN>(M, wl, lvs, W, S, lane, density_scale);
+  else if (ntile == 2) network_from_lds<2, GEN>(M, wl, lvs, W, S, lane, density_scale);
+  else network_from_lds<4, GEN>(M, wl, lvs, W, S, lane, density_scale);
 }
 
 // ------------------------------------------------------- the render kernel ----
-__global__ __launch_bounds__(256, 2) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
+#define NRF_RENDER_WAVES 2
+template <bool GEN>
+__global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
                                                      float* __restrict__ depth, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(const DevModel M, const 
     wave_sync();
 
     // ---- network on the S queued samples (sample-major MFMA tiles)
-    if (S > 0) network_dispatch(M, wl, lvs, W, S, lane, P.density_scale);
+    if (S > 0) network_dispatch<GEN>(M, wl, lvs, W, S, lane, P.density_scale);
     wave_sync();
 
     // ---- alpha compositing, R/include/nerf-cuda/render_utils.h:699-743
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const
 
 // Both MLPs on pre-encoded inputs: one wave = 64 samples per trip.
 // feat fp16 [n][32], dirfeat fp16 [n][16] -> out fp16 [n][4] = (r, g, b, sigma)
+template <bool GEN>
 __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
                                                           uint2* __restrict__ out) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, c
       df[t] = __builtin_bit_cast(half4_t, dv);
     }
     float4_t o[4];
-    mlp_tiles<4>(M, wl, lane, f, df, o);
+    mlp_tiles<4, GEN>(M, wl, lane, f, df, o);
     if (g == 0) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, c
 }
 
 // Whole network on raw march output through the SAME code path as render_kernel.
+template <bool GEN>
 __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const float* __restrict__ xyz,
                                                       const float* __restrict__ dir, uint32_t n, float* __restrict__ sigma,
                                                       float* __restrict__ rgb) {
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const
       }
     }
     wave_sync();
-    network_dispatch(M, wl, lvs, W, S, lane, 1.0f);
+    network_dispatch<GEN>(M, wl, lvs, W, S, lane, 1.0f);
     wave_sync();
     if (i < n) {
       const float4 so = W->out[lane];
@@ -475,8 +481,12 @@ static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
 hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st) {
   const int blocks = (P.n_local_tiles + 3) / 4;
   if (blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
-                     (unsigned long long*)counters);
+  if (M.generic_act)
+    hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
+                       (unsigned long long*)counters);
+  else
+    hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
+                       (unsigned long long*)counters);
   return hipGetLastError();
 }
 
@@ -496,16 +506,24 @@ hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, v
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, hipStream_t st) {
   if (!n) return hipSuccess;
   const uint64_t chunks = ((uint64_t)n + 63) / 64;
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
-                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
+  if (M.generic_act)
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
+                       (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
+  else
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
+                       (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
   return hipGetLastError();
 }
 
 hipError_t launch_network(const DevModel& M, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, hipStream_t st) {
   if (!n) return hipSuccess;
   const uint64_t chunks = ((uint64_t)n + 63) / 64;
-  hipLaunchKernelGGL(network_kernel, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M, (const float*)xyz,
-                     (const float*)dir, n, (float*)sigma, (float*)rgb);
+  if (M.generic_act)
+    hipLaunchKernelGGL(network_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
+                       (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
+  else
+    hipLaunchKernelGGL(network_kernel<false>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
+                       (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
   return hipGetLastError();
 }
 
@@ -545,5 +563,6 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
 }
 
 int render_lds_bytes() { return LDS_TOTAL_BYTES; }
+
 
 }  // namespace nrf
