@@ -147,6 +147,8 @@ struct nrf_context {
   void* d_occ = nullptr;
   void* d_wfrag = nullptr;
   void* d_lv = nullptr;
+  void* d_coarse = nullptr;
+  void* d_ctab = nullptr;
   nrf_options opt{};
   int W = 0, H = 0;
   int n_local_tiles = 0;
@@ -176,7 +178,9 @@ void free_model(nrf_context* c) {
   if (c->d_occ) (void)hipFree(c->d_occ);
   if (c->d_wfrag) (void)hipFree(c->d_wfrag);
   if (c->d_lv) (void)hipFree(c->d_lv);
-  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = nullptr;
+  if (c->d_coarse) (void)hipFree(c->d_coarse);
+  if (c->d_ctab) (void)hipFree(c->d_ctab);
+  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = nullptr;
   c->model_loaded = false;
 }
 
@@ -305,8 +309,8 @@ int nrf_create(int device, nrf_context** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, 16));
-  HIP_TRY(hipMemset(c->d_counters, 0, 16));
+  HIP_TRY(hipMalloc(&c->d_counters, 64));
+  HIP_TRY(hipMemset(c->d_counters, 0, 64));
   *out = c;
   return NRF_OK;
 }
@@ -377,6 +381,30 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   for (uint64_t i = 0; i < cells; ++i)
     if (d->density_grid[i] > thresh) occ[i >> 5] |= 1u << (i & 31);
 
+  // march tables (nrf_device.h march_next): coarse occupancy = OR over 4x4x4 cell blocks, and the
+  // cell-boundary table ((v/(H-1))*2-1)*mip_bound in the reference's fp32 operation order
+  const uint32_t Hs = d->density_grid_size, Cs = d->cascade;
+  const uint32_t coarse_shift = (Hs % 4 == 0 && Hs >= 8) ? 2u : 0u;
+  std::vector<uint32_t> coarse;
+  if (coarse_shift) {
+    const uint32_t Hc = Hs >> 2;
+    coarse.assign(((uint64_t)Cs * Hc * Hc * Hc + 31) / 32 + 1, 0u);
+    for (uint64_t i = 0; i < cells; ++i) {
+      if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
+      const uint32_t level = (uint32_t)(i / (Hh * Hh * Hh));
+      const uint64_t r = i % (Hh * Hh * Hh);
+      const uint32_t nx = (uint32_t)(r / (Hh * Hh)), ny = (uint32_t)((r / Hh) % Hh), nz = (uint32_t)(r % Hh);
+      const uint64_t cc = (((uint64_t)level * Hc + (nx >> 2)) * Hc + (ny >> 2)) * Hc + (nz >> 2);
+      coarse[cc >> 5] |= 1u << (cc & 31);
+    }
+  }
+  std::vector<float> ctab((size_t)Cs * (Hs + 1));
+  for (uint32_t level = 0; level < Cs; ++level) {
+    const float mip_bound = fminf(Cs > 1 ? ldexpf(1.0f, (int)level) : 1.0f, d->bound);
+    const float Hm1 = (float)(Hs - 1);
+    for (uint32_t v = 0; v <= Hs; ++v) ctab[(size_t)level * (Hs + 1) + v] = ((float)v / Hm1 * 2 - 1) * mip_bound;
+  }
+
   std::vector<LevelParams> lp(16);
   for (uint32_t l = 0; l < 16; ++l) {
     LevelParams& L = lp[l];
@@ -408,6 +436,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
+  if (coarse_shift) HIP_TRY(upload(&c->d_coarse, coarse.data(), coarse.size() * 4));
+  HIP_TRY(upload(&c->d_ctab, ctab.data(), ctab.size() * 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
 
@@ -423,6 +453,17 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.lv = (const LevelParams*)c->d_lv;
   for (int i = 0; i < 6; ++i) M.aabb[i] = d->aabb[i];
   M.bound = d->bound;
+  M.rbound = 1.0f / d->bound;
+  M.occ_coarse = (const uint32_t*)c->d_coarse;
+  M.cell_bound = (const float*)c->d_ctab;
+  M.coarse_shift = coarse_shift;
+  {
+    const uint64_t words = coarse_shift ? (uint64_t)coarse.size() : 0, fl = ctab.size();
+    if (coarse_shift && 4 * (words + fl) <= (uint64_t)render_lds_table_max_bytes()) {
+      M.lds_coarse_words = (uint32_t)words;
+      M.lds_ctab_floats = (uint32_t)fl;
+    }
+  }
   M.pos_w = (float)(1.0 / (2 * (double)d->bound));
   M.cascade = d->cascade;
   M.H = d->density_grid_size;
@@ -471,7 +512,7 @@ int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* s
   FrameParams P;
   fill_frame_params(c, cam, pose, P);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, st));
   HIP_TRY(hipEventRecord(c->ev0, st));
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
   void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
@@ -490,6 +531,15 @@ int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* s
     out->depth = depth;
     out->tile_major = P.tile_major;
   }
+  return NRF_OK;
+}
+
+// Diagnostic (not part of include/nerfhip.h): raw counters of the last render; slots 2..6 are
+// only filled by the NRF_PHASE_TIMING build (make prof).
+int nrf_debug_counters(nrf_context* c, unsigned long long out[8]) {
+  if (!c || !out) return fail(NRF_E_INVALID, "null argument");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipMemcpy(out, c->d_counters, 64, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
 

@@ -62,11 +62,14 @@ enum : int {
 struct DevModel {
   const uint32_t* grid;      // half2 entries
   const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
+  const uint32_t* occ_coarse;  // OR over 4x4x4 cell blocks, [C][(H/4)^3] bits; nullptr if H % 4 != 0
+  const float* cell_bound;     // [C][H+1] cell-boundary table (see march_next)
   const uint4* wfrag;        // N_FRAGS * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];
   float bound;
-  float pos_w;  // (float)(1.0/(2*bound)), R/src/nerf_render.cu:311-312
+  float rbound;  // 1.0f / bound
+  float pos_w;   // (float)(1.0/(2*bound)), R/src/nerf_render.cu:311-312
   uint32_t cascade;
   uint32_t H;
   uint32_t n_levels;
@@ -74,6 +77,9 @@ struct DevModel {
   uint32_t density_activation, density_output_activation, sigma_activation;
   uint32_t rgb_activation, rgb_output_activation;
   uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential (compile-time fast path)
+  uint32_t coarse_shift;    // 2 or 0
+  uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
+  uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
 };
 
 struct FrameParams {
@@ -152,63 +158,96 @@ __device__ __forceinline__ void near_far(const float* aabb, const float o[3], co
 }
 
 // ----------------------------------------------------------------- march ----
+// kernel_march_rays (render_utils.h:524-655), restated so that one loop trip costs ~40 VALU and,
+// in empty space, no global load and no division:
+//   * cell_bound[level][v] = ((v / (H-1)) * 2 - 1) * mip_bound for v = 0..H is tabulated on the
+//     host with the reference's own fp32 operation order (render_utils.h:643), since
+//     nx + 0.5f + 0.5f*sign(d) is exactly the integer nx or nx+1;
+//   * 1/mip_bound is 2^-level or the host's 1/bound (both correctly rounded, as `1 / mip_bound`);
+//   * a coarse occupancy bitfield (4x4x4 cells OR-ed) answers "empty" without touching the fine one.
+// Every value that reaches a sample (x, y, z, dt, t) is produced by the same individually rounded
+// fp32 operations as the reference/oracle, so marching stays bit-exact.
 struct MarchConst {
-  float bound, dt_gamma, dt_min, dt_max, Hf, Hm1;
-  uint32_t H, C;
+  float bound, rbound, dt_gamma, dt_min, dt_max, Hf, Hm1;
+  uint32_t H, C, HH, HHH;
+  uint32_t coarse_shift;  // 2 when the coarse grid is present, else 0
+  uint32_t Hc;            // H >> coarse_shift
 };
 
 __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_gamma) {
   MarchConst c;
   c.bound = M.bound;
+  c.rbound = M.rbound;
   c.dt_gamma = dt_gamma;
   c.dt_min = 2 * 1.7320508075688772f / 1024;  // MIN_STEPSIZE, render_utils.h:181-183
   c.dt_max = 2 * M.bound / (float)M.H;
   c.H = M.H;
   c.C = M.cascade;
+  c.HH = M.H * M.H;
+  c.HHH = M.H * M.H * M.H;
   c.Hf = (float)M.H;
   c.Hm1 = (float)(M.H - 1);
+  c.coarse_shift = M.coarse_shift;
+  c.Hc = M.H >> M.coarse_shift;
   return c;
 }
 
-// Advances t until the next occupied sample (returns true; x,y,z = clamped
-// position, dt = its step, t already advanced by dt) or until t >= far.
-// One loop trip = one trip of the `while (t < far && step < n_step)` loop of
-// render_utils.h:593-653.
-__device__ __forceinline__ bool march_next(const MarchConst& c, const uint32_t* __restrict__ occ, float ox, float oy,
-                                           float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz,
-                                           float far, float& t, float& x, float& y, float& z, float& dt_out) {
+enum : int { MARCH_FOUND = 0, MARCH_EXHAUSTED = 1, MARCH_OUT_OF_BUDGET = 2 };
+
+// Advances t until the next occupied sample (MARCH_FOUND: x,y,z = clamped position, dt_out = its
+// step; t is NOT yet advanced by dt), until t >= far (MARCH_EXHAUSTED) or until `budget` loop trips
+// are spent (MARCH_OUT_OF_BUDGET, t rests on the next candidate).  One loop trip = one trip of the
+// `while (t < far && step < n_step)` loop of render_utils.h:593-653.
+//   occ      fine bitfield (global)     coarse  coarse bitfield or nullptr     ctab  cell_bound table
+template <bool COARSE>
+__device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* __restrict__ occ, const uint32_t* coarse,
+                                          const float* ctab, float ox, float oy, float oz, float dx, float dy, float dz,
+                                          float rdx, float rdy, float rdz, int sx, int sy, int sz, float far, int& budget,
+                                          float& t, float& x, float& y, float& z, float& dt_out) {
   while (t < far) {
+    if (budget <= 0) return MARCH_OUT_OF_BUDGET;
+    --budget;
     x = clampf(ox + t * dx, -c.bound, c.bound);
     y = clampf(oy + t * dy, -c.bound, c.bound);
     z = clampf(oz + t * dz, -c.bound, c.bound);
-    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    int exponent;
-    (void)frexpf(mx, &exponent);
-    const int level = (int)fminf((float)c.C - 1, fmaxf(0.0f, (float)exponent));
-    const float mip_bound = fminf(ldexpf(1.0f, level), c.bound);
-    const float mip_rbound = 1 / mip_bound;
+    int level = 0;
+    float mip_bound = fminf(1.0f, c.bound), mip_rbound;
+    if (c.C > 1) {
+      const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+      int exponent;
+      (void)frexpf(mx, &exponent);
+      level = (int)fminf((float)c.C - 1, fmaxf(0.0f, (float)exponent));
+      mip_bound = fminf(ldexpf(1.0f, level), c.bound);
+    }
+    mip_rbound = (mip_bound == c.bound) ? c.rbound : ldexpf(1.0f, -level);  // == 1 / mip_bound
     // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic in the reference; for H < 2^24 the
     // double product is exact, so its narrowing to float equals the fp32 product (0.5f*v)*H.
     const int nx = (int)clampf((0.5f * (x * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     const int ny = (int)clampf((0.5f * (y * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     const int nz = (int)clampf((0.5f * (z * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
-    const uint32_t cell = (uint32_t)level * c.H * c.H * c.H + (uint32_t)nx * c.H * c.H + (uint32_t)ny * c.H + (uint32_t)nz;
-    const bool occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
-    if (occupied) {
-      const float dt = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
-      t += dt;
-      dt_out = dt;
-      return true;
+    bool occupied = true;
+    if (COARSE) {
+      const uint32_t cc = ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
+      occupied = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
     }
-    const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / c.Hm1 * 2 - 1) * mip_bound - x) * rdx;
-    const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / c.Hm1 * 2 - 1) * mip_bound - y) * rdy;
-    const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / c.Hm1 * 2 - 1) * mip_bound - z) * rdz;
+    if (occupied) {
+      const uint32_t cell = (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
+      occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+    }
+    if (occupied) {
+      dt_out = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+      return MARCH_FOUND;
+    }
+    const float* tab = ctab + (uint32_t)level * (c.H + 1);
+    const float tx = (tab[nx + sx] - x) * rdx;  // (((nx+0.5f+0.5f*sign)/(H-1)*2-1)*mip_bound - x) * rdx
+    const float ty = (tab[ny + sy] - y) * rdy;
+    const float tz = (tab[nz + sz] - z) * rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do {
       t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
     } while (t < tt);
   }
-  return false;
+  return MARCH_EXHAUSTED;
 }
 
 // ------------------------------------------------------------- hash grid ----

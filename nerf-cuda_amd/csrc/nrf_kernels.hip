@@ -30,7 +30,9 @@ static_assert(sizeof(WaveLds) == 4608, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
-constexpr int LDS_TOTAL_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);
+constexpr int LDS_FIXED_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);
+constexpr int LDS_TOTAL_BYTES = LDS_FIXED_BYTES;  // + march tables for render_kernel<., true>
+constexpr int LDS_MARCH_TABLE_MAX = 48 * 1024;    // beyond this the tables stay in global memory
 
 // cross-lane hand-off through LDS inside ONE wavefront: LDS operations of a
 // wave execute in order, so only the compiler has to be kept from reordering
@@ -39,6 +41,23 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Diagnostic build only (make prof, -DNRF_PHASE_TIMING): s_memtime stamps around the phases of a
+// round, summed per wave and added to counters[2..6]; the shipped kernel executes no stamp.
+#ifdef NRF_PHASE_TIMING
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define NRF_STAMP(var) const unsigned long long var = stamp()
+#define NRF_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define NRF_STAMP(var)
+#define NRF_ACC(acc, a, b)
+#endif
 
 __device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, LevelParams* lvs) {
   for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
@@ -100,7 +119,7 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 
 // ------------------------------------------------------- the render kernel ----
 #define NRF_RENDER_WAVES 2
-template <bool GEN>
+template <bool GEN, bool COARSE_LDS>
 __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
                                                      float* __restrict__ depth, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -111,6 +130,14 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   WaveLds* W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+  // march tables: coarse occupancy bits + cell-boundary table (staged once per workgroup)
+  uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + LDS_FIXED_BYTES);
+  float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
+  if (COARSE_LDS) {
+    for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
+    for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
+    __syncthreads();
+  }
 
   // XCD-aware block order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each
   // XCD one contiguous band of tile strips -> neighbouring tiles share that XCD's L2 (bijective remap).
@@ -124,6 +151,10 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool in_img = px < P.W && py < P.H;
 
+#ifdef NRF_PHASE_TIMING
+  unsigned long long c_march = 0, c_net = 0, c_comp = 0;
+#endif
+  NRF_STAMP(t_begin);
   // ---- ray generation + aabb
   const float o[3] = {P.org[0], P.org[1], P.org[2]};
   float d[3];
@@ -146,55 +177,79 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
     }
   }
   const MarchConst mc = march_const(M, P.dt_gamma);
+  const int sx = __builtin_signbitf(d[0]) ? 0 : 1;  // copysignf(1, d) > 0: the far face of the cell
+  const int sy = __builtin_signbitf(d[1]) ? 0 : 1;
+  const int sz = __builtin_signbitf(d[2]) ? 0 : 1;
 
-  float t = near;
+  // Per-ray semantics (DESIGN.md "Schedule-free compositing"): exactly the reference loop at
+  // n_step == 1 -- after every emitted sample the march restarts from the composited t
+  // (rays_t = t0 + (t1 - t0), nerf_render.cu:332 -> render_utils.h:716,742), a ray ends when
+  // T < 1e-4, when t >= far, or after max_steps samples.  How samples of different rays are
+  // batched into rounds therefore cannot change the picture, and the batching below is chosen
+  // for the hardware: every round fills up to 64 LDS sample slots (<= 8 per ray), and a lane
+  // may spend at most MARCH_BUDGET cell trips per round, so that one ray crossing empty space
+  // never stalls the other 63 (it simply contributes no sample until it finds one).
+  constexpr int MARCH_BUDGET = 16;
+  float t = near;    // march position
+  float tc = near;   // composited t (t at the last emitted sample)
   bool alive = in_img && (near < far);
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-  int steps_done = 0;
+  int n_ray_samples = 0;
   unsigned n_samples = 0, n_rounds = 0;
 
   while (true) {
-    const unsigned long long am = __ballot(alive);
-    if (am == 0ull || steps_done >= P.max_steps) break;
-    const int A = __popcll(am);
-    int n_step = 64 / A;  // R/src/nerf_render.cu:300 with N = 64 rays per wave tile
-    n_step = n_step > 8 ? 8 : n_step;
-
-    // ---- march: up to n_step samples per alive ray, compacted k-major into LDS slots
-    const float t_start = t;
-    float last_t = t;
+    if (__ballot(alive) == 0ull) break;
+    NRF_STAMP(t0);
+    // ---- march: ballot/mbcnt compaction of the found samples, k-major, into the wave's LDS slots
     unsigned long long slots = 0ull;
     int cnt = 0, S = 0;
+    int budget = MARCH_BUDGET;
     bool marching = alive;
-    for (int k = 0; k < n_step; ++k) {
+    bool ended = false;  // t >= far or sample cap: the ray dies after compositing this round's samples
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long mm = __ballot(marching);
+      if (mm == 0ull || S + __popcll(mm) > 64) break;
       float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
       bool found = false;
-      if (marching) found = march_next(mc, M.occ_bits, o[0], o[1], o[2], d[0], d[1], d[2], rdx, rdy, rdz, far, t, x, y, z, dt);
-      marching = found;
+      if (marching) {
+        const int r = COARSE_LDS ? march_next<true>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                                    rdy, rdz, sx, sy, sz, far, budget, t, x, y, z, dt)
+                                 : march_next<false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                                     rdy, rdz, sx, sy, sz, far, budget, t, x, y, z, dt);
+        found = r == MARCH_FOUND;
+        marching = found;
+        ended = ended || r == MARCH_EXHAUSTED;
+      }
       const unsigned long long fm = __ballot(found);
-      if (fm == 0ull) break;
       if (found) {
         const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        const float tn = t + dt;        // march: t += dt
+        const float delta = tn - tc;    // deltas[1] = t - last_t (last_t == composited t)
+        tc = tc + delta;                // composite: t += deltas[1]
+        t = tc;                         // next march starts from rays_t
         W->pos[slot] = make_float4(x, y, z, dt);
-        W->aux[slot] = make_float2(t - last_t, __builtin_bit_cast(float, lane));
-        last_t = t;
+        W->aux[slot] = make_float2(tc, __builtin_bit_cast(float, lane));
         slots |= (unsigned long long)slot << (8 * k);
         cnt++;
+        if (n_ray_samples + cnt >= P.max_steps) { marching = false; ended = true; }
       }
       S += __popcll(fm);
     }
     wave_sync();
+    NRF_STAMP(t1);
 
-    // ---- network on the S queued samples (sample-major MFMA tiles)
-    if (S > 0) network_dispatch<GEN>(M, wl, lvs, W, S, lane, P.density_scale);
-    wave_sync();
+    if (S > 0) {
+      // ---- network on the S queued samples (sample-major MFMA tiles)
+      network_dispatch<GEN>(M, wl, lvs, W, S, lane, P.density_scale);
+      wave_sync();
+    }
+    NRF_STAMP(t2);
 
     // ---- alpha compositing, R/include/nerf-cuda/render_utils.h:699-743
     if (alive) {
-      float tc = t_start;
-      int step = 0;
-      for (int k = 0; k < n_step; ++k) {
-        if (k >= cnt) break;  // deltas == 0: the ray ran out of samples
+      bool terminated = false;
+      for (int k = 0; k < 8; ++k) {
+        if (k >= cnt) break;
         const int slot = (int)((slots >> (8 * k)) & 0xffull);
         const float4 so = W->out[slot];
         const float dt = W->pos[slot].w;
@@ -202,22 +257,23 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
         const float T = 1 - ws;
         const float wgt = alpha * T;
         ws += wgt;
-        tc += W->aux[slot].x;
-        dep += wgt * tc;
+        dep += wgt * W->aux[slot].x;  // depth += weight * t, t = composited t of this sample
         cr += wgt * so.x;
         cg += wgt * so.y;
         cb += wgt * so.z;
         // `T < 1e-4` against a double literal: true exactly for T <= 9.99999974737875e-05f
-        if (T <= 9.99999974737875e-05f) break;
-        step++;
+        if (T <= 9.99999974737875e-05f) { terminated = true; break; }
       }
-      alive = step == n_step;
-      t = tc;
+      n_ray_samples += cnt;
+      alive = !(terminated || ended);
     }
     wave_sync();
+    NRF_STAMP(t3);
+    NRF_ACC(c_march, t0, t1);
+    NRF_ACC(c_net, t1, t2);
+    NRF_ACC(c_comp, t2, t3);
     n_samples += (unsigned)S;
     n_rounds++;
-    steps_done += n_step;
   }
 
   // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
@@ -236,6 +292,14 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
   if (lane == 0) {
     atomicAdd(&counters[0], (unsigned long long)n_samples);
     atomicAdd(&counters[1], (unsigned long long)n_rounds);
+#ifdef NRF_PHASE_TIMING
+    NRF_STAMP(t_end);
+    atomicAdd(&counters[2], c_march);
+    atomicAdd(&counters[3], c_net);
+    atomicAdd(&counters[4], c_comp);
+    atomicAdd(&counters[5], t_end - t_begin);
+    atomicAdd(&counters[6], 1ull);
+#endif
   }
 }
 
@@ -375,6 +439,7 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(const DevModel M, co
   }
 }
 
+template <bool COARSE>
 __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_gamma, const float* __restrict__ rays_o,
                                                     const float* __restrict__ rays_d, const float* __restrict__ rays_t,
                                                     const float* __restrict__ fars, uint32_t n, uint32_t n_step,
@@ -385,15 +450,21 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
     const float ox = rays_o[3 * (size_t)i], oy = rays_o[3 * (size_t)i + 1], oz = rays_o[3 * (size_t)i + 2];
     const float dx = rays_d[3 * (size_t)i], dy = rays_d[3 * (size_t)i + 1], dz = rays_d[3 * (size_t)i + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const int sx = __builtin_signbitf(dx) ? 0 : 1, sy = __builtin_signbitf(dy) ? 0 : 1, sz = __builtin_signbitf(dz) ? 0 : 1;
     const float far = fars[i];
-    float t = rays_t[i], last_t = t;
+    float t = rays_t[i], last_t = t;  // kernel_march_rays with an explicit n_step: render_utils.h:591-653
     bool marching = true;
     for (uint32_t k = 0; k < n_step; ++k) {
       const size_t s = (size_t)i * n_step + k;
       float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
       bool found = false;
-      if (marching) found = march_next(mc, M.occ_bits, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, t, x, y, z, dt);
+      if (marching) {
+        int budget = 0x7fffffff;
+        found = march_next<COARSE>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
+                                   far, budget, t, x, y, z, dt) == MARCH_FOUND;
+      }
       marching = found;
+      if (found) t += dt;
       // unused slots are zero-filled (deviation D-1)
       xyzs[3 * s] = found ? x : 0.f;
       xyzs[3 * s + 1] = found ? y : 0.f;
@@ -481,12 +552,17 @@ static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
 hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st) {
   const int blocks = (P.n_local_tiles + 3) / 4;
   if (blocks <= 0) return hipSuccess;
-  if (M.generic_act)
-    hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
-                       (unsigned long long*)counters);
-  else
-    hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(256), LDS_TOTAL_BYTES, st, M, P, (float4*)rgba, (float*)depth,
-                       (unsigned long long*)counters);
+  const bool lds_tab = M.lds_coarse_words > 0;
+  const int lds = LDS_FIXED_BYTES + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
+#define NRF_LAUNCH_RENDER(G, C)                                                                                          \
+  hipLaunchKernelGGL((render_kernel<G, C>), dim3(blocks), dim3(256), lds, st, M, P, (float4*)rgba, (float*)depth, \
+                     (unsigned long long*)counters)
+  if (M.generic_act) {
+    if (lds_tab) NRF_LAUNCH_RENDER(true, true); else NRF_LAUNCH_RENDER(true, false);
+  } else {
+    if (lds_tab) NRF_LAUNCH_RENDER(false, true); else NRF_LAUNCH_RENDER(false, false);
+  }
+#undef NRF_LAUNCH_RENDER
   return hipGetLastError();
 }
 
@@ -537,8 +613,14 @@ hipError_t launch_generate_rays(const DevModel& M, const FrameParams& P, void* r
 hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, const void* rays_d, const void* rays_t,
                         const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(march_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o, (const float*)rays_d,
-                     (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs, (float*)deltas);
+  if (M.coarse_shift)
+    hipLaunchKernelGGL(march_kernel<true>, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o,
+                       (const float*)rays_d, (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs,
+                       (float*)deltas);
+  else
+    hipLaunchKernelGGL(march_kernel<false>, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o,
+                       (const float*)rays_d, (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs,
+                       (float*)deltas);
   return hipGetLastError();
 }
 
@@ -562,7 +644,8 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
   return hipGetLastError();
 }
 
-int render_lds_bytes() { return LDS_TOTAL_BYTES; }
+int render_lds_bytes() { return LDS_FIXED_BYTES; }
+int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
 
 
 }  // namespace nrf

@@ -587,8 +587,9 @@ struct RayState {
 // skip_missed (TILE64 schedule only): rays with near >= far never enter the
 // alive list; they would emit no sample and die in their first composite, so
 // the image is unchanged.
+// fixed_n_step > 0 overrides the N/num_alive rule (PER_RAY schedule: 1).
 void render_group(const nrfo_model* m, const nrf_options* opt, std::vector<RayState>& rays,
-                  bool parallel, bool skip_missed, uint64_t* n_samples, uint64_t* n_rounds) {
+                  bool parallel, bool skip_missed, int fixed_n_step, uint64_t* n_samples, uint64_t* n_rounds) {
   const int N = (int)rays.size();
   std::vector<int> alive, next;
   alive.reserve(N);
@@ -611,7 +612,7 @@ void render_group(const nrfo_model* m, const nrf_options* opt, std::vector<RaySt
     first = false;
     const int num_alive = (int)alive.size();
     if (num_alive <= 0) break;  // :294
-    const int n_step = std::max(std::min(N / num_alive, 8), 1);  // :300
+    const int n_step = fixed_n_step > 0 ? fixed_n_step : std::max(std::min(N / num_alive, 8), 1);  // :300
     uint64_t round_samples = 0;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : round_samples) if (parallel)
     for (int a = 0; a < num_alive; ++a) {
@@ -749,12 +750,12 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
     depth[i] = span > 0.0f ? fmaxf(r.st[1] - r.near, 0.0f) / span : 0.0f;
   };
 
-  if (schedule == NRFO_SCHED_REFERENCE) {
+  if (schedule == NRFO_SCHED_REFERENCE || schedule == NRFO_SCHED_PER_RAY) {
     std::vector<RayState> rays((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int py = 0; py < H; ++py)
       for (int px = 0; px < W; ++px) init_ray(rays[(size_t)py * W + px], px, py);
-    render_group(m, o, rays, true, false, &n_samples, &n_rounds);
+    render_group(m, o, rays, true, schedule == NRFO_SCHED_PER_RAY, schedule == NRFO_SCHED_PER_RAY ? 1 : 0, &n_samples, &n_rounds);
 #pragma omp parallel for schedule(static)
     for (int py = 0; py < H; ++py)
       for (int px = 0; px < W; ++px) finish(rays[(size_t)py * W + px], px, py);
@@ -776,7 +777,7 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
         }
       }
       uint64_t s = 0, r = 0;
-      render_group(m, o, rays, false, true, &s, &r);
+      render_group(m, o, rays, false, true, 0, &s, &r);
       s_acc += s;
       r_acc += r;
       for (int l = 0; l < 64; ++l) {

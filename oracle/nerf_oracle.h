@@ -33,8 +33,14 @@ typedef struct nrfo_model nrfo_model;
 enum {
   NRFO_SCHED_REFERENCE = 0, /* nerf_render.cu:269-338: one global alive list,
                                n_step = clamp(N/num_alive,1,8)               */
-  NRFO_SCHED_TILE64 = 1     /* the HIP kernel's schedule: independent 8x8
-                               pixel tiles, n_step = clamp(64/alive,1,8)     */
+  NRFO_SCHED_TILE64 = 1,    /* independent 8x8 pixel tiles with
+                               n_step = clamp(64/alive,1,8)                  */
+  NRFO_SCHED_PER_RAY = 2    /* the reference loop with n_step == 1 for every
+                               iteration (what it does whenever more than
+                               half of the rays are alive): each ray is
+                               marched, evaluated and composited one sample
+                               at a time.  This is the per-ray semantics the
+                               HIP kernel implements; batching cannot change it */
 };
 
 const char* nrfo_last_error(void);

@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 LIB = ORACLE_DIR / "libnerf_oracle.so"
 
-SCHED_REFERENCE, SCHED_TILE64 = 0, 1
+SCHED_REFERENCE, SCHED_TILE64, SCHED_PER_RAY = 0, 1, 2
 _lib = None
 
 

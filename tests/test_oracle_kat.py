@@ -156,9 +156,13 @@ def test_reference_and_tile_schedules_agree():
     cam, pose = syn.default_camera(W, H), syn.orbit_pose(70, 20)
     a, da, sa = o.render(cam, pose, W, H, schedule=op.SCHED_REFERENCE)
     b, db, sb = o.render(cam, pose, W, H, schedule=op.SCHED_TILE64)
+    c, dc, sc = o.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
     np.testing.assert_allclose(a, b, atol=2e-6)
     np.testing.assert_allclose(da, db, atol=2e-6)
+    np.testing.assert_allclose(a, c, atol=2e-6)
+    np.testing.assert_allclose(da, dc, atol=2e-6)
     assert sa.n_samples > 0 and sb.n_samples > 0
+    assert sc.n_samples <= sa.n_samples  # one sample at a time never evaluates past a ray's end
     # rays that miss the aabb: background, alpha 0, depth 0 (deviation D-3)
     o2, d2, nr, fr = o.generate_rays(cam, pose, W, H)
     miss = (nr >= fr).reshape(H, W)
