@@ -398,6 +398,32 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       coarse[cc >> 5] |= 1u << (cc & 31);
     }
   }
+  // world-space box around every occupied cell, inflated by 2 cells of its cascade level
+  float occ_box[6] = {1.f, 1.f, 1.f, -1.f, -1.f, -1.f};  // empty
+  {
+    bool any = false;
+    for (uint32_t level = 0; level < Cs; ++level) {
+      uint32_t lo[3] = {Hs, Hs, Hs}, hi[3] = {0, 0, 0};
+      bool lvl_any = false;
+      for (uint64_t r = 0; r < Hh * Hh * Hh; ++r) {
+        const uint64_t i = (uint64_t)level * Hh * Hh * Hh + r;
+        if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
+        const uint32_t n3[3] = {(uint32_t)(r / (Hh * Hh)), (uint32_t)((r / Hh) % Hh), (uint32_t)(r % Hh)};
+        for (int a = 0; a < 3; ++a) { lo[a] = n3[a] < lo[a] ? n3[a] : lo[a]; hi[a] = n3[a] > hi[a] ? n3[a] : hi[a]; }
+        lvl_any = true;
+      }
+      if (!lvl_any) continue;
+      const double mip_bound = fmin(Cs > 1 ? ldexp(1.0, (int)level) : 1.0, (double)d->bound);
+      const double cell = 2.0 * mip_bound / (double)Hs;
+      for (int a = 0; a < 3; ++a) {
+        const float wlo = (float)(-mip_bound + ((double)lo[a] - 2.0) * cell);
+        const float whi = (float)(-mip_bound + ((double)hi[a] + 3.0) * cell);
+        if (!any || wlo < occ_box[a]) occ_box[a] = wlo;
+        if (!any || whi > occ_box[a + 3]) occ_box[a + 3] = whi;
+      }
+      any = true;
+    }
+  }
   std::vector<float> ctab((size_t)Cs * (Hs + 1));
   for (uint32_t level = 0; level < Cs; ++level) {
     const float mip_bound = fminf(Cs > 1 ? ldexpf(1.0f, (int)level) : 1.0f, d->bound);
@@ -453,6 +479,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.lv = (const LevelParams*)c->d_lv;
   for (int i = 0; i < 6; ++i) M.aabb[i] = d->aabb[i];
   M.bound = d->bound;
+  for (int i = 0; i < 6; ++i) M.occ_box[i] = occ_box[i];
   M.rbound = 1.0f / d->bound;
   M.occ_coarse = (const uint32_t*)c->d_coarse;
   M.cell_bound = (const float*)c->d_ctab;

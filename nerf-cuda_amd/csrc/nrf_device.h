@@ -67,6 +67,7 @@ struct DevModel {
   const uint4* wfrag;        // N_FRAGS * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];
+  float occ_box[6];  // world-space box around every occupied cell, inflated by 2 cells; min > max when nothing is occupied
   float bound;
   float rbound;  // 1.0f / bound
   float pos_w;   // (float)(1.0/(2*bound)), R/src/nerf_render.cu:311-312
@@ -157,6 +158,22 @@ __device__ __forceinline__ void near_far(const float* aabb, const float o[3], co
   far_out = miss ? 3.402823466e+38f : fr;
 }
 
+// Interval of t on which the ray is inside `box` (slab test); empty when t_in > t_out.  Used with
+// the inflated box of occupied cells: a march trip at a t outside this interval tests a cell
+// that is certainly empty, so no sample exists there and the ray may stop at t_out (exact).
+__device__ __forceinline__ void box_interval(const float* box, const float o[3], float rdx, float rdy, float rdz,
+                                             float& t_in, float& t_out) {
+  float a = (box[0] - o[0]) * rdx, b = (box[3] - o[0]) * rdx;
+  t_in = fminf(a, b);
+  t_out = fmaxf(a, b);
+  a = (box[1] - o[1]) * rdy; b = (box[4] - o[1]) * rdy;
+  t_in = fmaxf(t_in, fminf(a, b));
+  t_out = fminf(t_out, fmaxf(a, b));
+  a = (box[2] - o[2]) * rdz; b = (box[5] - o[2]) * rdz;
+  t_in = fmaxf(t_in, fminf(a, b));
+  t_out = fminf(t_out, fmaxf(a, b));
+}
+
 // ----------------------------------------------------------------- march ----
 // kernel_march_rays (render_utils.h:524-655), restated so that one loop trip costs ~40 VALU and,
 // in empty space, no global load and no division:
@@ -225,23 +242,27 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     const int nx = (int)clampf((0.5f * (x * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     const int ny = (int)clampf((0.5f * (y * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     const int nz = (int)clampf((0.5f * (z * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
-    bool occupied = true;
+    // all loads of the trip are issued together (addresses depend only on the cell), so the
+    // trip pays one memory latency instead of three dependent ones
+    const uint32_t cell = (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
+    const float* tab = ctab + (uint32_t)level * (c.H + 1);
+    const float bx = tab[nx + sx], by = tab[ny + sy], bz = tab[nz + sz];
+    bool occupied;
     if (COARSE) {
       const uint32_t cc = ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
-      occupied = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
-    }
-    if (occupied) {
-      const uint32_t cell = (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
+      const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
+      occupied = coarse_occ;
+      if (coarse_occ) occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+    } else {
       occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
     }
     if (occupied) {
       dt_out = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
       return MARCH_FOUND;
     }
-    const float* tab = ctab + (uint32_t)level * (c.H + 1);
-    const float tx = (tab[nx + sx] - x) * rdx;  // (((nx+0.5f+0.5f*sign)/(H-1)*2-1)*mip_bound - x) * rdx
-    const float ty = (tab[ny + sy] - y) * rdy;
-    const float tz = (tab[nz + sz] - z) * rdz;
+    const float tx = (bx - x) * rdx;  // (((nx+0.5f+0.5f*sign)/(H-1)*2-1)*mip_bound - x) * rdx
+    const float ty = (by - y) * rdy;
+    const float tz = (bz - z) * rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do {
       t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max);

@@ -30,8 +30,10 @@ static_assert(sizeof(WaveLds) == 4608, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
-constexpr int LDS_FIXED_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);
-constexpr int LDS_TOTAL_BYTES = LDS_FIXED_BYTES;  // + march tables for render_kernel<., true>
+constexpr int RENDER_WAVES = 8;  // waves (8x8 pixel tiles) per workgroup
+constexpr int RENDER_THREADS = 64 * RENDER_WAVES;
+constexpr int LDS_FIXED_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + RENDER_WAVES * (int)sizeof(WaveLds);
+constexpr int LDS_TOTAL_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);  // network_kernel (4 waves)
 constexpr int LDS_MARCH_TABLE_MAX = 48 * 1024;    // beyond this the tables stay in global memory
 
 // cross-lane hand-off through LDS inside ONE wavefront: LDS operations of a
@@ -71,13 +73,13 @@ __device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, Leve
 // hash levels 4g..4g+3, direction entries 4g..4g+3.
 template <int NT, bool GEN>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
-                                                 int S, int lane, float density_scale) {
+                                                 int S, int base, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
   half8_t feat[NT];
   half4_t dirf[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int slot = 16 * n + c;
+    const int slot = base + 16 * n + c;
     uint32_t fb[4] = {0u, 0u, 0u, 0u};
     uint2 db = make_uint2(0u, 0u);
     if (slot < S) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
   if (g == 0) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const int slot = 16 * n + c;
+      const int slot = base + 16 * n + c;
       float sigma = o[n][3];
       if (density_scale != 1.0f) sigma = density_scale * sigma;  // R/src/nerf_render.cu:328 (float multiply)
       if (slot < S) W->out[slot] = make_float4(o[n][0], o[n][1], o[n][2], sigma);
@@ -108,19 +110,23 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
   }
 }
 
+// At most NT_MAX tiles are evaluated together: NT_MAX = 2 keeps the kernel under 128 VGPRs
+// (4 waves per SIMD); the 20 KiB of weight fragments are then read from LDS once per 32 samples.
+constexpr int NT_MAX = 2;
 template <bool GEN>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  int S, int lane, float density_scale) {
-  const int ntile = (S + 15) >> 4;  // wave-uniform
-  if (ntile <= 1) network_from_lds<1, GEN>(M, wl, lvs, W, S, lane, density_scale);
-  else if (ntile == 2) network_from_lds<2, GEN>(M, wl, lvs, W, S, lane, density_scale);
-  else network_from_lds<4, GEN>(M, wl, lvs, W, S, lane, density_scale);
+  for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
+    const int ntile = (S - base + 15) >> 4;
+    if (ntile <= 1) network_from_lds<1, GEN>(M, wl, lvs, W, S, base, lane, density_scale);
+    else network_from_lds<NT_MAX, GEN>(M, wl, lvs, W, S, base, lane, density_scale);
+  }
 }
 
 // ------------------------------------------------------- the render kernel ----
-#define NRF_RENDER_WAVES 2
+// 512 threads, >= 4 waves per SIMD (two workgroups per CU): caps the kernel at 128 VGPRs
 template <bool GEN, bool COARSE_LDS>
-__global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
                                                      float* __restrict__ depth, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
   const int nb = (int)gridDim.x, b = (int)blockIdx.x;
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  const int k_local = swz * 4 + wave;
+  const int k_local = swz * RENDER_WAVES + wave;
   if (k_local >= P.n_local_tiles) return;  // no barrier after this point
   const int tile = k_local * P.shard_count + P.shard_index;
   const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
@@ -193,6 +199,18 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
   float t = near;    // march position
   float tc = near;   // composited t (t at the last emitted sample)
   bool alive = in_img && (near < far);
+  // No sample can lie outside the (inflated) box of occupied cells: rays that miss it are done,
+  // the others stop marching where they leave it.  NaN-safe: a 0*inf in the slab test fails `<`.
+  float far_m = far;
+  {
+    float t_in, t_out;
+    box_interval(M.occ_box, o, rdx, rdy, rdz, t_in, t_out);
+    const bool hits = (M.occ_box[0] <= M.occ_box[3]) && (t_in <= t_out) && (t_out > near);
+    if (t_out < far_m) far_m = t_out;
+    const bool nan = !(t_in == t_in) || !(t_out == t_out);
+    if (nan) far_m = far;  // degenerate direction: fall back to the plain aabb range
+    alive = alive && (hits || nan);
+  }
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
   int n_ray_samples = 0;
   unsigned n_samples = 0, n_rounds = 0;
@@ -213,9 +231,9 @@ __global__ __launch_bounds__(256, NRF_RENDER_WAVES) void render_kernel(const Dev
       bool found = false;
       if (marching) {
         const int r = COARSE_LDS ? march_next<true>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                    rdy, rdz, sx, sy, sz, far, budget, t, x, y, z, dt)
+                                                    rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt)
                                  : march_next<false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                     rdy, rdz, sx, sy, sz, far, budget, t, x, y, z, dt);
+                                                     rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt);
         found = r == MARCH_FOUND;
         marching = found;
         ended = ended || r == MARCH_EXHAUSTED;
@@ -550,12 +568,12 @@ static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
 }
 
 hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st) {
-  const int blocks = (P.n_local_tiles + 3) / 4;
+  const int blocks = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
   if (blocks <= 0) return hipSuccess;
   const bool lds_tab = M.lds_coarse_words > 0;
   const int lds = LDS_FIXED_BYTES + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
 #define NRF_LAUNCH_RENDER(G, C)                                                                                          \
-  hipLaunchKernelGGL((render_kernel<G, C>), dim3(blocks), dim3(256), lds, st, M, P, (float4*)rgba, (float*)depth, \
+  hipLaunchKernelGGL((render_kernel<G, C>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, (float4*)rgba, (float*)depth, \
                      (unsigned long long*)counters)
   if (M.generic_act) {
     if (lds_tab) NRF_LAUNCH_RENDER(true, true); else NRF_LAUNCH_RENDER(true, false);
