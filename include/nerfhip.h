@@ -202,10 +202,17 @@ int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
  * returns to the context's own buffers.  Replaces the host round trip
  * render_frame -> host_to_accumulate_buffer of main.cu:87-129.               */
 int nrf_bind_output(nrf_context* ctx, void* rgba, void* depth);
+/* nrf_render on the context's own stream WITHOUT waiting for it (the way the
+ * reference overlaps its NGPU devices, nerf_render.cu:252-362); nrf_sync waits. */
+int nrf_render_async(nrf_context* ctx, const float cam[4], const float pose[16], nrf_frame* out);
+int nrf_sync(nrf_context* ctx);
 /* Host copy + quantisation, nerf_render.cu:345-359 (saturating, row-major). */
 int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
 /* Host copy of the float buffers (row-major; single-shard frames only).      */
 int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
+/* Host copy of this context's shard as rendered: rgba [n_tiles*64][4], depth
+ * [n_tiles*64] (tile-major when shard_count > 1, else the row-major frame).  */
+int nrf_read_shard_f32(nrf_context* ctx, float* rgba, float* depth);
 /* Rearranges gathered tile-major shards ([shard][n_tiles_max][64][C] floats,
  * as produced by an all-gather of every rank's nrf_frame buffer) into a
  * row-major [H][W][C] image on the device.  Replaces the de-interleave loop
@@ -240,6 +247,10 @@ int nrf_network(nrf_context* ctx, const void* xyz, const void* dir, uint32_t n,
 int nrf_generate_rays(nrf_context* ctx, const float cam[4], const float pose[16],
                       void* rays_o, void* rays_d, void* nears, void* fars,
                       void* stream);
+/* Same with HOST output arrays (any may be NULL); NerfRender::generate_rays
+ * (nerf_render.cu:369-386) for callers that hold no device memory.           */
+int nrf_generate_rays_host(nrf_context* ctx, const float cam[4], const float pose[16],
+                           float* rays_o, float* rays_d, float* nears, float* fars);
 /* kernel_march_rays (render_utils.h:524-655) for n rays with explicit start
  * t: xyzs [n][n_step][3], dirs likewise, deltas [n][n_step][2]; unused slots
  * are zero-filled (DESIGN.md deviation D-1).                                 */

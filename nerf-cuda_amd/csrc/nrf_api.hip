@@ -570,6 +570,20 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[8]) {
   return NRF_OK;
 }
 
+int nrf_render_async(nrf_context* c, const float cam[4], const float pose[16], nrf_frame* out) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  return nrf_render(c, cam, pose, (void*)c->stream, out);
+}
+
+int nrf_sync(nrf_context* c) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  int rc = set_device(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->last_stream && c->last_stream != c->stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
+  return NRF_OK;
+}
+
 int nrf_bind_output(nrf_context* c, void* rgba, void* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if ((rgba == nullptr) != (depth == nullptr)) return fail(NRF_E_INVALID, "bind both planes or neither");
@@ -603,6 +617,18 @@ int nrf_read_f32(nrf_context* c, float* rgba, float* depth) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->last_stream));
   const size_t n = (size_t)c->W * c->H;
+  if (rgba) HIP_TRY(hipMemcpy(rgba, c->last_rgba, n * 16, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(hipMemcpy(depth, c->last_depth, n * 4, hipMemcpyDeviceToHost));
+  return NRF_OK;
+}
+
+int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  int rc = set_device(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  const size_t n = c->opt.shard_count > 1 ? (size_t)c->n_local_tiles * 64 : (size_t)c->W * c->H;
   if (rgba) HIP_TRY(hipMemcpy(rgba, c->last_rgba, n * 16, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(hipMemcpy(depth, c->last_depth, n * 4, hipMemcpyDeviceToHost));
   return NRF_OK;
@@ -690,6 +716,30 @@ int nrf_generate_rays(nrf_context* c, const float cam[4], const float pose[16], 
   fill_frame_params(c, cam, pose, P);
   HIP_TRY(launch_generate_rays(c->dm, P, rays_o, rays_d, nears, fars, st));
   STAGE_EPILOGUE();
+}
+
+int nrf_generate_rays_host(nrf_context* c, const float cam[4], const float pose[16], float* rays_o, float* rays_d,
+                           float* nears, float* fars) {
+  int rc = need_model(c);
+  if (rc) return rc;
+  if (c->W <= 0) return fail(NRF_E_STATE, "set_resolution has not been called");
+  const size_t n = (size_t)c->W * c->H;
+  void* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, n * 8 * sizeof(float)));
+  float* d_o = (float*)buf;
+  float* d_d = d_o + 3 * n;
+  float* d_n = d_d + 3 * n;
+  float* d_f = d_n + n;
+  rc = nrf_generate_rays(c, cam, pose, d_o, d_d, d_n, d_f, nullptr);
+  hipError_t e = hipSuccess;
+  if (!rc && rays_o) e = hipMemcpy(rays_o, d_o, n * 12, hipMemcpyDeviceToHost);
+  if (!rc && e == hipSuccess && rays_d) e = hipMemcpy(rays_d, d_d, n * 12, hipMemcpyDeviceToHost);
+  if (!rc && e == hipSuccess && nears) e = hipMemcpy(nears, d_n, n * 4, hipMemcpyDeviceToHost);
+  if (!rc && e == hipSuccess && fars) e = hipMemcpy(fars, d_f, n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy");
+  return NRF_OK;
 }
 
 int nrf_march(nrf_context* c, const void* rays_o, const void* rays_d, const void* rays_t, const void* fars, uint32_t n,

@@ -1,0 +1,85 @@
+// nerf_render.h -- C++ host mirror of the reference's renderer class on the C ABI.
+//
+// Same names, argument meaning and error behaviour as ngp::NerfRender
+// (reference include/nerf-cuda/nerf_render.h:29-50), ngp::Camera and ngp::Image
+// (include/nerf-cuda/common.h:68-89).  Third-party parameter types are replaced
+// by small own equivalents: Eigen::Vector2i -> ngp::Vector2i, Eigen::Matrix4f ->
+// ngp::Matrix4f (row-major, operator()(row, col)), nlohmann::json -> mpk::Value,
+// filesystem::path -> std::string.  Everything device-side happens behind
+// include/nerfhip.h; this file contains no HIP.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/nerfhip.h"
+#include "msgpack_lite.h"
+
+namespace ngp {
+
+struct Camera {  // reference common.h:68-74
+  float fl_x, fl_y, cx, cy;
+};
+
+struct Image {  // reference common.h:76-89; pointers are owned by NerfRender, valid until the next render_frame
+  int W, H;
+  unsigned char* rgb;    // W * H * 3, row-major
+  unsigned char* depth;  // W * H
+  Image(int w, int h, unsigned char* in_rgb, unsigned char* in_depth) : W(w), H(h), rgb(in_rgb), depth(in_depth) {}
+};
+
+struct Vector2i {
+  int v[2];
+  Vector2i(int x = 0, int y = 0) : v{x, y} {}
+  int& operator[](int i) { return v[i]; }
+  int operator[](int i) const { return v[i]; }
+};
+
+struct Matrix4f {  // row-major 4x4, camera-to-world in the NeRF/Blender convention
+  float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float& operator()(int r, int c) { return m[4 * r + c]; }
+  float operator()(int r, int c) const { return m[4 * r + c]; }
+};
+
+class NerfRender {
+ public:
+  // The reference fixes the device count with the NGPU macro (common.h:91); here it is a
+  // constructor argument (or the NERF_NGPU environment variable).  Device i renders the 8x8
+  // tiles with tile_id % n == i; the shards are gathered on the host like nerf_render.cu:345-359.
+  // n_gpus < 0: host-only instance that can load and inspect snapshots but not render.
+  explicit NerfRender(int n_gpus = 0);
+  ~NerfRender();
+  NerfRender(const NerfRender&) = delete;
+  NerfRender& operator=(const NerfRender&) = delete;
+
+  void reload_network_from_file(const std::string& network_config_path);
+  mpk::Value load_network_config(const std::string& network_config_path);
+  void reset_network();
+  void set_resolution(Vector2i resolution);
+  Image render_frame(Camera cam, Matrix4f pos);
+  // device ray buffers of the reference are internal to the fused kernel; this fills host copies
+  void generate_rays(Camera cam, Matrix4f pos, int threadid);
+  void generate_density_grid();  // dead code in the reference (nerf_render.cu:388-429): throws
+  void load_snapshot(const std::string& filepath_string);
+
+  // additions (the reference has no accessors)
+  int n_gpus() const { return (int)m_ctx.size(); }
+  const nrf_model_desc& model_desc() const { return m_desc; }
+  nrf_stats last_stats(int gpu = 0) const;
+  const std::vector<float>& rays_o() const { return m_rays_o; }
+  const std::vector<float>& rays_d() const { return m_rays_d; }
+
+ private:
+  void check(int rc, const char* what) const;
+  std::vector<nrf_context*> m_ctx;
+  mpk::Value m_network_config;
+  std::string m_network_config_path;
+  nrf_model_desc m_desc{};
+  bool m_have_snapshot = false, m_have_network = false;
+  std::vector<float> m_params, m_density_grid;
+  Vector2i resolution;
+  std::vector<unsigned char> us_image, us_depth;
+  std::vector<float> m_shard_rgba, m_shard_depth, m_rays_o, m_rays_d;
+  int m_tiles_per_shard = 0;
+};
+
+}  // namespace ngp

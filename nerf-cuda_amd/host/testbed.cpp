@@ -1,0 +1,49 @@
+// testbed.cpp -- mirror of the reference's `testbed` main (src/main.cu:131-206) without the
+// GLFW/Vulkan/DLSS presentation part: load a snapshot, render ONE frame with the hard-coded camera
+// and pose, print "Process time", write image.png / deep.png.
+//   usage: testbed [snapshot.msgpack] [width height] [out_prefix]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "nerf_render.h"
+#include "png_lite.h"
+
+using namespace ngp;
+
+int main(int argc, char** argv) {
+  std::cout << "Hello, Metavese!" << std::endl;
+  try {
+    NerfRender* render = new NerfRender();
+    const std::string config_path = argc > 1 ? argv[1] : "freality.msgpack";
+    render->reload_network_from_file(config_path);  // Init Model
+    const int W = argc > 3 ? std::atoi(argv[2]) : 4000 / 8, H = argc > 3 ? std::atoi(argv[3]) : 4000 / 8;
+    const std::string prefix = argc > 4 ? argv[4] : "./";
+    const float s = (float)W / 500.0f;
+    Camera cam = {3550.115f / 8 * s, 3554.515f / 8 * s, 3010.45f / 8 * s, 1996.027f / 8 * s};
+    Matrix4f pos;
+    const float p[16] = {-0.5575427361517304f, -0.11682263918046752f, 0.8218871992959822f, 3.9673954052389253f,
+                         0.8300327085486383f,  -0.094966079921629f,   0.5495699649760266f, 2.667431152445114f,
+                         0.013849191732089516f, 0.9886020001326434f,  0.14991425965987268f, 0.45955395816033995f,
+                         0.0f, 0.0f, 0.0f, 1.0f};
+    for (int i = 0; i < 16; ++i) pos.m[i] = p[i];
+    render->set_resolution(Vector2i(W, H));
+    const auto t0 = std::chrono::steady_clock::now();
+    Image img = render->render_frame(cam, pos);
+    const auto t1 = std::chrono::steady_clock::now();
+    std::printf("Process time : %f s / frame\n", std::chrono::duration<double>(t1 - t0).count());
+    const nrf_stats st = render->last_stats();
+    std::printf("samples %llu  device time %.3f ms\n", (unsigned long long)st.n_samples, st.render_ms);
+    pnglite::write((prefix + "deep.png").c_str(), img.W, img.H, 1, img.depth);
+    pnglite::write((prefix + "image.png").c_str(), img.W, img.H, 3, img.rgb);
+    FILE* f = std::fopen((prefix + "image.rgb").c_str(), "wb");  // raw copy for the parity test
+    if (f) { std::fwrite(img.rgb, 1, (size_t)img.W * img.H * 3, f); std::fclose(f); }
+    delete render;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -137,8 +137,13 @@ _SIGS = {
     "nrf_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "nrf_render": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(Frame)]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_render_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
+    "nrf_sync": (C.c_int, [C.c_void_p]),
+    "nrf_generate_rays_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     "nrf_read_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_read_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_read_shard_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),

@@ -173,3 +173,26 @@ REFERENCE_MAIN_POSE = np.array([  # the hard-coded pose of reference src/main.cu
     [0.8300327085486383, -0.094966079921629, 0.5495699649760266, 2.667431152445114],
     [0.013849191732089516, 0.9886020001326434, 0.14991425965987268, 0.45955395816033995],
     [0.0, 0.0, 0.0, 1.0]], np.float32)
+
+
+def write_snapshot(path, config, params, density_grid):
+    """Writes a snapshot in the format the reference consumes: msgpack of a
+    JSON object whose `snapshot.params` / `snapshot.density_grid` are plain arrays of numbers
+    (float32 on the wire)."""
+    import msgpack
+
+    cfg = {k: v for k, v in config.items() if k != "snapshot"}
+    snap = dict(config["snapshot"])
+    snap["params"] = np.asarray(params, np.float32).tolist()
+    snap["density_grid"] = np.asarray(density_grid, np.float32).tolist()
+    cfg["snapshot"] = snap
+    with open(path, "wb") as f:
+        f.write(msgpack.packb(cfg, use_single_float=True))
+
+
+def read_snapshot(path):
+    """Inverse of write_snapshot: returns the config dict (arrays as lists)."""
+    import msgpack
+
+    with open(path, "rb") as f:
+        return msgpack.unpackb(f.read(), raw=False)

@@ -1,0 +1,137 @@
+"""The C++ host mirror (nerf-cuda_amd/host): snapshot parsing and config derivation on the CPU,
+the testbed and the render_server wire protocol on the GPU."""
+import json
+import socket
+import subprocess
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import synthetic as syn
+
+ROOT = Path(__file__).resolve().parent.parent
+HOST = ROOT / "nerf-cuda_amd" / "host"
+
+
+@pytest.fixture(scope="module")
+def snapshot(tmp_path_factory):
+    d = tmp_path_factory.mktemp("snap")
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    path = d / "tiny.msgpack"
+    syn.write_snapshot(path, cfg, keep[0], keep[1])
+    return path, desc, keep, cfg
+
+
+def _info(path):
+    r = subprocess.run([str(HOST / "snapshot_info"), str(path)], capture_output=True, text=True)
+    return r
+
+
+def test_cpp_snapshot_parsing_matches_python(snapshot):
+    path, desc, keep, cfg = snapshot
+    r = _info(path)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["rc"] == 0 and d["n_params"] == desc.n_params == d["expected"]
+    assert d["n_grid"] == desc.n_density_grid
+    for k, v in dict(grid_type=desc.grid_type, n_levels=desc.n_levels, F=desc.n_features_per_level,
+                     log2T=desc.log2_hashmap_size, base=desc.base_resolution, n_neurons=desc.n_neurons,
+                     dh=desc.density_hidden_layers, da=desc.density_activation, doa=desc.density_output_activation,
+                     dno=desc.density_n_output, sa=desc.sigma_activation, rh=desc.rgb_hidden_layers,
+                     ra=desc.rgb_activation, roa=desc.rgb_output_activation, dir=desc.dir_encoding,
+                     shdeg=desc.sh_degree, cascade=desc.cascade, H=desc.density_grid_size).items():
+        assert d[k] == v, k
+    assert d["pls"] == pytest.approx(desc.per_level_scale, rel=1e-7)
+    assert d["bound"] == desc.bound and d["scale"] == pytest.approx(desc.scale)
+    assert d["mean_density"] == pytest.approx(desc.mean_density, rel=1e-6)
+    # python round trip of the same file
+    back = syn.read_snapshot(path)
+    d2, _ = nh.desc_from_config(back)
+    assert d2.n_params == desc.n_params and d2.per_level_scale == desc.per_level_scale
+
+
+def test_cpp_error_behaviour(tmp_path, snapshot):
+    # nerf_render.cu:73-76: missing file
+    r = _info(tmp_path / "nope.msgpack")
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    # nerf_render.cu:434-436: no snapshot block
+    import msgpack
+    p = tmp_path / "nosnap.msgpack"
+    p.write_bytes(msgpack.packb({"encoding": {"otype": "HashGrid"}}))
+    r = _info(p)
+    assert r.returncode == 1 and "does not contain a snapshot" in r.stderr
+    # nerf_render.cu:467-469: density grid size vs cascade
+    path, desc, keep, cfg = snapshot
+    bad = dict(cfg)
+    bad["snapshot"] = dict(cfg["snapshot"], cascade=2)
+    p = tmp_path / "badgrid.msgpack"
+    syn.write_snapshot(p, bad, keep[0], keep[1])
+    r = _info(p)
+    assert r.returncode == 1 and "Incompatible number of grid cascades" in r.stderr
+
+
+@pytest.mark.gpu
+def test_testbed_matches_python_binding(tmp_path, snapshot):
+    path, desc, keep, cfg = snapshot
+    W, H = 120, 88
+    r = subprocess.run([str(HOST / "testbed"), str(path), str(W), str(H), str(tmp_path) + "/"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Process time" in r.stdout
+    got = np.fromfile(tmp_path / "image.rgb", np.uint8).reshape(H, W, 3)
+    assert (tmp_path / "image.png").stat().st_size > W * H * 3 and (tmp_path / "deep.png").exists()
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    ctx.set_resolution(W, H)
+    s = np.float32(W) / np.float32(500.0)
+    cam = np.array([3550.115 / 8, 3554.515 / 8, 3010.45 / 8, 1996.027 / 8], np.float32) * s
+    ctx.render(cam, syn.REFERENCE_MAIN_POSE)
+    rgb8, _ = ctx.read_u8()
+    np.testing.assert_array_equal(got, rgb8)
+    assert rgb8.min() < 250  # the object is in view
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_render_server_wire_protocol(snapshot):
+    path, desc, keep, cfg = snapshot
+    W, H, port = 64, 64, 23457
+    srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    try:
+        sock = None
+        for _ in range(200):
+            try:
+                sock = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                break
+            except OSError:
+                time.sleep(0.1)
+        assert sock is not None, "server did not come up"
+        sock.settimeout(30)
+        ctx = nh.NerfHip(0)
+        ctx.load_model(desc)
+        ctx.set_resolution(W, H)
+        cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
+        for pose in (syn.REFERENCE_MAIN_POSE, syn.orbit_pose(200, 20)):
+            sock.sendall(np.ascontiguousarray(pose, np.float32).tobytes())  # 64 bytes, row-major 4x4
+            buf = bytearray()
+            while len(buf) < 3 * W * H:
+                chunk = sock.recv(3 * W * H - len(buf))
+                assert chunk, "connection closed early"
+                buf += chunk
+            ctx.render(cam, pose)
+            rgb8, _ = ctx.read_u8()
+            np.testing.assert_array_equal(np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3), rgb8)
+        quit_msg = np.zeros(16, np.float32)
+        quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
+        sock.sendall(quit_msg.tobytes())
+        sock.close()
+        srv.wait(timeout=20)
+        ctx.close()
+    finally:
+        if srv.poll() is None:
+            srv.kill()
