@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the frame unsharded and compares")
     args = ap.parse_args()
 
     import torch
@@ -61,13 +65,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = 0 if (world == 1 or args.single_device) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    dev = torch.device("cuda", dev_index)
     W, H = args.width, args.height
 
     # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits)
@@ -136,6 +142,22 @@ def main():
     else:
         total_samples = local_samples
 
+    check = None
+    if args.check and world > 1:
+        # the gathered + untiled frame of the last step must equal an unsharded render of the same pose
+        torch.cuda.synchronize(dev)
+        step(0)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            solo = nh.NerfHip(dev.index)
+            solo.load_model(desc)
+            solo.set_resolution(W, H)
+            solo.render(cam, poses[0])
+            want, _ = solo.read_f32()
+            check = bool(np.array_equal(frame.cpu().numpy(), want))
+            solo.close()
+        dist.barrier()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -178,6 +200,8 @@ def main():
             "mfma_frac": round(mean_samples_launch * FLOP_PER_SAMPLE / mean_kern_s / 1e12 / MFMA_PEAK_TFLOPS, 5),
         },
     }
+    if check is not None:
+        out["sharded_frame_equals_unsharded"] = check
     if world == 1:
         out["config"]["samples_per_frame"] = int(mean_samples_launch)
         out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)

@@ -423,3 +423,22 @@ class NerfHip:
     def composite(self, sigmas, rgbs, deltas, n, n_step, rays_t, state, stream=None):
         _check(self.lib.nrf_composite(self.h, C.c_void_p(sigmas), C.c_void_p(rgbs), C.c_void_p(deltas), n, n_step,
                                       C.c_void_p(rays_t), C.c_void_p(state), C.c_void_p(stream or 0)))
+
+
+# --------------------------------------------------------------------------
+# tile partition of one frame over ranks (host-side mirror of render_kernel's mapping and of
+# untile_kernel): tile id = ty*ceil(W/8)+tx belongs to rank tile_id % world, local index tile_id // world
+# --------------------------------------------------------------------------
+def shard_tile_ids(width: int, height: int, rank: int, world: int):
+    total = ((width + 7) // 8) * ((height + 7) // 8)
+    return list(range(rank, total, world))
+
+
+def untile_numpy(gathered: np.ndarray, width: int, height: int):
+    """gathered [world][tiles_per_shard*64][C] (every rank's tile-major shard) -> [H][W][C]."""
+    world = gathered.shape[0]
+    tiles_x = (width + 7) // 8
+    ys, xs = np.mgrid[0:height, 0:width]
+    tile = (ys // 8) * tiles_x + xs // 8
+    lane = (ys % 8) * 8 + xs % 8
+    return gathered[tile % world, (tile // world) * 64 + lane]

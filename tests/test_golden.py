@@ -1,0 +1,71 @@
+"""Committed golden fixture (tests/golden/tiny_scene.npz, made by make_golden.py with the oracle):
+the oracle must keep reproducing it bit for bit (CPU), the HIP path must match it (GPU)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import oracle_py as op
+import synthetic as syn
+
+G = np.load(Path(__file__).parent / "golden" / "tiny_scene.npz")
+LOG2T, H, W, HH, SEED = [int(v) for v in G["meta"]]
+
+
+def _model():
+    desc, keep, cfg = models.build_model(log2_hashmap_size=LOG2T, H=H, seed=SEED)
+    # the fixture stores its own inputs: rebuild the description from them, not from the generator
+    desc, keep = nh.desc_from_config(cfg, G["params"], G["density_grid"].astype(np.float32))
+    return desc, keep
+
+
+def test_generator_is_reproducible():
+    desc, keep, cfg = models.build_model(log2_hashmap_size=LOG2T, H=H, seed=SEED)
+    np.testing.assert_array_equal(keep[0], G["params"])
+    np.testing.assert_array_equal(keep[1], G["density_grid"].astype(np.float32))
+
+
+def test_oracle_reproduces_golden():
+    desc, keep = _model()
+    o = op.Oracle(desc)
+    d01 = (np.float32(0.5) * G["dir"] + np.float32(0.5)).astype(np.float32)
+    np.testing.assert_array_equal(o.encode_grid(G["pos01"]), G["feat"])
+    np.testing.assert_array_equal(o.encode_dir(d01), G["dirf"])
+    np.testing.assert_array_equal(o.mlp_forward(G["feat"], G["dirf"]), G["out4"])
+    xyz = ((G["pos01"] - np.float32(0.5)) * np.float32(2.0)).astype(np.float32)
+    s, c = o.network(xyz, G["dir"])
+    np.testing.assert_array_equal(s, G["sigma"])
+    np.testing.assert_array_equal(c, G["rgb"])
+    ro, rd, nr, fr = o.generate_rays(G["cam"], G["pose"], W, HH)
+    np.testing.assert_array_equal(rd, G["rays_d"])
+    np.testing.assert_array_equal(nr, G["nears"])
+    xyzs, dirs, deltas = o.march(ro, rd, nr, fr, 4)
+    np.testing.assert_array_equal(xyzs, G["xyzs"])
+    np.testing.assert_array_equal(deltas, G["deltas"])
+    rgba, depth, st = o.render(G["cam"], G["pose"], W, HH, schedule=op.SCHED_PER_RAY)
+    np.testing.assert_array_equal(rgba, G["rgba"])
+    np.testing.assert_array_equal(depth, G["depth"])
+    assert st.n_samples == int(G["n_samples"]) > 0
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden():
+    torch = pytest.importorskip("torch")
+    desc, keep = _model()
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    n = len(G["pos01"])
+    pos = torch.from_numpy(G["pos01"]).cuda()
+    out = torch.empty((n, 32), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_grid(pos.data_ptr(), n, out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), G["feat"])  # bit-exact
+    ctx.set_resolution(W, HH)
+    ctx.render(G["cam"], G["pose"])
+    rgba, depth = ctx.read_f32()
+    assert np.abs(rgba - G["rgba"]).max() <= 2.0 / 255.0 and models.psnr(rgba, G["rgba"]) >= 45.0
+    assert np.abs(depth - G["depth"]).max() <= 2.0 / 255.0
+    assert ctx.stats().n_samples >= int(G["n_samples"])
+    ctx.close()

@@ -1,0 +1,81 @@
+"""The N > 1 path on CPU: two gloo ranks shard one frame by 8x8 tiles exactly as bench.py does
+(tile_id % world == rank), exchange their tile-major shards with ONE all_gather, and rank 0 untiles.
+The GPU kernels are replaced by a per-pixel function, so this covers the host-side partition,
+padding and gather logic (the device untile kernel is checked against the same mapping on the GPU)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, q):
+    sys.path[:0] = [str(ROOT / "nerf-cuda_amd")]
+    import torch
+    import torch.distributed as dist
+
+    import nerfhip as nh
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tps = nh.tiles_per_shard(W, H, world)
+    tiles = nh.shard_tile_ids(W, H, rank, world)
+    tiles_x = (W + 7) // 8
+    shard = torch.zeros((tps * 64, 4))
+    for k, t in enumerate(tiles):  # "render": pixel value = f(x, y), zeros outside the image
+        tx, ty = t % tiles_x, t // tiles_x
+        for l in range(64):
+            px, py = tx * 8 + (l & 7), ty * 8 + (l >> 3)
+            if px < W and py < H:
+                shard[k * 64 + l] = torch.tensor([px, py, px * 0.5 + py, 1.0])
+    gathered = torch.empty((world, tps * 64, 4))
+    dist.all_gather_into_tensor(gathered.view(-1), shard.view(-1))
+    samples = torch.tensor([len(tiles) * 10], dtype=torch.int64)
+    dist.all_reduce(samples)
+    if rank == 0:
+        q.put((nh.untile_numpy(gathered.numpy(), W, H), int(samples.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H", [(40, 24), (37, 19)])
+def test_two_rank_tile_sharding_gloo(W, H):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    img, samples = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ys, xs = np.mgrid[0:H, 0:W]
+    np.testing.assert_array_equal(img[..., 0], xs)
+    np.testing.assert_array_equal(img[..., 1], ys)
+    np.testing.assert_array_equal(img[..., 2], xs * 0.5 + ys)
+    total_tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    assert samples == total_tiles * 10  # every tile owned by exactly one rank
+
+
+def test_partition_is_exact_cover():
+    sys.path[:0] = [str(ROOT / "nerf-cuda_amd")]
+    import nerfhip as nh
+    for W, H, world in [(1920, 1080, 8), (1920, 1080, 3), (20, 12, 4), (8, 8, 2)]:
+        ids = sorted(t for r in range(world) for t in nh.shard_tile_ids(W, H, r, world))
+        assert ids == list(range(((W + 7) // 8) * ((H + 7) // 8)))
+        assert max(len(nh.shard_tile_ids(W, H, r, world)) for r in range(world)) == nh.tiles_per_shard(W, H, world)
