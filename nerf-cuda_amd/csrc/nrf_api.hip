@@ -372,9 +372,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   std::vector<_Float16> frags;
   pack_fragments(w16, frags);
   const size_t n_grid = (size_t)lv.offset[16] * 2;
-  std::vector<_Float16> grid16(n_grid);
   const float* gp = d->params + n_mlp;
-  for (size_t i = 0; i < n_grid; ++i) grid16[i] = (_Float16)gp[i];
   // occupancy bitfield: grid[cell] > min(0.01, mean_density) (render_utils.h:560,619), decided once
   const float thresh = fminf(0.01f, d->mean_density);
   std::vector<uint32_t> occ((cells + 31) / 32 + 1, 0u);
@@ -432,12 +430,12 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   }
 
   std::vector<LevelParams> lp(16);
+  bool generic_grid = false;
   for (uint32_t l = 0; l < 16; ++l) {
     LevelParams& L = lp[l];
     std::memset(&L, 0, sizeof(L));
     L.scale = lv.scale[l];
     L.res = lv.resolution[l];
-    L.offset = lv.offset[l];
     L.size = lv.offset[l + 1] - lv.offset[l];
     L.hashed = d->grid_type == NRF_GRID_HASH;
     // replay grid_index's stride loop (grid.h:106-114) in uint32 to classify the level
@@ -448,8 +446,23 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     if (uses_hash && (L.size & (L.size - 1)) == 0) L.mode = LV_HASH_POW2;
     else if (!uses_hash && dims == 3 && L.res >= 2 && (uint64_t)L.res * L.res * L.res <= L.size) L.mode = LV_DENSE;
     else L.mode = LV_GENERIC;
+    generic_grid = generic_grid || L.mode == LV_GENERIC;
   }
-
+  // Device copy of the table: the reference's entries level by level; a dense level is followed by
+  // res^2 + res + 1 copies of its first entries so that x + y*res + z*res^2 (at most
+  // size + res^2 + res when a +1 corner sits on the x = 1 / y = 1 / z = 1 face) needs no modulo.
+  std::vector<_Float16> grid16;
+  grid16.reserve(n_grid + 2 * 16 * 4096);
+  for (uint32_t l = 0; l < 16; ++l) {
+    LevelParams& L = lp[l];
+    L.offset = (uint32_t)(grid16.size() / 2);
+    const float* src = gp + (size_t)lv.offset[l] * 2;
+    for (size_t i = 0; i < (size_t)L.size * 2; ++i) grid16.push_back((_Float16)src[i]);
+    if (L.mode == LV_DENSE) {
+      const size_t extra = (size_t)L.res * L.res + L.res + 1;
+      for (size_t i = 0; i < extra * 2; ++i) grid16.push_back((_Float16)src[i % ((size_t)L.size * 2)]);
+    }
+  }
   // Uploads go through the context's own stream and the device is drained afterwards: the
   // render stream is non-blocking, so a NULL-stream hipMemcpy gives no ordering against it
   // (seen on MI355X as a few stale table entries in the first frame after a reload).
@@ -458,7 +471,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   };
-  HIP_TRY(upload(&c->d_grid, grid16.data(), n_grid * 2));
+  HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
@@ -503,7 +516,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.sigma_activation = d->sigma_activation;
   M.rgb_activation = d->rgb_activation;
   M.rgb_output_activation = d->rgb_output_activation;
-  M.generic_act = !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+  M.generic_act = generic_grid || !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
                     d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
                     d->sigma_activation == NRF_ACT_EXPONENTIAL);
   c->model_loaded = true;

@@ -77,7 +77,8 @@ struct DevModel {
   uint32_t dir_encoding, sh_degree, n_frequencies;
   uint32_t density_activation, density_output_activation, sigma_activation;
   uint32_t rgb_activation, rgb_output_activation;
-  uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential (compile-time fast path)
+  uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential AND every grid level dense or
+                         // power-of-two hashed (compile-time fast path); 1: the generic kernel instances
   uint32_t coarse_shift;    // 2 or 0
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
@@ -272,9 +273,24 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
 }
 
 // ------------------------------------------------------------- hash grid ----
+// (half)(w * (float)h) for both halves of a table entry: fp32 product rounded to fp32, then to fp16
+// (grid.h:258-260).  NOT v_fma_mixlo/hi_f16: measured on gfx950 it rounds the exact product once,
+// which differs from these two roundings for about 1 in 30 000 products.
+__device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
+  const half2_t val = bits_h2(entry);
+  half2_t p;
+  p.x = (half_t)(w * (float)val.x);
+  p.y = (half_t)(w * (float)val.y);
+  return p;
+}
+
 // One (sample, level) of kernel_grid<half,3,2>: 8 corner gathers of a half2,
 // fp16 accumulation in corner order (grid.h:236-262).  Returns the packed
 // half2 (feature 0 in the low half).
+//   GENERIC == false: every level is LV_DENSE or LV_HASH_POW2 (the hot path); dense levels are
+//   stored with res^2 + res + 1 wrapped entries appended (nrf_api.hip), so `index % size` of
+//   grid.h:116 needs no instruction: a dense index never exceeds size + res^2 + res.
+template <bool GENERIC>
 __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
                                                  float py, float pz) {
   float fx = px * L.scale; fx = fx + 0.5f;
@@ -289,7 +305,7 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
   const uint32_t* table = grid + L.offset;
 
   uint32_t idx[8];
-  if (L.mode == LV_GENERIC) {
+  if (GENERIC && L.mode == LV_GENERIC) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t p0 = gx + (c & 1), p1 = gy + ((c >> 1) & 1), p2 = gz + ((c >> 2) & 1);
@@ -307,18 +323,15 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
     const bool hashed = L.mode == LV_HASH_POW2;
     const uint32_t my = hashed ? 2654435761u : L.res;
     const uint32_t mz = hashed ? 805459861u : L.res * L.res;
+    const uint32_t mask = hashed ? L.size - 1 : 0xffffffffu;
     const uint32_t ax[2] = {gx, gx + 1};
     const uint32_t ay0 = gy * my, az0 = gz * mz;
     const uint32_t ay[2] = {ay0, ay0 + my};
     const uint32_t az[2] = {az0, az0 + mz};
-    const uint32_t mask = L.size - 1;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
-      const uint32_t hsh = (a ^ b ^ d) & mask;
-      uint32_t dns = a + b + d;
-      dns = dns >= L.size ? dns - L.size : dns;
-      idx[c] = hashed ? hsh : dns;
+      idx[c] = (hashed ? (a ^ b ^ d) : (a + b + d)) & mask;
     }
   }
   uint32_t v[8];
@@ -330,11 +343,7 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
   for (int c = 0; c < 8; ++c) {
     // weight = ((1 * wx) * wy) * wz in dimension order (grid.h:240-252)
     const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
-    const half2_t val = bits_h2(v[c]);
-    half2_t p;
-    p.x = (half_t)(w * (float)val.x);
-    p.y = (half_t)(w * (float)val.y);
-    acc = acc + p;  // v_pk_add_f16, RNE: result += (T)(weight * data)
+    acc = acc + weight_times_entry(w, v[c]);  // v_pk_add_f16, RNE: result += (T)(weight * data)
   }
   return h2_bits(acc);
 }
@@ -434,18 +443,27 @@ __device__ __forceinline__ float act_sel(uint32_t runtime_act, float v) {
   else return v;
 }
 
-// pack two D fragments (after the hidden activation, rounded to fp16) into one B fragment
+// pack two D fragments (after the hidden activation, rounded to fp16) into one B fragment.
+// Hot path: ReLU commutes with the (monotonic, sign-preserving) rounding to fp16, so it is applied
+// to the packed halves: one v_pk_max_f16 per two values instead of two v_max_f32 per value.
 template <bool GEN>
 __device__ __forceinline__ half8_t pack_acc(uint32_t act, float4_t lo, float4_t hi) {
   half8_t r;
-  r[0] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[0]);
-  r[1] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[1]);
-  r[2] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[2]);
-  r[3] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, lo[3]);
-  r[4] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[0]);
-  r[5] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[1]);
-  r[6] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[2]);
-  r[7] = (half_t)act_sel<GEN, NRF_ACT_RELU>(act, hi[3]);
+  if constexpr (GEN) {
+    r[0] = (half_t)activate(act, lo[0]);
+    r[1] = (half_t)activate(act, lo[1]);
+    r[2] = (half_t)activate(act, lo[2]);
+    r[3] = (half_t)activate(act, lo[3]);
+    r[4] = (half_t)activate(act, hi[0]);
+    r[5] = (half_t)activate(act, hi[1]);
+    r[6] = (half_t)activate(act, hi[2]);
+    r[7] = (half_t)activate(act, hi[3]);
+  } else {
+    r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
+    r[4] = (half_t)hi[0]; r[5] = (half_t)hi[1]; r[6] = (half_t)hi[2]; r[7] = (half_t)hi[3];
+    const half8_t zero8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    r = __builtin_elementwise_max(r, zero8);
+  }
   return r;
 }
 

@@ -89,7 +89,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       float py = M.pos_w * p.y; py = py + 0.5f;
       float pz = M.pos_w * p.z; pz = pz + 0.5f;
 #pragma unroll
-      for (int jl = 0; jl < 4; ++jl) fb[jl] = encode_level(M.grid, lvs[4 * g + jl], px, py, pz);
+      for (int jl = 0; jl < 4; ++jl) fb[jl] = encode_level<GEN>(M.grid, lvs[4 * g + jl], px, py, pz);
       const int ray = __builtin_bit_cast(int, W->aux[slot].y);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
   const uint64_t total = (uint64_t)n * 16u;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
-    out[i] = encode_level(M.grid, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
+    out[i] = encode_level<true>(M.grid, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
   }
 }
 
