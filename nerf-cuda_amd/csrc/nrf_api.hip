@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -162,6 +163,7 @@ struct nrf_context {
   void* bound_depth = nullptr;
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
+  int march_budget = 16;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
   bool rendered = false;
   hipStream_t last_stream = nullptr;
 };
@@ -236,6 +238,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.dt_gamma = c->opt.dt_gamma;
   P.density_scale = c->opt.density_scale;
   P.max_steps = c->opt.max_steps;
+  P.march_budget = c->march_budget;
   return NRF_OK;
 }
 
@@ -305,6 +308,10 @@ int nrf_create(int device, nrf_context** out) {
   nrf_context* c = new nrf_context;
   c->device = device;
   nrf_default_options(&c->opt);
+  if (const char* e = std::getenv("NRF_MARCH_BUDGET")) {
+    const int b = std::atoi(e);
+    if (b >= 1 && b <= 4096) c->march_budget = b;
+  }
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));

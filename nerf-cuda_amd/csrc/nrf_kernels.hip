@@ -145,11 +145,11 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     __syncthreads();
   }
 
-  // XCD-aware block order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each
-  // XCD one contiguous band of tile strips -> neighbouring tiles share that XCD's L2 (bijective remap).
-  const int nb = (int)gridDim.x, b = (int)blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  // Block -> tile-strip order.  Consecutive blocks go to different XCDs (round-robin dispatch); keeping
+  // that order interleaves the image over all 8 XCDs at strip granularity, which balances the load
+  // (the object covers a few image bands only; an "XCD owns a contiguous band" remap left half of
+  // the XCDs idle: 43 % wave-slot occupancy in profiles/r01/pmc_summary_c.txt).
+  const int swz = (int)blockIdx.x;
   const int k_local = swz * RENDER_WAVES + wave;
   if (k_local >= P.n_local_tiles) return;  // no barrier after this point
   const int tile = k_local * P.shard_count + P.shard_index;
@@ -193,9 +193,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // T < 1e-4, when t >= far, or after max_steps samples.  How samples of different rays are
   // batched into rounds therefore cannot change the picture, and the batching below is chosen
   // for the hardware: every round fills up to 64 LDS sample slots (<= 8 per ray), and a lane
-  // may spend at most MARCH_BUDGET cell trips per round, so that one ray crossing empty space
+  // may spend at most P.march_budget cell trips per round, so that one ray crossing empty space
   // never stalls the other 63 (it simply contributes no sample until it finds one).
-  constexpr int MARCH_BUDGET = 16;
   float t = near;    // march position
   float tc = near;   // composited t (t at the last emitted sample)
   bool alive = in_img && (near < far);
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     // ---- march: ballot/mbcnt compaction of the found samples, k-major, into the wave's LDS slots
     unsigned long long slots = 0ull;
     int cnt = 0, S = 0;
-    int budget = MARCH_BUDGET;
+    int budget = P.march_budget;
     bool marching = alive;
     bool ended = false;  // t >= far or sample cap: the ray dies after compositing this round's samples
     for (int k = 0; k < 8; ++k) {
