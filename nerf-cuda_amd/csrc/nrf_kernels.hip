@@ -21,16 +21,18 @@ namespace nrf {
 
 // ---------------------------------------------------------------- LDS map ----
 struct WaveLds {
-  float4 pos[64];        // sample slot: x, y, z (world, clamped), dt
-  float2 aux[64];        // sample slot: t - last_t, ray lane (bit pattern)
-  float4 out[64];        // sample slot: r, g, b, sigma
+  union {
+    float4 pos[64];      // sample slot before the network phase: x, y, z (world, clamped), ray lane (bit pattern)
+    float4 out[64];      // sample slot after it: r, g, b, sigma (each lane overwrites only slots it has consumed)
+  };
+  float2 aux[64];        // sample slot: dt, composited t
   uint32_t dirf[64][8];  // ray lane: 16 fp16 direction-encoding values
 };
-static_assert(sizeof(WaveLds) == 4608, "WaveLds layout");
+static_assert(sizeof(WaveLds) == 3584, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
-constexpr int RENDER_WAVES = 8;  // waves (8x8 pixel tiles) per workgroup
+constexpr int RENDER_WAVES = 4;  // waves (8x8 pixel tiles) per workgroup
 constexpr int RENDER_THREADS = 64 * RENDER_WAVES;
 constexpr int LDS_FIXED_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + RENDER_WAVES * (int)sizeof(WaveLds);
 constexpr int LDS_TOTAL_BYTES = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + 4 * (int)sizeof(WaveLds);  // network_kernel (4 waves)
@@ -90,7 +92,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       float pz = M.pos_w * p.z; pz = pz + 0.5f;
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) fb[jl] = encode_level<GEN>(M.grid, lvs[4 * g + jl], px, py, pz);
-      const int ray = __builtin_bit_cast(int, W->aux[slot].y);
+      const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
     }
     const uint4 fv = make_uint4(fb[0], fb[1], fb[2], fb[3]);
@@ -124,7 +126,9 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 }
 
 // ------------------------------------------------------- the render kernel ----
-// 512 threads, >= 4 waves per SIMD (two workgroups per CU): caps the kernel at 128 VGPRs
+// 256 threads, >= 4 waves per SIMD (four workgroups per CU, 39.9 KB of LDS each): caps the kernel at
+// 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
+// slowest tile is done.
 template <bool GEN, bool COARSE_LDS>
 __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
                                                      float* __restrict__ depth, unsigned long long* __restrict__ counters) {
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
         const float delta = tn - tc;    // deltas[1] = t - last_t (last_t == composited t)
         tc = tc + delta;                // composite: t += deltas[1]
         t = tc;                         // next march starts from rays_t
-        W->pos[slot] = make_float4(x, y, z, dt);
-        W->aux[slot] = make_float2(tc, __builtin_bit_cast(float, lane));
+        W->pos[slot] = make_float4(x, y, z, __builtin_bit_cast(float, lane));
+        W->aux[slot] = make_float2(dt, tc);
         slots |= (unsigned long long)slot << (8 * k);
         cnt++;
         if (n_ray_samples + cnt >= P.max_steps) { marching = false; ended = true; }
@@ -269,12 +273,12 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
         if (k >= cnt) break;
         const int slot = (int)((slots >> (8 * k)) & 0xffull);
         const float4 so = W->out[slot];
-        const float dt = W->pos[slot].w;
-        const float alpha = 1.0f - __expf(-so.w * dt);
+        const float2 dtc = W->aux[slot];
+        const float alpha = 1.0f - __expf(-so.w * dtc.x);
         const float T = 1 - ws;
         const float wgt = alpha * T;
         ws += wgt;
-        dep += wgt * W->aux[slot].x;  // depth += weight * t, t = composited t of this sample
+        dep += wgt * dtc.y;  // depth += weight * t, t = composited t of this sample
         cr += wgt * so.x;
         cg += wgt * so.y;
         cb += wgt * so.z;
@@ -410,8 +414,8 @@ __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const
     const uint32_t i = (chunk << 6) + lane;
     const int S = (int)min(64u, n - (chunk << 6));
     if (i < n) {
-      W->pos[lane] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
-      W->aux[lane] = make_float2(0.f, __builtin_bit_cast(float, lane));
+      W->pos[lane] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+                                 __builtin_bit_cast(float, lane));
       half_t e[16];
       float u0 = 0.5f * dir[3 * (size_t)i]; u0 = u0 + 0.5f;
       float u1 = 0.5f * dir[3 * (size_t)i + 1]; u1 = u1 + 0.5f;
