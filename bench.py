@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default (3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -76,36 +77,56 @@ def main():
     dev = torch.device("cuda", dev_index)
     W, H = args.width, args.height
 
-    # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits)
+    # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits).
+    # `depth` frames are in flight: one context + stream + output buffers per slot, so the tail of one
+    # frame (a few long-lived tiles) overlaps the head of the next; every step is still a whole frame.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
-    ctx = nh.NerfHip(dev.index)
-    ctx.load_model(desc)
+    depth = args.frames_in_flight or 3
     opts = nh.default_options()
     opts.shard_index, opts.shard_count = rank, world
-    ctx.set_options(opts)
-    ctx.set_resolution(W, H)
     tps = nh.tiles_per_shard(W, H, world)
     cam = syn.default_camera(W, H)
     poses = [syn.orbit_pose(45.0 * i, 30.0) for i in range(8)]
+    n_px = tps * 64 if world > 1 else W * H
 
-    # a real (non-NULL) stream: with the NULL stream the C ABI would fall back to its own
-    # stream and synchronise after every call
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    if world > 1:
-        shard = torch.zeros((tps * 64, 4), device=dev)
-        sdepth = torch.zeros((tps * 64,), device=dev)
-        gathered = torch.empty((world, tps * 64, 4), device=dev)
-        frame = torch.empty((H, W, 4), device=dev)
-        ctx.bind_output(shard.data_ptr(), sdepth.data_ptr())
+    class Slot:
+        pass
+
+    slots = []
+    for _ in range(depth):
+        sl = Slot()
+        sl.ctx = nh.NerfHip(dev.index)
+        sl.ctx.load_model(desc)
+        sl.ctx.set_options(opts)
+        sl.ctx.set_resolution(W, H)
+        sl.stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: NULL would make the ABI synchronise per call
+        sl.rgba = torch.zeros((n_px, 4), device=dev)
+        sl.depth = torch.zeros((n_px,), device=dev)
+        sl.ctx.bind_output(sl.rgba.data_ptr(), sl.depth.data_ptr())
+        sl.rendered = torch.cuda.Event()
+        sl.gathered = torch.cuda.Event()
+        if world > 1:
+            sl.all = torch.empty((world, tps * 64, 4), device=dev)
+            sl.frame = torch.empty((H, W, 4), device=dev) if rank == 0 else None
+        slots.append(sl)
+    ctx = slots[0].ctx
+    comm = torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
 
     def step(i):
-        ctx.render(cam, poses[i % len(poses)], stream=stream.cuda_stream)
+        sl = slots[i % depth]
+        if world > 1:
+            sl.stream.wait_event(sl.gathered)  # the slot's previous shard has left the building
+        sl.ctx.render(cam, poses[i % len(poses)], stream=sl.stream.cuda_stream)
         if world > 1:
             # the one exchange of the path: RGBA shards -> every rank (xGMI all-gather), untile on rank 0
-            dist.all_gather_into_tensor(gathered.view(-1), shard.view(-1))
-            if rank == 0:
-                ctx.untile(gathered.data_ptr(), world, tps, 4, frame.data_ptr(), stream=stream.cuda_stream)
+            sl.rendered.record(sl.stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(sl.rendered)
+                dist.all_gather_into_tensor(sl.all.view(-1), sl.rgba.view(-1))
+                if rank == 0:
+                    sl.ctx.untile(sl.all.data_ptr(), world, tps, 4, sl.frame.data_ptr(), stream=comm.cuda_stream)
+                sl.gathered.record(comm)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -128,6 +149,7 @@ def main():
 
     # per-pose sample counts and kernel durations (untimed replays; the counts are deterministic)
     samples_pose, kern_ms = [], []
+    stream = slots[0].stream
     for p in poses:
         ctx.render(cam, p, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
@@ -149,6 +171,7 @@ def main():
         step(0)
         torch.cuda.synchronize(dev)
         if rank == 0:
+            frame = slots[0].frame
             solo = nh.NerfHip(dev.index)
             solo.load_model(desc)
             solo.set_resolution(W, H)
@@ -185,7 +208,7 @@ def main():
         "config": {"workload": f"synthetic Lego-like scene {W}x{H}, hash grid L=16 F=2 T=2^19 base 16, "
                                "density MLP 32-64-16 + rgb MLP 32-64-64-16, SH-4, 8 orbit cameras",
                    "samples_per_frame": None,
-                   "parallelism": f"tile{world}"},
+                   "parallelism": f"tile{world}", "frames_in_flight": depth},
         "roofline": {
             "kernel": "render_kernel",
             "bound": "hbm",
@@ -204,7 +227,8 @@ def main():
         out["sharded_frame_equals_unsharded"] = check
     if world == 1:
         out["config"]["samples_per_frame"] = int(mean_samples_launch)
-        out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
+        with torch.cuda.stream(stream):
+            out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, poses[0], W, H, args.cpu_sample_div)
     print(json.dumps(out), flush=True)
