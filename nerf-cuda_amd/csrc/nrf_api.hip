@@ -149,6 +149,7 @@ struct nrf_context {
   void* d_wfrag = nullptr;
   void* d_lv = nullptr;
   void* d_coarse = nullptr;
+  void* d_dilated = nullptr;
   void* d_ctab = nullptr;
   nrf_options opt{};
   int W = 0, H = 0;
@@ -182,7 +183,8 @@ void free_model(nrf_context* c) {
   if (c->d_lv) (void)hipFree(c->d_lv);
   if (c->d_coarse) (void)hipFree(c->d_coarse);
   if (c->d_ctab) (void)hipFree(c->d_ctab);
-  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = nullptr;
+  if (c->d_dilated) (void)hipFree(c->d_dilated);
+  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = nullptr;
   c->model_loaded = false;
 }
 
@@ -429,6 +431,28 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       any = true;
     }
   }
+  // Conservative coarse visibility set (single cascade): coarse cells that contain, or lie within one
+  // density cell of, an occupied density cell (= the coarse image of the occupancy dilated by one
+  // fine cell); used by the per-ray DDA of render_kernel (nrf_device.h coarse_visibility).
+  std::vector<uint32_t> dilated;
+  if (coarse_shift && Cs == 1) {
+    const int Hc = (int)(Hs >> 2), Hf = (int)Hs;
+    dilated.assign(((uint64_t)Hc * Hc * Hc + 31) / 32 + 1, 0u);
+    for (int x = 0; x < Hf; ++x)
+      for (int y = 0; y < Hf; ++y)
+        for (int z = 0; z < Hf; ++z) {
+          const uint64_t i = ((uint64_t)x * Hf + y) * Hf + z;
+          if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
+          for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dz = -1; dz <= 1; ++dz) {
+                const int X = x + dx, Y = y + dy, Z = z + dz;
+                if (X < 0 || Y < 0 || Z < 0 || X >= Hf || Y >= Hf || Z >= Hf) continue;
+                const uint64_t nn = ((uint64_t)(X >> 2) * Hc + (Y >> 2)) * Hc + (Z >> 2);
+                dilated[nn >> 5] |= 1u << (nn & 31);
+              }
+        }
+  }
   std::vector<float> ctab((size_t)Cs * (Hs + 1));
   for (uint32_t level = 0; level < Cs; ++level) {
     const float mip_bound = fminf(Cs > 1 ? ldexpf(1.0f, (int)level) : 1.0f, d->bound);
@@ -484,6 +508,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
   if (coarse_shift) HIP_TRY(upload(&c->d_coarse, coarse.data(), coarse.size() * 4));
   HIP_TRY(upload(&c->d_ctab, ctab.data(), ctab.size() * 4));
+  if (!dilated.empty()) HIP_TRY(upload(&c->d_dilated, dilated.data(), dilated.size() * 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
 
@@ -503,6 +528,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.rbound = 1.0f / d->bound;
   M.occ_coarse = (const uint32_t*)c->d_coarse;
   M.cell_bound = (const float*)c->d_ctab;
+  M.occ_dilated = (const uint32_t*)c->d_dilated;
   M.coarse_shift = coarse_shift;
   {
     const uint64_t words = coarse_shift ? (uint64_t)coarse.size() : 0, fl = ctab.size();

@@ -64,6 +64,7 @@ struct DevModel {
   const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
   const uint32_t* occ_coarse;  // OR over 4x4x4 cell blocks, [C][(H/4)^3] bits; nullptr if H % 4 != 0
   const float* cell_bound;     // [C][H+1] cell-boundary table (see march_next)
+  const uint32_t* occ_dilated;  // coarse cells within one density cell of an occupied density cell; C == 1 only, else nullptr
   const uint4* wfrag;        // N_FRAGS * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];
@@ -174,6 +175,56 @@ __device__ __forceinline__ void box_interval(const float* box, const float o[3],
   a = (box[2] - o[2]) * rdz; b = (box[5] - o[2]) * rdz;
   t_in = fmaxf(t_in, fminf(a, b));
   t_out = fminf(t_out, fmaxf(a, b));
+}
+
+// Conservative visibility of the occupied set along one ray (single cascade): a 3-D DDA over the
+// coarse grid (cells of 4x4x4 density cells); a coarse bit is set when the cell contains, or lies
+// within ONE density cell of, an occupied density cell (host: nrf_load_model).
+// A march trip can only find a sample at a point of the ray that lies in an occupied density cell
+// f.  The DDA visits the coarse cell containing that point or, when the point sits within fp error
+// of a coarse boundary, its neighbour across that boundary -- which is then within one density
+// cell of f.  Either way the visited cell's bit is set.  So: no set bit on the way -> the ray
+// cannot produce a sample; otherwise no sample exists beyond the exit of the last set cell.  Returns false when the ray is sample-free; t_last is
+// the exit parameter of the last dilated cell otherwise.
+__device__ __forceinline__ bool coarse_visibility(const uint32_t* __restrict__ dil, int Hc, float mip_bound, const float o[3],
+                                                  const float d[3], float rdx, float rdy, float rdz, float t0, float t1,
+                                                  float& t_last) {
+  const float cs = 2.0f * mip_bound / (float)Hc, rcs = (float)Hc / (2.0f * mip_bound);
+  const float rd[3] = {rdx, rdy, rdz};
+  int i[3], step[3];
+  float tmax[3], tdelta[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = o[a] + t0 * d[a];
+    int c = (int)floorf((p + mip_bound) * rcs);
+    c = c < 0 ? 0 : (c > Hc - 1 ? Hc - 1 : c);
+    i[a] = c;
+    step[a] = d[a] >= 0.0f ? 1 : -1;
+    const float edge = (float)(c + (d[a] >= 0.0f ? 1 : 0)) * cs - mip_bound;
+    const bool flat = !(fabsf(rd[a]) <= 3.0e38f);  // d == 0 (or NaN): never crosses along this axis
+    tmax[a] = flat ? 3.0e38f : (edge - o[a]) * rd[a];
+    tdelta[a] = flat ? 3.0e38f : cs * fabsf(rd[a]);
+  }
+  bool any = false;
+  float t = t0;
+  t_last = t0;
+  for (int guard = 0; guard < 3 * Hc + 3; ++guard) {
+    const uint32_t cc = ((uint32_t)i[0] * Hc + (uint32_t)i[1]) * Hc + (uint32_t)i[2];
+    const float t_exit = fminf(tmax[0], fminf(tmax[1], tmax[2]));
+    if ((dil[cc >> 5] >> (cc & 31u)) & 1u) {
+      any = true;
+      t_last = t_exit;
+    }
+    if (!(t_exit < t1)) break;
+    t = t_exit;
+    // advance along the axis (axes) reaching their boundary first
+    if (tmax[0] <= t_exit) { i[0] += step[0]; tmax[0] += tdelta[0]; }
+    if (tmax[1] <= t_exit) { i[1] += step[1]; tmax[1] += tdelta[1]; }
+    if (tmax[2] <= t_exit) { i[2] += step[2]; tmax[2] += tdelta[2]; }
+    if ((unsigned)i[0] >= (unsigned)Hc || (unsigned)i[1] >= (unsigned)Hc || (unsigned)i[2] >= (unsigned)Hc) break;
+  }
+  (void)t;
+  return any;
 }
 
 // ----------------------------------------------------------------- march ----

@@ -213,6 +213,14 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     const bool nan = !(t_in == t_in) || !(t_out == t_out);
     if (nan) far_m = far;  // degenerate direction: fall back to the plain aabb range
     alive = alive && (hits || nan);
+    // finer, still exact: walk the dilated coarse occupancy between the box entry and exit
+    if (M.occ_dilated != nullptr && alive && !nan) {
+      float t_last;
+      const float t0 = fmaxf(t_in, near);
+      const bool vis = coarse_visibility(M.occ_dilated, (int)(M.H >> 2), fminf(1.0f, M.bound), o, d, rdx, rdy, rdz, t0, far_m, t_last);
+      alive = vis;
+      if (t_last < far_m) far_m = t_last;
+    }
   }
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
   int n_ray_samples = 0;
