@@ -269,7 +269,12 @@ enum : int { MARCH_FOUND = 0, MARCH_EXHAUSTED = 1, MARCH_OUT_OF_BUDGET = 2 };
 // are spent (MARCH_OUT_OF_BUDGET, t rests on the next candidate).  One loop trip = one trip of the
 // `while (t < far && step < n_step)` loop of render_utils.h:593-653.
 //   occ      fine bitfield (global)     coarse  coarse bitfield or nullptr     ctab  cell_bound table
-template <bool COARSE>
+// UNIT == true: single cascade with mip_bound == 1 (bound >= 1): level 0, `x * mip_rbound` is `x * 1`
+// (exact), so the level / mip arithmetic disappears.  clamp() is v_med3_f32 (same value as
+// fminf(hi, fmaxf(lo, x)) for non-NaN x), index arithmetic is 24-bit.
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+template <bool COARSE, bool UNIT>
 __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* __restrict__ occ, const uint32_t* coarse,
                                           const float* ctab, float ox, float oy, float oz, float dx, float dy, float dz,
                                           float rdx, float rdy, float rdz, int sx, int sy, int sz, float far, int& budget,
@@ -277,32 +282,42 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
   while (t < far) {
     if (budget <= 0) return MARCH_OUT_OF_BUDGET;
     --budget;
-    x = clampf(ox + t * dx, -c.bound, c.bound);
-    y = clampf(oy + t * dy, -c.bound, c.bound);
-    z = clampf(oz + t * dz, -c.bound, c.bound);
+    x = clamp3(ox + t * dx, -c.bound, c.bound);
+    y = clamp3(oy + t * dy, -c.bound, c.bound);
+    z = clamp3(oz + t * dz, -c.bound, c.bound);
     int level = 0;
-    float mip_bound = fminf(1.0f, c.bound), mip_rbound;
-    if (c.C > 1) {
-      const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-      int exponent;
-      (void)frexpf(mx, &exponent);
-      level = (int)fminf((float)c.C - 1, fmaxf(0.0f, (float)exponent));
-      mip_bound = fminf(ldexpf(1.0f, level), c.bound);
+    int nx, ny, nz;
+    if (UNIT) {
+      // mip_bound == 1: (x * 1 + 1) == (x + 1)
+      nx = (int)clamp3((0.5f * (x + 1)) * c.Hf, 0.0f, c.Hm1);
+      ny = (int)clamp3((0.5f * (y + 1)) * c.Hf, 0.0f, c.Hm1);
+      nz = (int)clamp3((0.5f * (z + 1)) * c.Hf, 0.0f, c.Hm1);
+    } else {
+      float mip_bound = fminf(1.0f, c.bound), mip_rbound;
+      if (c.C > 1) {
+        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        int exponent;
+        (void)frexpf(mx, &exponent);
+        level = (int)fminf((float)c.C - 1, fmaxf(0.0f, (float)exponent));
+        mip_bound = fminf(ldexpf(1.0f, level), c.bound);
+      }
+      mip_rbound = (mip_bound == c.bound) ? c.rbound : ldexpf(1.0f, -level);  // == 1 / mip_bound
+      // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic in the reference; for H < 2^24 the
+      // double product is exact, so its narrowing to float equals the fp32 product (0.5f*v)*H.
+      nx = (int)clamp3((0.5f * (x * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
+      ny = (int)clamp3((0.5f * (y * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
+      nz = (int)clamp3((0.5f * (z * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     }
-    mip_rbound = (mip_bound == c.bound) ? c.rbound : ldexpf(1.0f, -level);  // == 1 / mip_bound
-    // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic in the reference; for H < 2^24 the
-    // double product is exact, so its narrowing to float equals the fp32 product (0.5f*v)*H.
-    const int nx = (int)clampf((0.5f * (x * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
-    const int ny = (int)clampf((0.5f * (y * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
-    const int nz = (int)clampf((0.5f * (z * mip_rbound + 1)) * c.Hf, 0.0f, c.Hm1);
     // all loads of the trip are issued together (addresses depend only on the cell), so the
     // trip pays one memory latency instead of three dependent ones
-    const uint32_t cell = (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
-    const float* tab = ctab + (uint32_t)level * (c.H + 1);
+    const uint32_t cell = UNIT ? __umul24(__umul24((uint32_t)nx, c.H) + (uint32_t)ny, c.H) + (uint32_t)nz
+                               : (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
+    const float* tab = UNIT ? ctab : ctab + (uint32_t)level * (c.H + 1);
     const float bx = tab[nx + sx], by = tab[ny + sy], bz = tab[nz + sz];
     bool occupied;
     if (COARSE) {
-      const uint32_t cc = ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
+      const uint32_t cc = UNIT ? __umul24(__umul24((uint32_t)nx >> 2, c.Hc) + ((uint32_t)ny >> 2), c.Hc) + ((uint32_t)nz >> 2)
+                               : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
       const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
       occupied = coarse_occ;
       if (coarse_occ) occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
@@ -310,7 +325,7 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
       occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
     }
     if (occupied) {
-      dt_out = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+      dt_out = clamp3(t * c.dt_gamma, c.dt_min, c.dt_max);
       return MARCH_FOUND;
     }
     const float tx = (bx - x) * rdx;  // (((nx+0.5f+0.5f*sign)/(H-1)*2-1)*mip_bound - x) * rdx
@@ -318,7 +333,7 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     const float tz = (bz - z) * rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do {
-      t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+      t += clamp3(t * c.dt_gamma, c.dt_min, c.dt_max);
     } while (t < tt);
   }
   return MARCH_EXHAUSTED;

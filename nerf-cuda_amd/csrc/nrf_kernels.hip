@@ -129,7 +129,7 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 // 256 threads, >= 4 waves per SIMD (four workgroups per CU, 39.9 KB of LDS each): caps the kernel at
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
-template <bool GEN, bool COARSE_LDS>
+template <bool GEN, bool COARSE_LDS, bool UNIT>
 __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
                                                      float* __restrict__ depth, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
       bool found = false;
       if (marching) {
-        const int r = COARSE_LDS ? march_next<true>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+        const int r = COARSE_LDS ? march_next<true, UNIT>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                     rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt)
-                                 : march_next<false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                 : march_next<false, false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                      rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt);
         found = r == MARCH_FOUND;
         marching = found;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
       bool found = false;
       if (marching) {
         int budget = 0x7fffffff;
-        found = march_next<COARSE>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
+        found = march_next<COARSE, false>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
                                    far, budget, t, x, y, z, dt) == MARCH_FOUND;
       }
       marching = found;
@@ -583,13 +583,17 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, vo
   if (blocks <= 0) return hipSuccess;
   const bool lds_tab = M.lds_coarse_words > 0;
   const int lds = LDS_FIXED_BYTES + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
-#define NRF_LAUNCH_RENDER(G, C)                                                                                          \
-  hipLaunchKernelGGL((render_kernel<G, C>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, (float4*)rgba, (float*)depth, \
-                     (unsigned long long*)counters)
+#define NRF_LAUNCH_RENDER(G, C, U)                                                                                       \
+  hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, (float4*)rgba,         \
+                     (float*)depth, (unsigned long long*)counters)
+  // hot instance: compile-time activations, march tables in LDS, single cascade with mip_bound == 1
+  const bool unit = lds_tab && M.cascade == 1 && M.bound >= 1.0f;
   if (M.generic_act) {
-    if (lds_tab) NRF_LAUNCH_RENDER(true, true); else NRF_LAUNCH_RENDER(true, false);
+    if (lds_tab) NRF_LAUNCH_RENDER(true, true, false); else NRF_LAUNCH_RENDER(true, false, false);
   } else {
-    if (lds_tab) NRF_LAUNCH_RENDER(false, true); else NRF_LAUNCH_RENDER(false, false);
+    if (unit) NRF_LAUNCH_RENDER(false, true, true);
+    else if (lds_tab) NRF_LAUNCH_RENDER(false, true, false);
+    else NRF_LAUNCH_RENDER(false, false, false);
   }
 #undef NRF_LAUNCH_RENDER
   return hipGetLastError();
