@@ -113,11 +113,19 @@ def main():
     comm = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
 
-    def step(i):
+    launch_events = []  # (start, end) HIP events around every render launch of the timed region
+
+    def step(i, timed=False):
         sl = slots[i % depth]
         if world > 1:
             sl.stream.wait_event(sl.gathered)  # the slot's previous shard has left the building
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(sl.stream)
         sl.ctx.render(cam, poses[i % len(poses)], stream=sl.stream.cuda_stream)
+        if timed:
+            e1.record(sl.stream)
+            launch_events.append((e0, e1))
         if world > 1:
             # the one exchange of the path: RGBA shards -> every rank (xGMI all-gather), untile on rank 0
             sl.rendered.record(sl.stream)
@@ -139,7 +147,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,9 +196,17 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     msamples_s = total_samples / elapsed / 1e6
-    mean_kern_s = float(np.mean(kern_ms)) * 1e-3
-    mean_samples_launch = float(np.mean(samples_pose))
+    # the kernel's average launch duration over the timed region (HIP events on the launch streams;
+    # launches of different slots overlap, so this is what rocprofv3 --stats reports for the same command)
+    mean_kern_s = float(np.mean([a.elapsed_time(b) for a, b in launch_events])) * 1e-3
+    iso_kern_s = float(np.mean(kern_ms)) * 1e-3  # the same launches replayed one at a time
+    mean_samples_launch = float(np.mean([samples_pose[i % len(poses)] for i in range(args.steps)]))
     gather_gbs = mean_samples_launch * BYTES_PER_SAMPLE / mean_kern_s / 1e9
+    in_flight = mean_kern_s * 1e3 / ms_per_step
+    traffic = None
+    tfile = ROOT / "profiles" / "r01" / "pmc_traffic.json"
+    if world == 1 and (W, H) == (WIDTH, HEIGHT) and tfile.exists():  # PMC passes cannot run inside this process
+        traffic = json.loads(tfile.read_text())["hbm_bytes_per_launch"]
     out = {
         "metric": "megasamples/s (network-evaluated march samples), Lego-like NeRF render @1920x1080",
         "value": round(msamples_s, 2),
@@ -216,11 +232,18 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(gather_gbs / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
+            "algorithmic_bytes_per_launch": int(mean_samples_launch * BYTES_PER_SAMPLE),
             "kernel_ms": round(mean_kern_s * 1e3, 4),
             "samples_per_launch": int(mean_samples_launch),
-            "mfma_tflops": round(mean_samples_launch * FLOP_PER_SAMPLE / mean_kern_s / 1e12, 3),
-            "mfma_frac": round(mean_samples_launch * FLOP_PER_SAMPLE / mean_kern_s / 1e12 / MFMA_PEAK_TFLOPS, 5),
+            # `achieved` is per launch while ~launches_in_flight launches share the chip; the chip-level figures:
+            "launches_in_flight": round(in_flight, 2),
+            "aggregate_achieved": round(gather_gbs * in_flight, 2),
+            "aggregate_frac": round(gather_gbs * in_flight / HBM_PEAK_GBS, 5),
+            "isolated_kernel_ms": round(iso_kern_s * 1e3, 4),
+            "isolated_frac": round(mean_samples_launch * BYTES_PER_SAMPLE / iso_kern_s / 1e9 / HBM_PEAK_GBS, 5),
+            "mfma_tflops_aggregate": round(msamples_s * 1e6 * FLOP_PER_SAMPLE / 1e12 / max(world, 1), 3),
         },
     }
     if check is not None:
