@@ -133,10 +133,12 @@ typedef struct nrf_options {
   int32_t max_steps;   /* 1024   m_max_infer_steps                            */
   float density_scale; /* 1      m_density_scale                              */
   int32_t perturb;     /* 0      m_perturb (only 0 implemented)               */
-  /* Sharding of one frame over ranks: the frame is cut into 8x8-pixel tiles,
-   * tile id = ty*ceil(W/8)+tx, and tile id % shard_count == shard_index
-   * belongs to this context.  Replaces the pixel interleave
-   * p = NGPU*tid + gpu of render_utils.h:37.                                 */
+  /* Sharding of one frame over ranks: the frame is cut into 8x8-pixel tiles
+   * and those into strips of 4 horizontally adjacent tiles (32x8 pixels, one
+   * workgroup); strip id = ty*ceil(ceil(W/8)/4) + tx/4, and strip id %
+   * shard_count == shard_index belongs to this context, as local strip
+   * id / shard_count (local tile = 4*local strip + tx%4).  Replaces the pixel
+   * interleave p = NGPU*tid + gpu of render_utils.h:37.                      */
   int32_t shard_index; /* 0 */
   int32_t shard_count; /* 1 */
 } nrf_options;
@@ -147,7 +149,8 @@ typedef struct nrf_options {
  * (nerf_render.cu:200-202).                                                  */
 typedef struct nrf_frame {
   int32_t width, height;
-  int32_t n_tiles;      /* tiles rendered by this shard                       */
+  int32_t n_tiles;      /* tiles rendered by this shard (4 per strip, including
+                           out-of-image padding tiles of a ragged strip)      */
   void* rgba;           /* device float [n_px][4]; rgb after background blend
                            (render_utils.h:259-261), a = weight_sum           */
   void* depth;          /* device float [n_px] (render_utils.h:262-263)       */

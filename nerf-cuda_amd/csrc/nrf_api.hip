@@ -198,10 +198,12 @@ void free_frame(nrf_context* c) {
   c->rendered = false;
 }
 
+int total_strips(int W, int H) { return ((((W + 7) / 8) + 3) / 4) * ((H + 7) / 8); }
+
 int local_tiles(int W, int H, int shard_index, int shard_count) {
-  const int total = ((W + 7) / 8) * ((H + 7) / 8);
+  const int total = total_strips(W, H);
   if (shard_index >= total) return 0;
-  return (total - shard_index + shard_count - 1) / shard_count;
+  return 4 * ((total - shard_index + shard_count - 1) / shard_count);
 }
 
 int alloc_frame(nrf_context* c) {
@@ -291,8 +293,7 @@ int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t 
 
 int nrf_tiles_per_shard(int width, int height, int shard_count, int* n) {
   if (!n || width <= 0 || height <= 0 || shard_count <= 0) return fail(NRF_E_INVALID, "bad argument");
-  const int total = ((width + 7) / 8) * ((height + 7) / 8);
-  *n = (total + shard_count - 1) / shard_count;
+  *n = 4 * ((total_strips(width, height) + shard_count - 1) / shard_count);
   return NRF_OK;
 }
 

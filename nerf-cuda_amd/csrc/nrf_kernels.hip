@@ -156,8 +156,11 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   const int swz = (int)blockIdx.x;
   const int k_local = swz * RENDER_WAVES + wave;
   if (k_local >= P.n_local_tiles) return;  // no barrier after this point
-  const int tile = k_local * P.shard_count + P.shard_index;
-  const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+  // partition unit = a strip of 4 horizontally adjacent tiles (one workgroup): strip s belongs to
+  // rank s % shard_count, local strip index s / shard_count (nerfhip.h nrf_options)
+  const int strips_x = (P.tiles_x + 3) >> 2;
+  const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
+  const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool in_img = px < P.W && py < P.H;
 
@@ -541,10 +544,12 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ gathered, int shard_count, int tiles_per_shard,
                                                      int C, int W, int H, int tiles_x, float* __restrict__ out) {
   const size_t total = (size_t)W * H;
+  const int strips_x = (tiles_x + 3) >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int px = (int)(i % W), py = (int)(i / W);
-    const int tile = (py >> 3) * tiles_x + (px >> 3);
-    const int shard = tile % shard_count, k = tile / shard_count;
+    const int tx = px >> 3, ty = py >> 3;
+    const int strip = ty * strips_x + (tx >> 2);
+    const int shard = strip % shard_count, k = (strip / shard_count) * 4 + (tx & 3);
     const int l = (py & 7) * 8 + (px & 7);
     const float* src = gathered + (((size_t)shard * tiles_per_shard + k) * 64 + l) * C;
     for (int ch = 0; ch < C; ++ch) out[i * C + ch] = src[ch];

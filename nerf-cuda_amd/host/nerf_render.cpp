@@ -241,11 +241,11 @@ Image NerfRender::render_frame(Camera cam, Matrix4f pos) {
   std::vector<nrf_frame> frames(n);
   for (int gpu = 0; gpu < n; ++gpu) check(nrf_render_async(m_ctx[gpu], c4, pos.m, &frames[gpu]), "nrf_render_async");
   for (int gpu = 0; gpu < n; ++gpu) check(nrf_sync(m_ctx[gpu]), "nrf_sync");
-  const int tiles_x = (W + 7) / 8;
+  const int strips_x = ((W + 7) / 8 + 3) / 4;
   for (int gpu = 0; gpu < n; ++gpu) {
     check(nrf_read_shard_f32(m_ctx[gpu], m_shard_rgba.data(), m_shard_depth.data()), "nrf_read_shard_f32");
     for (int k = 0; k < frames[gpu].n_tiles; ++k) {
-      const int tile = k * n + gpu, tx = tile % tiles_x, ty = tile / tiles_x;
+      const int strip = (k / 4) * n + gpu, tx = (strip % strips_x) * 4 + k % 4, ty = strip / strips_x;
       for (int l = 0; l < 64; ++l) {
         const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
         if (px >= W || py >= H) continue;

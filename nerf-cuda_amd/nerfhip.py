@@ -427,18 +427,26 @@ class NerfHip:
 
 # --------------------------------------------------------------------------
 # tile partition of one frame over ranks (host-side mirror of render_kernel's mapping and of
-# untile_kernel): tile id = ty*ceil(W/8)+tx belongs to rank tile_id % world, local index tile_id // world
+# untile_kernel): a strip = 4 horizontally adjacent 8x8 tiles; strip id = ty*strips_x + tx//4 belongs to
+# rank strip % world as local strip strip // world; local tile = 4*local strip + tx % 4
 # --------------------------------------------------------------------------
 def shard_tile_ids(width: int, height: int, rank: int, world: int):
-    total = ((width + 7) // 8) * ((height + 7) // 8)
-    return list(range(rank, total, world))
+    """(tx, ty) of this rank's local tiles, in local order; padding tiles of a ragged strip included."""
+    tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+    strips_x = (tiles_x + 3) // 4
+    out = []
+    for strip in range(rank, strips_x * tiles_y, world):
+        for j in range(4):
+            out.append(((strip % strips_x) * 4 + j, strip // strips_x))
+    return out
 
 
 def untile_numpy(gathered: np.ndarray, width: int, height: int):
     """gathered [world][tiles_per_shard*64][C] (every rank's tile-major shard) -> [H][W][C]."""
     world = gathered.shape[0]
-    tiles_x = (width + 7) // 8
+    strips_x = ((width + 7) // 8 + 3) // 4
     ys, xs = np.mgrid[0:height, 0:width]
-    tile = (ys // 8) * tiles_x + xs // 8
+    tx, ty = xs // 8, ys // 8
+    strip = ty * strips_x + tx // 4
     lane = (ys % 8) * 8 + xs % 8
-    return gathered[tile % world, (tile // world) * 64 + lane]
+    return gathered[strip % world, ((strip // world) * 4 + tx % 4) * 64 + lane]

@@ -63,9 +63,9 @@ def test_struct_layout_matches_header():
 
 def test_host_helpers():
     assert nh.default_per_level_scale(1.0, 16, 16) == pytest.approx(1.3819129, abs=1e-6)
-    assert nh.tiles_per_shard(1920, 1080, 8) == 4050
+    assert nh.tiles_per_shard(1920, 1080, 8) == 4052  # 8100 strips of 4 tiles over 8 ranks: 1013 strips each
     assert nh.tiles_per_shard(1920, 1080, 1) == 32400
-    assert nh.tiles_per_shard(20, 12, 4) == 2  # 3x2 ragged tiles over 4 shards
+    assert nh.tiles_per_shard(20, 12, 4) == 4  # 3x2 tiles = 2 strips (one per tile row) over 4 shards: 1 strip = 4 tiles
     o = nh.Options()
     nh.load_library().nrf_default_options(C.byref(o))
     d = nh.default_options()

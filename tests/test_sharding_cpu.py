@@ -34,15 +34,15 @@ def _worker(rank, world, port, W, H, q):
     tiles = nh.shard_tile_ids(W, H, rank, world)
     tiles_x = (W + 7) // 8
     shard = torch.zeros((tps * 64, 4))
-    for k, t in enumerate(tiles):  # "render": pixel value = f(x, y), zeros outside the image
-        tx, ty = t % tiles_x, t // tiles_x
+    for k, (tx, ty) in enumerate(tiles):  # "render": pixel value = f(x, y), zeros outside the image
         for l in range(64):
             px, py = tx * 8 + (l & 7), ty * 8 + (l >> 3)
             if px < W and py < H:
                 shard[k * 64 + l] = torch.tensor([px, py, px * 0.5 + py, 1.0])
     gathered = torch.empty((world, tps * 64, 4))
     dist.all_gather_into_tensor(gathered.view(-1), shard.view(-1))
-    samples = torch.tensor([len(tiles) * 10], dtype=torch.int64)
+    in_image = [t for t in tiles if t[0] < tiles_x and t[1] < (H + 7) // 8]
+    samples = torch.tensor([len(in_image) * 10], dtype=torch.int64)
     dist.all_reduce(samples)
     if rank == 0:
         q.put((nh.untile_numpy(gathered.numpy(), W, H), int(samples.item())))
@@ -75,7 +75,8 @@ def test_two_rank_tile_sharding_gloo(W, H):
 def test_partition_is_exact_cover():
     sys.path[:0] = [str(ROOT / "nerf-cuda_amd")]
     import nerfhip as nh
-    for W, H, world in [(1920, 1080, 8), (1920, 1080, 3), (20, 12, 4), (8, 8, 2)]:
-        ids = sorted(t for r in range(world) for t in nh.shard_tile_ids(W, H, r, world))
-        assert ids == list(range(((W + 7) // 8) * ((H + 7) // 8)))
+    for W, H, world in [(1920, 1080, 8), (1920, 1080, 3), (20, 12, 4), (8, 8, 2), (100, 30, 5)]:
+        tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+        ids = sorted(t for r in range(world) for t in nh.shard_tile_ids(W, H, r, world) if t[0] < tiles_x)
+        assert ids == sorted((x, y) for y in range(tiles_y) for x in range(tiles_x))  # exact cover, no tile twice
         assert max(len(nh.shard_tile_ids(W, H, r, world)) for r in range(world)) == nh.tiles_per_shard(W, H, world)
