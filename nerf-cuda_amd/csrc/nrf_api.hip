@@ -99,7 +99,7 @@ int expected_params(const nrf_model_desc& d, const nrf_level_table& t, uint64_t&
 
 // fp16 weight fragments for v_mfma_f32_16x16x32_f16 (see nrf_device.h mlp_tiles):
 // fragment f, lane l, element j  =  W[16m + (l&15)][kmap(s, l>>4, j)]
-//   input layers   kmap(g,j) = 8g + j                      (density: hash features)
+//   input layers   kmap(g,j) = 2(4(j>>1) + g) + (j&1)      (density: lane group g holds levels g, 4+g, 8+g, 12+g)
 //                  kmap(g,j) = j<4 ? 4g+j : 16+4g+(j-4)    (rgb: [density out | dir enc])
 //   hidden->next   kmap(s,g,j) = 16(2s + (j>>2)) + 4g + (j&3)   (a D fragment re-used in-lane as B)
 void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& frags) {
@@ -114,7 +114,7 @@ void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& fra
     for (int l = 0; l < 64; ++l)
       for (int j = 0; j < 8; ++j) frags[((size_t)f * 64 + l) * 8 + j] = Wm[(size_t)(16 * m + (l & 15)) * in + kmap(l >> 4, j)];
   };
-  for (int m = 0; m < 4; ++m) put(FRAG_D0 + m, D0, 32, m, [](int g, int j) { return 8 * g + j; });
+  for (int m = 0; m < 4; ++m) put(FRAG_D0 + m, D0, 32, m, [](int g, int j) { return 2 * (4 * (j >> 1) + g) + (j & 1); });
   for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
   for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
   for (int m = 0; m < 4; ++m)
@@ -550,6 +550,15 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.sigma_activation = d->sigma_activation;
   M.rgb_activation = d->rgb_activation;
   M.rgb_output_activation = d->rgb_output_activation;
+  M.uni_modes = 0;
+  for (int jl = 0; jl < 4; ++jl) {
+    bool all_dense = true, all_hash = true;
+    for (int g = 0; g < 4; ++g) {
+      all_dense = all_dense && lp[4 * jl + g].mode == LV_DENSE;
+      all_hash = all_hash && lp[4 * jl + g].mode == LV_HASH_POW2;
+    }
+    M.uni_modes |= (all_dense ? 1u : (all_hash ? 2u : 0u)) << (2 * jl);
+  }
   M.generic_act = generic_grid || !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
                     d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
                     d->sigma_activation == NRF_ACT_EXPONENTIAL);

@@ -78,6 +78,8 @@ struct DevModel {
   uint32_t dir_encoding, sh_degree, n_frequencies;
   uint32_t density_activation, density_output_activation, sigma_activation;
   uint32_t rgb_activation, rgb_output_activation;
+  uint32_t uni_modes;    // 2 bits per unrolled step jl = 0..3 of the fused kernel (levels 4*jl + g): 0 mixed, 1 all dense,
+                         // 2 all power-of-two hashed (host: nrf_load_model)
   uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential AND every grid level dense or
                          // power-of-two hashed (compile-time fast path); 1: the generic kernel instances
   uint32_t coarse_shift;    // 2 or 0
@@ -341,13 +343,19 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
 
 // ------------------------------------------------------------- hash grid ----
 // (half)(w * (float)h) for both halves of a table entry: fp32 product rounded to fp32, then to fp16
-// (grid.h:258-260).  NOT v_fma_mixlo/hi_f16: measured on gfx950 it rounds the exact product once,
+// (grid.h:258-260).  v_fma_mix_f32 reads the fp16 half directly and returns fma(w, h, -0.0) in fp32,
+// which is bit-for-bit `w * (float)h` (the conversion is exact, x + (-0.0) == x including the sign
+// of zero): one instruction instead of v_cvt_f32_f16 + v_mul_f32.  The conversion to fp16 stays a
+// separate v_cvt_pk_f16_f32: v_fma_mixlo/hi_f16 was measured to round the exact product ONCE,
 // which differs from these two roundings for about 1 in 30 000 products.
 __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
-  const half2_t val = bits_h2(entry);
+  float lo, hi;
+  const float neg_zero = -0.0f;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(lo) : "v"(w), "v"(entry), "v"(neg_zero));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(hi) : "v"(w), "v"(entry), "v"(neg_zero));
   half2_t p;
-  p.x = (half_t)(w * (float)val.x);
-  p.y = (half_t)(w * (float)val.y);
+  p.x = (half_t)lo;
+  p.y = (half_t)hi;
   return p;
 }
 
@@ -357,7 +365,9 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 //   GENERIC == false: every level is LV_DENSE or LV_HASH_POW2 (the hot path); dense levels are
 //   stored with res^2 + res + 1 wrapped entries appended (nrf_api.hip), so `index % size` of
 //   grid.h:116 needs no instruction: a dense index never exceeds size + res^2 + res.
-template <bool GENERIC>
+//   UNI: 0 = the lanes of the wave may mix dense and hashed levels (per-lane select);
+//        1 = every lane's level is dense, 2 = every lane's level is power-of-two hashed.
+template <bool GENERIC, int UNI = 0>
 __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
                                                  float py, float pz) {
   float fx = px * L.scale; fx = fx + 0.5f;
@@ -387,7 +397,7 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
     }
   } else {
     // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
-    const bool hashed = L.mode == LV_HASH_POW2;
+    const bool hashed = UNI == 2 || (UNI == 0 && L.mode == LV_HASH_POW2);
     const uint32_t my = hashed ? 2654435761u : L.res;
     const uint32_t mz = hashed ? 805459861u : L.res * L.res;
     const uint32_t mask = hashed ? L.size - 1 : 0xffffffffu;
@@ -398,7 +408,9 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
-      idx[c] = (hashed ? (a ^ b ^ d) : (a + b + d)) & mask;
+      if (UNI == 1) idx[c] = a + b + d;
+      else if (UNI == 2) idx[c] = (a ^ b ^ d) & mask;
+      else idx[c] = (hashed ? (a ^ b ^ d) : (a + b + d)) & mask;
     }
   }
   uint32_t v[8];

@@ -72,7 +72,7 @@ __device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, Leve
 
 // Encodes and evaluates the S (<= 16*NT) samples queued in the wave's LDS
 // slots; results go to W->out[slot].  Lane (g, c): sample c of each tile,
-// hash levels 4g..4g+3, direction entries 4g..4g+3.
+// hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
 template <int NT, bool GEN>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  int S, int base, int lane, float density_scale) {
@@ -90,8 +90,17 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       float px = M.pos_w * p.x; px = px + 0.5f;
       float py = M.pos_w * p.y; py = py + 0.5f;
       float pz = M.pos_w * p.z; pz = pz + 0.5f;
+      // lane group g encodes levels {g, 4+g, 8+g, 12+g}: for each unrolled step jl the four groups work
+      // on four ADJACENT levels, which for the usual tables are all dense (jl = 0) or all hashed
+      // (jl >= 2), so the index arithmetic is specialised per step by a wave-uniform branch.
 #pragma unroll
-      for (int jl = 0; jl < 4; ++jl) fb[jl] = encode_level<GEN>(M.grid, lvs[4 * g + jl], px, py, pz);
+      for (int jl = 0; jl < 4; ++jl) {
+        const LevelParams L = lvs[4 * jl + g];
+        const uint32_t uni = GEN ? 0u : (M.uni_modes >> (2 * jl)) & 3u;
+        if (uni == 2u) fb[jl] = encode_level<GEN, 2>(M.grid, L, px, py, pz);
+        else if (uni == 1u) fb[jl] = encode_level<GEN, 1>(M.grid, L, px, py, pz);
+        else fb[jl] = encode_level<GEN, 0>(M.grid, L, px, py, pz);
+      }
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
     }
@@ -388,7 +397,9 @@ __global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, c
       uint4 fv = make_uint4(0u, 0u, 0u, 0u);
       uint2 dv = make_uint2(0u, 0u);
       if (s < n) {
-        fv = feat[(size_t)s * 4 + g];     // features 8g..8g+7: 16 B, fully coalesced across the wave
+        // element pair jl of the B fragment = level 4*jl + g (the fused kernel's lane mapping)
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(feat) + (size_t)s * 16;
+        fv = make_uint4(row[g], row[4 + g], row[8 + g], row[12 + g]);
         dv = dirfeat[(size_t)s * 4 + g];  // entries 4g..4g+3
       }
       f[t] = __builtin_bit_cast(half8_t, fv);
