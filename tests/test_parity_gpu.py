@@ -407,3 +407,63 @@ def test_generic_activation_kernel_instance(ctx):
     ctx.network(x_d.data_ptr(), dd.data_ptr(), n, sig.data_ptr(), rgb.data_ptr())
     mlp_close(rgb.cpu().numpy(), rgb_w, "rgb (generic network)")
     mlp_close(np.log(sig.cpu().numpy()), np.log(sig_w), "log sigma (generic network)")
+
+
+def test_config4_large_bound_five_cascades(ctx):
+    """BASELINE config 4 shape: bound 16, 5 density-grid cascades, T = 2^19, up to 1024 samples per ray
+    (the generic march path: levels from frexp, cell tables read from LDS for 5 cascades)."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128, bound=16.0, cascade=5)
+    assert nh.level_table(desc).offset[16] == 6811592  # SURVEY Appendix C, bound 16
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    W, H = 96, 64
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(60, 25)
+    # bit-exact marching through the cascades
+    ro, rd, nr, fr = _rays(ctx, o, W, H, cam, pose)
+    n = W * H
+    xyzs = torch.empty((n, 8, 3), device="cuda"); dirs = torch.empty((n, 8, 3), device="cuda")
+    deltas = torch.empty((n, 8, 2), device="cuda")
+    sync()
+    ctx.march(ro.data_ptr(), rd.data_ptr(), nr.data_ptr(), fr.data_ptr(), n, 8, xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr())
+    wx, wd, wdl = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), 8)
+    np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
+    np.testing.assert_array_equal(deltas.cpu().numpy(), wdl)
+    rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
+    assert st.n_samples > 0
+    assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
+    assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+
+
+def test_config5_batched_views_800x800(ctx):
+    """BASELINE config 5 shape: independent 800x800 camera requests rendered back to back on one
+    context must equal the same views rendered alone (no state leaks between requests), and a crop
+    of each matches the oracle."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    W = H = 800
+    cam = syn.default_camera(W, H)
+    poses = [syn.orbit_pose(az, el) for az, el in ((0, 30), (95, 10), (190, 45), (300, -10))]
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    batch = []
+    for p in poses:  # queued on the context's stream without waiting in between
+        f = nh.Frame()
+        cam_c = np.ascontiguousarray(cam, np.float32); pose_c = np.ascontiguousarray(p, np.float32).reshape(16)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        rc = ctx.lib.nrf_render_async(ctx.h, fp(cam_c), fp(pose_c), C.byref(f))
+        assert rc == 0
+        rc = ctx.lib.nrf_sync(ctx.h)
+        assert rc == 0
+        batch.append(ctx.read_f32()[0].copy())
+    for p, got in zip(poses, batch):
+        fresh = nh.NerfHip(0)
+        fresh.load_model(desc)
+        fresh.set_resolution(W, H)
+        fresh.render(cam, p)
+        np.testing.assert_array_equal(fresh.read_f32()[0], got)
+        fresh.close()
+        x0, y0, cw, ch = 368, 376, 64, 48
+        ccam = cam.copy(); ccam[2] -= x0; ccam[3] -= y0
+        want, _, _ = o.render(ccam, p, cw, ch, schedule=op.SCHED_PER_RAY)
+        assert np.abs(got[y0:y0 + ch, x0:x0 + cw] - want).max() <= 2.0 / 255.0
