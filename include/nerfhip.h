@@ -266,6 +266,35 @@ int nrf_composite(nrf_context* ctx, const void* sigmas, const void* rgbs,
                   const void* deltas, uint32_t n, uint32_t n_step, void* rays_t,
                   void* state, void* stream);
 
+/* ---- render buffer (presentation chain) -----------------------------------
+ * Replaces ngp::CudaRenderBuffer (include/nerf-cuda/render_buffer.h:160-315,
+ * src/render_buffer.cu:224-259 accumulate_kernel, :261-342 tonemap,
+ * :529-556 tonemap_kernel, :590-627).  The frame buffer is RGBA fp32 + depth
+ * on the device: bind it as the render target with
+ * nrf_bind_output(ctx, rgba, depth) and the kernel composites straight into
+ * it (the reference goes through host u8, main.cu:87-129).  GL / CUDA-surface
+ * / DLSS / overlay parts of the reference class are out of scope; the
+ * tonemapped result goes to a plain RGBA fp32 "surface" buffer.              */
+enum { NRF_CS_LINEAR = 0, NRF_CS_SRGB = 1, NRF_CS_VISPOSNEG = 2 };          /* EColorSpace, common.h:93-97     */
+enum { NRF_TM_IDENTITY = 0, NRF_TM_ACES = 1, NRF_TM_HABLE = 2, NRF_TM_REINHARD = 3 }; /* ETonemapCurve :100-105 */
+typedef struct nrf_render_buffer nrf_render_buffer;
+int nrf_rb_create(int device, nrf_render_buffer** out);
+int nrf_rb_destroy(nrf_render_buffer* rb);
+int nrf_rb_resize(nrf_render_buffer* rb, int width, int height);           /* resize(), zero-fills           */
+int nrf_rb_reset_accumulation(nrf_render_buffer* rb);                      /* m_spp = 0                      */
+int nrf_rb_spp(nrf_render_buffer* rb, uint32_t* spp);
+int nrf_rb_set_color_space(nrf_render_buffer* rb, int color_space);        /* m_color_space                  */
+int nrf_rb_set_tonemap_curve(nrf_render_buffer* rb, int curve);            /* m_tonemap_curve                */
+/* device pointers: frame RGBA [h][w][4], depth [h][w], accumulate RGBA, surface RGBA (tonemap output) */
+int nrf_rb_buffers(nrf_render_buffer* rb, void** frame, void** depth, void** accumulate, void** surface);
+int nrf_rb_clear_frame(nrf_render_buffer* rb, void* stream);               /* clear_frame()                  */
+int nrf_rb_accumulate(nrf_render_buffer* rb, float exposure, void* stream);/* accumulate(): running mean     */
+int nrf_rb_tonemap(nrf_render_buffer* rb, float exposure, const float background_color[4],
+                   int output_color_space, void* stream);                  /* tonemap()                      */
+/* host_to_accumulate_buffer(): rgb u8 [n][3] -> accumulate RGBA = rgb/255, a = 1 (render_buffer.h:231-241) */
+int nrf_rb_host_to_accumulate_buffer(nrf_render_buffer* rb, const uint8_t* rgb, int n);
+int nrf_rb_read(nrf_render_buffer* rb, float* accumulate_rgba, float* surface_rgba);  /* host copies (either may be NULL) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -257,6 +257,7 @@ int need_model(nrf_context* c) {
 extern "C" {
 
 const char* nrf_last_error(void) { return g_err.c_str(); }
+void nrf_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by nrf_renderbuffer.hip
 int nrf_abi_version(void) { return NRF_ABI_VERSION; }
 
 void nrf_default_options(nrf_options* o) {

@@ -10,6 +10,7 @@
 
 #include "nerf_render.h"
 #include "png_lite.h"
+#include "render_buffer.h"
 
 using namespace ngp;
 
@@ -38,6 +39,23 @@ int main(int argc, char** argv) {
     std::printf("samples %llu  device time %.3f ms\n", (unsigned long long)st.n_samples, st.render_ms);
     pnglite::write((prefix + "deep.png").c_str(), img.W, img.H, 1, img.depth);
     pnglite::write((prefix + "image.png").c_str(), img.W, img.H, 3, img.rgb);
+    // presentation chain of main.cu:87-129,171-206 without DLSS: u8 image -> accumulate buffer -> tonemap (sRGB)
+    {
+      RenderBuffer rb;
+      rb.resize(Vector2i(img.W, img.H));
+      rb.reset_accumulation();
+      rb.host_to_accumulate_buffer(img.rgb, img.W * img.H);
+      const float bg[4] = {0.f, 0.f, 0.f, 1.f};
+      rb.tonemap(0.0f, bg, EColorSpace::SRGB);
+      const std::vector<float> result = rb.surface_host();
+      std::vector<unsigned char> out((size_t)img.W * img.H * 3);
+      for (size_t i = 0; i < (size_t)img.W * img.H; ++i)
+        for (int j = 0; j < 3; ++j) {
+          const float v = result[i * 4 + j] * 255;
+          out[i * 3 + j] = (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+        }
+      pnglite::write((prefix + "tonemapped.png").c_str(), img.W, img.H, 3, out.data());
+    }
     FILE* f = std::fopen((prefix + "image.rgb").c_str(), "wb");  // raw copy for the parity test
     if (f) { std::fwrite(img.rgb, 1, (size_t)img.W * img.H * 3, f); std::fclose(f); }
     delete render;

@@ -147,6 +147,20 @@ _SIGS = {
     "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "nrf_rb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nrf_rb_destroy": (C.c_int, [C.c_void_p]),
+    "nrf_rb_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nrf_rb_reset_accumulation": (C.c_int, [C.c_void_p]),
+    "nrf_rb_spp": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nrf_rb_set_color_space": (C.c_int, [C.c_void_p, C.c_int]),
+    "nrf_rb_set_tonemap_curve": (C.c_int, [C.c_void_p, C.c_int]),
+    "nrf_rb_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_void_p)]),
+    "nrf_rb_clear_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nrf_rb_accumulate": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "nrf_rb_tonemap": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "nrf_rb_host_to_accumulate_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "nrf_rb_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_encode_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "nrf_encode_dir": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -423,6 +437,75 @@ class NerfHip:
     def composite(self, sigmas, rgbs, deltas, n, n_step, rays_t, state, stream=None):
         _check(self.lib.nrf_composite(self.h, C.c_void_p(sigmas), C.c_void_p(rgbs), C.c_void_p(deltas), n, n_step,
                                       C.c_void_p(rays_t), C.c_void_p(state), C.c_void_p(stream or 0)))
+
+
+CS_LINEAR, CS_SRGB, CS_VISPOSNEG = 0, 1, 2
+TM_IDENTITY, TM_ACES, TM_HABLE, TM_REINHARD = 0, 1, 2, 3
+
+
+class RenderBuffer:
+    """nrf_render_buffer: the presentation chain of the reference's CudaRenderBuffer (same method names)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.nrf_rb_create(device, C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nrf_rb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, width, height):
+        _check(self.lib.nrf_rb_resize(self.h, width, height))
+        self.width, self.height = width, height
+
+    def reset_accumulation(self):
+        _check(self.lib.nrf_rb_reset_accumulation(self.h))
+
+    def spp(self):
+        v = C.c_uint32()
+        _check(self.lib.nrf_rb_spp(self.h, C.byref(v)))
+        return int(v.value)
+
+    def set_color_space(self, cs):
+        _check(self.lib.nrf_rb_set_color_space(self.h, cs))
+
+    def set_tonemap_curve(self, curve):
+        _check(self.lib.nrf_rb_set_tonemap_curve(self.h, curve))
+
+    def buffers(self):
+        f, d, a, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self.lib.nrf_rb_buffers(self.h, C.byref(f), C.byref(d), C.byref(a), C.byref(s)))
+        return f.value, d.value, a.value, s.value
+
+    def clear_frame(self, stream=None):
+        _check(self.lib.nrf_rb_clear_frame(self.h, C.c_void_p(stream or 0)))
+
+    def accumulate(self, exposure=0.0, stream=None):
+        _check(self.lib.nrf_rb_accumulate(self.h, C.c_float(exposure), C.c_void_p(stream or 0)))
+
+    def tonemap(self, exposure, background_color, output_color_space, stream=None):
+        bg = np.ascontiguousarray(background_color, np.float32).reshape(4)
+        _check(self.lib.nrf_rb_tonemap(self.h, C.c_float(exposure), _fptr(bg), output_color_space, C.c_void_p(stream or 0)))
+
+    def host_to_accumulate_buffer(self, rgb_u8):
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        _check(self.lib.nrf_rb_host_to_accumulate_buffer(self.h, rgb.ctypes.data, rgb.size // 3))
+
+    def read(self):
+        acc = np.empty((self.height, self.width, 4), np.float32)
+        sur = np.empty((self.height, self.width, 4), np.float32)
+        _check(self.lib.nrf_rb_read(self.h, acc.ctypes.data, sur.ctypes.data))
+        return acc, sur
 
 
 # --------------------------------------------------------------------------

@@ -819,4 +819,88 @@ void nrfo_quantize_u8(const float* rgba, const float* depth, int n_px, uint8_t* 
   }
 }
 
+// ---- render buffer chain -----------------------------------------------------------------
+// colour helpers: R/include/nerf-cuda/common_device.cuh:38-60
+static inline float srgb_to_linear1(float srgb) {
+  return srgb <= 0.04045f ? srgb / 12.92f : std::pow((srgb + 0.055f) / 1.055f, 2.4f);
+}
+static inline float linear_to_srgb1(float linear) {
+  return linear < 0.0031308f ? 12.92f * linear : 1.055f * std::pow(linear, 0.41666f) - 0.055f;
+}
+
+// R/src/render_buffer.cu:224-259
+void nrfo_rb_accumulate(const float* frame, float* accum, int n, float sample_count, int color_space) {
+  for (int i = 0; i < n; ++i) {
+    float color[4] = {frame[4 * i], frame[4 * i + 1], frame[4 * i + 2], frame[4 * i + 3]};
+    float* tmp = accum + 4 * (size_t)i;
+    if (color_space == NRF_CS_VISPOSNEG) {
+      const float val = color[0] - color[1];
+      float tmp_val = tmp[0] - tmp[1];
+      tmp_val = (tmp_val * sample_count + val) / (sample_count + 1);
+      tmp[0] = fmaxf(tmp_val, 0.0f);
+      tmp[1] = fmaxf(-tmp_val, 0.0f);
+    } else {
+      if (color_space == NRF_CS_SRGB)
+        for (int k = 0; k < 3; ++k) color[k] = linear_to_srgb1(color[k]);
+      for (int k = 0; k < 3; ++k) tmp[k] = (tmp[k] * sample_count + color[k]) / (sample_count + 1);
+    }
+    tmp[3] = (tmp[3] * sample_count + color[3]) / (sample_count + 1);
+  }
+}
+
+// R/src/render_buffer.cu:261-318
+static void tonemap_curve(float c[3], int curve) {
+  if (curve == NRF_TM_IDENTITY) return;
+  for (int i = 0; i < 3; ++i) c[i] = fmaxf(c[i], 0.f);
+  float k0, k1, k2, k3, k4, k5;
+  if (curve == NRF_TM_ACES) {
+    k0 = 0.6f * 0.6f * 2.51f; k1 = 0.6f * 0.03f; k2 = 0.0f;
+    k3 = 0.6f * 0.6f * 2.43f; k4 = 0.6f * 0.59f; k5 = 0.14f;
+  } else if (curve == NRF_TM_HABLE) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    k0 = A * F - A * E; k1 = C * B * F - B * E; k2 = 0.0f;
+    k3 = A * F; k4 = B * F; k5 = D * F * F;
+    const float W = 11.2f;
+    const float nom = k0 * (W * W) + k1 * W + k2;
+    const float denom = k3 * (W * W) + k4 * W + k5;
+    const float white_scale = denom / nom;
+    k0 = 4.0f * k0 * white_scale; k1 = 2.0f * k1 * white_scale; k2 = k2 * white_scale;
+    k3 = 4.0f * k3; k4 = 2.0f * k4;
+  } else {
+    const float Y = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2];
+    const float s = 1.f / (Y + 1.0f);
+    for (int i = 0; i < 3; ++i) c[i] = c[i] * s;
+    return;
+  }
+  for (int i = 0; i < 3; ++i) {
+    const float sq = c[i] * c[i];
+    c[i] = (sq * k0 + k1 * c[i] + k2) / (k3 * sq + k4 * c[i] + k5);
+  }
+}
+
+// R/src/render_buffer.cu:320-342 and :529-556
+void nrfo_rb_tonemap(const float* accum, float* surface, int n, float exposure, const float bg_in[4], int color_space,
+                     int output_color_space, int curve, int clamp_output) {
+  float bg[4] = {bg_in[0], bg_in[1], bg_in[2], bg_in[3]};
+  if (color_space != NRF_CS_SRGB)
+    for (int k = 0; k < 3; ++k) bg[k] = srgb_to_linear1(bg[k]);
+  const float gain = std::pow(2.0f, exposure);
+  for (int i = 0; i < n; ++i) {
+    const float* color = accum + 4 * (size_t)i;
+    const float weight = (1 - color[3]) * bg[3];
+    float c[3] = {color[0] + bg[0] * weight, color[1] + bg[1] * weight, color[2] + bg[2] * weight};
+    const float a = color[3] + weight;
+    if (color_space == NRF_CS_SRGB)
+      for (int k = 0; k < 3; ++k) c[k] = srgb_to_linear1(c[k]);
+    for (int k = 0; k < 3; ++k) c[k] *= gain;
+    tonemap_curve(c, curve);
+    if (output_color_space == NRF_CS_SRGB)
+      for (int k = 0; k < 3; ++k) c[k] = linear_to_srgb1(c[k]);
+    float o[4] = {c[0], c[1], c[2], a};
+    if (clamp_output)
+      for (int k = 0; k < 4; ++k) o[k] = fminf(fmaxf(o[k], 0.f), 1.f);
+    for (int k = 0; k < 4; ++k) surface[4 * (size_t)i + k] = o[k];
+  }
+}
+
 }  // extern "C"

@@ -84,6 +84,12 @@ void nrfo_quantize_u8(const float* rgba, const float* depth, int n_px, uint8_t* 
                       uint8_t* depth_u8);
 int nrfo_max_threads(void);
 
+/* render buffer chain: R/src/render_buffer.cu:224-259 (accumulate_kernel) and :261-342, :529-556
+ * (tonemap + tonemap_kernel); color spaces / curves are the NRF_CS_* / NRF_TM_* enums.           */
+void nrfo_rb_accumulate(const float* frame_rgba, float* accum_rgba, int n, float sample_count, int color_space);
+void nrfo_rb_tonemap(const float* accum_rgba, float* surface_rgba, int n, float exposure, const float bg[4],
+                     int color_space, int output_color_space, int curve, int clamp_output);
+
 #ifdef __cplusplus
 }
 #endif

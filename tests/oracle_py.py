@@ -58,6 +58,10 @@ def lib():
     L.nrfo_quantize_u8.argtypes = [vp, vp, C.c_int, vp, vp]
     L.nrfo_quantize_u8.restype = None
     L.nrfo_max_threads.restype = C.c_int
+    L.nrfo_rb_accumulate.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int]
+    L.nrfo_rb_accumulate.restype = None
+    L.nrfo_rb_tonemap.argtypes = [vp, vp, C.c_int, C.c_float, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.nrfo_rb_tonemap.restype = None
     _lib = L
     return L
 
@@ -165,6 +169,20 @@ def composite(sigmas, rgbs, deltas, rays_t, state):
     _ck(lib().nrfo_composite(sigmas.ctypes.data, rgbs.ctypes.data, deltas.ctypes.data, n, n_step,
                              rays_t.ctypes.data, state.ctypes.data))
     return rays_t, state
+
+
+def rb_accumulate(frame, accum, sample_count, color_space):
+    frame, accum = _f32(frame), _f32(accum).copy()
+    lib().nrfo_rb_accumulate(frame.ctypes.data, accum.ctypes.data, frame.size // 4, float(sample_count), color_space)
+    return accum
+
+
+def rb_tonemap(accum, exposure, bg, color_space, output_color_space, curve, clamp=False):
+    accum, bg = _f32(accum), _f32(bg).reshape(4)
+    out = np.empty_like(accum)
+    lib().nrfo_rb_tonemap(accum.ctypes.data, out.ctypes.data, accum.size // 4, float(exposure), _fp(bg), color_space,
+                          output_color_space, curve, int(clamp))
+    return out
 
 
 def quantize_u8(rgba, depth):

@@ -84,6 +84,7 @@ def test_testbed_matches_python_binding(tmp_path, snapshot):
     assert "Process time" in r.stdout
     got = np.fromfile(tmp_path / "image.rgb", np.uint8).reshape(H, W, 3)
     assert (tmp_path / "image.png").stat().st_size > W * H * 3 and (tmp_path / "deep.png").exists()
+    assert (tmp_path / "tonemapped.png").stat().st_size > W * H * 3  # render buffer chain ran (host u8 -> tonemap)
     ctx = nh.NerfHip(0)
     ctx.load_model(desc)
     ctx.set_resolution(W, H)

@@ -380,7 +380,8 @@ def test_full_size_properties_1080p(ctx):
 def _d2d(dst, src, nbytes):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipMemcpy(dst, src, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+    assert hip.hipMemcpy(dst, src, nbytes, 3) == 0  # hipMemcpyDeviceToDevice (not host-synchronous)
+    hip.hipDeviceSynchronize()
 
 
 def test_generic_activation_kernel_instance(ctx):

@@ -1,0 +1,105 @@
+"""Render-buffer presentation chain (reference src/render_buffer.cu accumulate / tonemap): oracle known
+answers on the CPU, HIP kernels against the oracle on the GPU, and the device-side hand-off
+render -> frame buffer -> accumulate -> tonemap that replaces the reference's host round trip."""
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import oracle_py as op
+import synthetic as syn
+
+
+def test_oracle_known_answers():
+    acc = np.array([[0.2, 0.4, 0.6, 0.5], [1.0, 0.0, 0.25, 1.0]], np.float32)
+    # Identity curve, linear in/out, white background with alpha 1: c + (1-a), a -> 1
+    out = op.rb_tonemap(acc, 0.0, [1, 1, 1, 1], nh.CS_LINEAR, nh.CS_LINEAR, nh.TM_IDENTITY)
+    np.testing.assert_allclose(out, [[0.7, 0.9, 1.1, 1.0], [1.0, 0.0, 0.25, 1.0]], rtol=1e-6)
+    # exposure +1 doubles; sRGB output of 0.5 with the reference's 0.41666 exponent
+    out = op.rb_tonemap(acc[1:], 1.0, [0, 0, 0, 0], nh.CS_LINEAR, nh.CS_SRGB, nh.TM_IDENTITY)
+    want = 1.055 * (0.5 ** 0.41666) - 0.055
+    assert out[0, 2] == pytest.approx(want, rel=1e-5) and out[0, 1] == 0.0
+    # Reinhard: x / (1 + Y)
+    out = op.rb_tonemap(acc[:1], 0.0, [0, 0, 0, 0], nh.CS_LINEAR, nh.CS_LINEAR, nh.TM_REINHARD)
+    Y = 0.2126 * 0.2 + 0.7152 * 0.4 + 0.0722 * 0.6
+    np.testing.assert_allclose(out[0, :3], np.array([0.2, 0.4, 0.6]) / (1 + Y), rtol=1e-6)
+    # ACES and Hable map 0 -> 0 and are increasing, bounded near 1 for large inputs
+    x = np.zeros((5, 4), np.float32); x[:, :3] = np.array([0, 0.1, 0.5, 2, 50], np.float32)[:, None]; x[:, 3] = 1
+    for curve in (nh.TM_ACES, nh.TM_HABLE):
+        y = op.rb_tonemap(x, 0.0, [0, 0, 0, 0], nh.CS_LINEAR, nh.CS_LINEAR, curve)[:, 0]
+        assert y[0] == 0 and np.all(np.diff(y) > 0) and 0.8 < y[-1] < 1.3
+    # accumulate: running mean over spp
+    f1 = np.array([[1, 0, 0, 1]], np.float32); f2 = np.array([[0, 1, 0, 0]], np.float32)
+    a = op.rb_accumulate(f1, np.zeros((1, 4), np.float32), 0, nh.CS_LINEAR)
+    a = op.rb_accumulate(f2, a, 1, nh.CS_LINEAR)
+    np.testing.assert_allclose(a, [[0.5, 0.5, 0, 0.5]])
+    v = op.rb_accumulate(np.array([[0.2, 0.7, 0, 1]], np.float32), np.zeros((1, 4), np.float32), 0, nh.CS_VISPOSNEG)
+    np.testing.assert_allclose(v[0, :2], [0.0, 0.5], atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cs,ocs,curve,exposure", [(0, 1, 1, 0.5), (0, 0, 0, 0.0), (1, 1, 2, -1.0), (0, 1, 3, 2.0), (2, 0, 0, 0.0)])
+def test_hip_matches_oracle(cs, ocs, curve, exposure):
+    torch = pytest.importorskip("torch")
+    W, H = 67, 41
+    rb = nh.RenderBuffer(0)
+    rb.resize(W, H)
+    rb.set_color_space(cs)
+    rb.set_tonemap_curve(curve)
+    frame_p, depth_p, acc_p, sur_p = rb.buffers()
+    rng = np.random.default_rng(cs * 10 + curve)
+    acc_ref = np.zeros((H * W, 4), np.float32)
+    for spp in range(3):
+        frame = rng.random((H * W, 4), dtype=np.float32) * np.float32(1.5)
+        t = torch.from_numpy(frame).cuda()
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        torch.cuda.synchronize()
+        assert hip.hipMemcpy(frame_p, t.data_ptr(), frame.nbytes, 3) == 0  # device-to-device: NOT host-synchronous
+        torch.cuda.synchronize()
+        rb.accumulate(0.0)
+        acc_ref = op.rb_accumulate(frame, acc_ref, spp, cs)
+    assert rb.spp() == 3
+    bg = [0.3, 0.6, 0.9, 0.8]
+    rb.tonemap(exposure, bg, ocs)
+    acc, sur = rb.read()
+    np.testing.assert_allclose(acc.reshape(-1, 4), acc_ref, rtol=2e-6, atol=1e-7)  # powf: device vs libm
+    want = op.rb_tonemap(acc_ref, exposure, bg, cs, ocs, curve)
+    np.testing.assert_allclose(sur.reshape(-1, 4), want, rtol=2e-5, atol=2e-6)
+    rb.reset_accumulation()
+    assert rb.spp() == 0
+    rb.close()
+
+
+@pytest.mark.gpu
+def test_render_into_render_buffer_on_device():
+    """nrf_render composites straight into the render buffer's frame plane (no host round trip),
+    then accumulate + tonemap run on the device; equals the oracle chain on the oracle frame."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    W, H = 72, 56
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    ctx.set_resolution(W, H)
+    rb = nh.RenderBuffer(0)
+    rb.resize(W, H)
+    rb.set_tonemap_curve(nh.TM_ACES)
+    frame_p, depth_p, _, _ = rb.buffers()
+    ctx.bind_output(frame_p, depth_p)
+    cam = syn.default_camera(W, H)
+    o = op.Oracle(desc)
+    acc_ref = np.zeros((H * W, 4), np.float32)
+    for spp, az in enumerate((20.0, 20.0)):
+        rb.clear_frame()
+        ctx.render(cam, syn.orbit_pose(az, 30))
+        rb.accumulate(0.0)
+        want, _, _ = o.render(cam, syn.orbit_pose(az, 30), W, H, schedule=op.SCHED_PER_RAY)
+        acc_ref = op.rb_accumulate(want.reshape(-1, 4), acc_ref, spp, nh.CS_LINEAR)
+    rb.tonemap(0.0, [1, 1, 1, 1], nh.CS_SRGB)
+    acc, sur = rb.read()
+    assert np.abs(acc.reshape(-1, 4) - acc_ref).max() <= 2.0 / 255.0
+    want = op.rb_tonemap(acc_ref, 0.0, [1, 1, 1, 1], nh.CS_LINEAR, nh.CS_SRGB, nh.TM_ACES)
+    assert np.abs(sur.reshape(-1, 4) - want).max() <= 3.0 / 255.0
+    ctx.bind_output(None, None)
+    ctx.close()
+    rb.close()
