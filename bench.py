@@ -7,8 +7,8 @@ A "step" = one whole 1920x1080 frame: ray generation -> occupancy march ->
 hash-grid + SH encoding -> fused MLPs -> compositing -> RGBA/depth in HBM, all
 inside ONE launch of the fused gfx950 kernel per rank.  With N ranks the frame's
 8x8 tiles are dealt round-robin to the ranks (strong scaling of one frame) and
-the only exchange is one RCCL all-gather of the RGBA shards, followed by an
-untile kernel on rank 0 (BASELINE.json configs[2]).
+the only exchange is one RCCL gather of the RGBA shards to rank 0, followed by an
+untile kernel there (BASELINE.json configs[2]).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (render_kernel), bound "hbm": algorithmic gather
@@ -106,7 +106,8 @@ def main():
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
         if world > 1:
-            sl.all = torch.empty((world, tps * 64, 4), device=dev)
+            sl.all = torch.empty((world, tps * 64, 4), device=dev) if rank == 0 else None
+            sl.parts = [sl.all[r] for r in range(world)] if rank == 0 else None
             sl.frame = torch.empty((H, W, 4), device=dev) if rank == 0 else None
         slots.append(sl)
     ctx = slots[0].ctx
@@ -127,11 +128,12 @@ def main():
             e1.record(sl.stream)
             launch_events.append((e0, e1))
         if world > 1:
-            # the one exchange of the path: RGBA shards -> every rank (xGMI all-gather), untile on rank 0
+            # the one exchange of the path: every rank's RGBA shard -> rank 0 (direct xGMI sends: xGMI is
+            # point-to-point, so a gather moves 1/N-th of what an all-gather would), untile on rank 0
             sl.rendered.record(sl.stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(sl.rendered)
-                dist.all_gather_into_tensor(sl.all.view(-1), sl.rgba.view(-1))
+                dist.gather(sl.rgba, sl.parts if rank == 0 else None, dst=0)
                 if rank == 0:
                     sl.ctx.untile(sl.all.data_ptr(), world, tps, 4, sl.frame.data_ptr(), stream=comm.cuda_stream)
                 sl.gathered.record(comm)
