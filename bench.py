@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default (3)")
+    ap.add_argument("--lib", default=None, help="another build of libnerfhip.so (A/B comparisons on one box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -62,6 +63,8 @@ def main():
     import models
     import nerfhip as nh
     import synthetic as syn
+    if args.lib:
+        nh.LIB_PATH = Path(args.lib).resolve()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -367,18 +367,22 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 //   grid.h:116 needs no instruction: a dense index never exceeds size + res^2 + res.
 //   UNI: 0 = the lanes of the wave may mix dense and hashed levels (per-lane select);
 //        1 = every lane's level is dense, 2 = every lane's level is power-of-two hashed.
+// The level is evaluated in two halves so that a caller can put the gathers of SEVERAL levels in
+// flight before consuming any of them (network_from_lds: all 4 levels of a sample, 32 loads per
+// lane): the network phase is bound by gather latency, not by instruction issue.
+//   level_gather: corner indices + the 8 loads (results not touched) + the fractional position
+//   level_interp: trilinear weights and the fp16 accumulation in corner order
 template <bool GENERIC, int UNI = 0>
-__device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
-                                                 float py, float pz) {
+__device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, const LevelParams L, float px, float py,
+                                             float pz, uint32_t (&v)[8], float (&frac)[3]) {
   float fx = px * L.scale; fx = fx + 0.5f;
   float fy = py * L.scale; fy = fy + 0.5f;
   float fz = pz * L.scale; fz = fz + 0.5f;
   const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
   const uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
-  fx -= flx; fy -= fly; fz -= flz;
-  const float wx[2] = {1 - fx, fx};
-  const float wy[2] = {1 - fy, fy};
-  const float wz[2] = {1 - fz, fz};
+  frac[0] = fx - flx;
+  frac[1] = fy - fly;
+  frac[2] = fz - flz;
   const uint32_t* table = grid + L.offset;
 
   uint32_t idx[8];
@@ -413,10 +417,14 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
       else idx[c] = (hashed ? (a ^ b ^ d) : (a + b + d)) & mask;
     }
   }
-  uint32_t v[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) v[c] = table[idx[c]];
+}
 
+__device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const float (&frac)[3]) {
+  const float wx[2] = {1 - frac[0], frac[0]};
+  const float wy[2] = {1 - frac[1], frac[1]};
+  const float wz[2] = {1 - frac[2], frac[2]};
   half2_t acc = {(half_t)0.0f, (half_t)0.0f};
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -425,6 +433,15 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ gr
     acc = acc + weight_times_entry(w, v[c]);  // v_pk_add_f16, RNE: result += (T)(weight * data)
   }
   return h2_bits(acc);
+}
+
+template <bool GENERIC, int UNI = 0>
+__device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
+                                                 float py, float pz) {
+  uint32_t v[8];
+  float frac[3];
+  level_gather<GENERIC, UNI>(grid, L, px, py, pz, v, frac);
+  return level_interp(v, frac);
 }
 
 // ------------------------------------------------------ direction encoding ----

@@ -93,14 +93,19 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       // lane group g encodes levels {g, 4+g, 8+g, 12+g}: for each unrolled step jl the four groups work
       // on four ADJACENT levels, which for the usual tables are all dense (jl = 0) or all hashed
       // (jl >= 2), so the index arithmetic is specialised per step by a wave-uniform branch.
+      // all 32 gathers of the sample go out before the first one is consumed
+      uint32_t gv[4][8];
+      float gf[4][3];
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) {
         const LevelParams L = lvs[4 * jl + g];
         const uint32_t uni = GEN ? 0u : (M.uni_modes >> (2 * jl)) & 3u;
-        if (uni == 2u) fb[jl] = encode_level<GEN, 2>(M.grid, L, px, py, pz);
-        else if (uni == 1u) fb[jl] = encode_level<GEN, 1>(M.grid, L, px, py, pz);
-        else fb[jl] = encode_level<GEN, 0>(M.grid, L, px, py, pz);
+        if (uni == 2u) level_gather<GEN, 2>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
+        else if (uni == 1u) level_gather<GEN, 1>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
+        else level_gather<GEN, 0>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
       }
+#pragma unroll
+      for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp(gv[jl], gf[jl]);
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
     }
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
+  unsigned n_tile_slots = 0;
 #endif
   NRF_STAMP(t_begin);
   // ---- ray generation + aabb
@@ -315,6 +321,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     NRF_ACC(c_comp, t2, t3);
     n_samples += (unsigned)S;
     n_rounds++;
+#ifdef NRF_PHASE_TIMING
+    n_tile_slots += (unsigned)((S + 15) & ~15);
+#endif
   }
 
   // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     atomicAdd(&counters[4], c_comp);
     atomicAdd(&counters[5], t_end - t_begin);
     atomicAdd(&counters[6], 1ull);
+    atomicAdd(&counters[7], (unsigned long long)n_tile_slots);
 #endif
   }
 }

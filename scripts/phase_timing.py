@@ -3,7 +3,7 @@ import ctypes as C, pathlib, sys
 sys.path[:0] = ["nerf-cuda_amd", "tests"]
 import numpy as np
 import models, nerfhip as nh, synthetic as syn
-nh.LIB_PATH = pathlib.Path("nerf-cuda_amd/libnerfhip_prof.so").resolve()
+nh.LIB_PATH = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 else "nerf-cuda_amd/libnerfhip_prof.so").resolve()
 desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
 ctx = nh.NerfHip(0)
 ctx.load_model(desc)
@@ -19,9 +19,9 @@ for az in (0, 45, 90):
     out = (C.c_ulonglong * 8)()
     ctx.lib.nrf_debug_counters(ctx.h, out)
     s, r, m, n, c, tot, waves = [int(x) for x in out[:7]]
-    trips = int(out[7])
+    slots = int(out[7])
     other = tot - m - n - c
     print(f"az {az}: {st.render_ms:.3f} ms samples {s} rounds {r} waves {waves}  samples/round {s/max(r,1):.1f}")
     print(f"   cycles/wave {tot/waves:.0f}  march {100*m/tot:.1f}%  network {100*n/tot:.1f}%  composite {100*c/tot:.1f}%  setup+final {100*other/tot:.1f}%")
-    print(f"   cell trips {trips}  = {trips/s:.2f} per sample, {trips/(W*H):.1f} per ray")
+    print(f"   MFMA tile slots evaluated {slots} = {100*s/max(slots,1):.1f}% filled")
     print(f"   per round: march {m/r:.0f}  network {n/r:.0f}  composite {c/r:.0f} cycles")
