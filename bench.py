@@ -3,12 +3,17 @@
 1920x1080 on the seeded synthetic Lego-like scene (BASELINE.json configs[1]:
 hash grid L=16 F=2 T=2^19, 64-wide MLPs, SH-4 directions).
 
-A "step" = one whole 1920x1080 frame: ray generation -> occupancy march ->
-hash-grid + SH encoding -> fused MLPs -> compositing -> RGBA/depth in HBM, all
-inside ONE launch of the fused gfx950 kernel per rank.  With N ranks the frame's
-8x8 tiles are dealt round-robin to the ranks (strong scaling of one frame) and
-the only exchange is one RCCL gather of the RGBA shards to rank 0, followed by an
-untile kernel there (BASELINE.json configs[2]).
+A "step" = one batch of 8 camera views (8 whole 1920x1080 frames of the orbit):
+ray generation -> occupancy march -> hash-grid + SH encoding -> fused MLPs ->
+compositing -> RGBA/depth in HBM, all inside ONE launch of the fused gfx950
+kernel per rank (nrf_render_views; --views-per-step 1 gives one frame per step).
+The views of a batch are independent frames: batching only lets the workgroups
+of view v+1 take the wave slots that the few long-lived tiles of view v leave
+idle.  Two steps are in flight (one context + stream + buffers each).  With N
+ranks every frame's tile strips are dealt round-robin to the ranks (strong
+scaling of the same frames) and the only exchange is one RCCL gather of the
+batch's RGBA shards to rank 0, followed by an untile kernel there
+(BASELINE.json configs[2]).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (render_kernel), bound "hbm": algorithmic gather
@@ -18,6 +23,14 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 is CUDA-only) timed on this host on a bounded sample.
 """
 from __future__ import annotations
+
+import os
+
+# Steps in flight run on separate HIP streams; the runtime maps streams onto 4 hardware queues by
+# default and kernels sharing a queue serialise.  8 queues keep the render streams, the RCCL stream
+# and the untile stream apart (measured with single-view steps: 0.196 -> 0.124 ms per 1/8-frame
+# shard, scripts/pipeline_test.py).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import argparse
 import ctypes as C
@@ -38,6 +51,8 @@ BYTES_PER_SAMPLE = 16 * 8 * 4      # hash-grid gather, the path'
 FLOP_PER_SAMPLE = 20480            # both MLPs, padded
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16
+DEFAULT_VIEWS = 8                  # camera views per step (one launch)
+DEFAULT_DEPTH = 2                  # steps in flight (one context + stream + buffers each)
 
 
 def main():
@@ -50,6 +65,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default (3)")
+    ap.add_argument("--views-per-step", type=int, default=0,
+                    help="camera views rendered by ONE launch per step (nrf_render_views); 0 = default")
     ap.add_argument("--lib", default=None, help="another build of libnerfhip.so (A/B comparisons on one box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -81,10 +98,12 @@ def main():
     W, H = args.width, args.height
 
     # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits).
-    # `depth` frames are in flight: one context + stream + output buffers per slot, so the tail of one
-    # frame (a few long-lived tiles) overlaps the head of the next; every step is still a whole frame.
+    # `depth` steps are in flight: one context + stream + output buffers per slot, so the tail of one
+    # batch (a few long-lived tiles) overlaps the head of the next.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
-    depth = args.frames_in_flight or 3
+    depth = args.frames_in_flight or DEFAULT_DEPTH
+    V = args.views_per_step or DEFAULT_VIEWS
+    assert 1 <= V <= nh.NRF_MAX_VIEWS, "one launch per step: at most NRF_MAX_VIEWS views"
     opts = nh.default_options()
     opts.shard_index, opts.shard_count = rank, world
     tps = nh.tiles_per_shard(W, H, world)
@@ -103,21 +122,22 @@ def main():
         sl.ctx.set_options(opts)
         sl.ctx.set_resolution(W, H)
         sl.stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: NULL would make the ABI synchronise per call
-        sl.rgba = torch.zeros((n_px, 4), device=dev)
-        sl.depth = torch.zeros((n_px,), device=dev)
+        sl.rgba = torch.zeros((V, n_px, 4), device=dev)
+        sl.depth = torch.zeros((V, n_px), device=dev)
         sl.ctx.bind_output(sl.rgba.data_ptr(), sl.depth.data_ptr())
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
         if world > 1:
-            sl.all = torch.empty((world, tps * 64, 4), device=dev) if rank == 0 else None
+            sl.all = torch.empty((world, V, tps * 64, 4), device=dev) if rank == 0 else None
             sl.parts = [sl.all[r] for r in range(world)] if rank == 0 else None
-            sl.frame = torch.empty((H, W, 4), device=dev) if rank == 0 else None
+            sl.frame = torch.empty((V, H, W, 4), device=dev) if rank == 0 else None
         slots.append(sl)
     ctx = slots[0].ctx
     comm = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
 
     launch_events = []  # (start, end) HIP events around every render launch of the timed region
+    cams_step = np.stack([cam] * V)
 
     def step(i, timed=False):
         sl = slots[i % depth]
@@ -126,7 +146,7 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(sl.stream)
-        sl.ctx.render(cam, poses[i % len(poses)], stream=sl.stream.cuda_stream)
+        sl.ctx.render_views(cams_step, [poses[(i * V + v) % len(poses)] for v in range(V)], stream=sl.stream.cuda_stream)
         if timed:
             e1.record(sl.stream)
             launch_events.append((e0, e1))
@@ -138,7 +158,7 @@ def main():
                 comm.wait_event(sl.rendered)
                 dist.gather(sl.rgba, sl.parts if rank == 0 else None, dst=0)
                 if rank == 0:
-                    sl.ctx.untile(sl.all.data_ptr(), world, tps, 4, sl.frame.data_ptr(), stream=comm.cuda_stream)
+                    sl.ctx.untile_views(sl.all.data_ptr(), world, tps, 4, V, sl.frame.data_ptr(), stream=comm.cuda_stream)
                 sl.gathered.record(comm)
 
     def barrier():
@@ -160,16 +180,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-pose sample counts and kernel durations (untimed replays; the counts are deterministic)
+    # per-pose sample counts (untimed single-view replays; the counts are deterministic) and the duration
+    # of one step's launch when it has the chip to itself
     samples_pose, kern_ms = [], []
     stream = slots[0].stream
     for p in poses:
         ctx.render(cam, p, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
-        st = ctx.stats()
-        samples_pose.append(int(st.n_samples))
-        kern_ms.append(float(st.render_ms))
-    local_samples = sum(samples_pose[i % len(poses)] for i in range(args.steps))
+        samples_pose.append(int(ctx.stats().n_samples))
+    for i in range(min(args.steps, 4)):
+        ctx.render_views(cams_step, [poses[(i * V + v) % len(poses)] for v in range(V)], stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        kern_ms.append(float(ctx.stats().render_ms))
+    step_samples = [sum(samples_pose[(i * V + v) % len(poses)] for v in range(V)) for i in range(args.steps)]
+    local_samples = sum(step_samples)
     if world > 1:
         t = torch.tensor([local_samples], device=dev, dtype=torch.int64)
         dist.all_reduce(t)
@@ -184,7 +208,7 @@ def main():
         step(0)
         torch.cuda.synchronize(dev)
         if rank == 0:
-            frame = slots[0].frame
+            frame = slots[0].frame[0]
             solo = nh.NerfHip(dev.index)
             solo.load_model(desc)
             solo.set_resolution(W, H)
@@ -205,7 +229,7 @@ def main():
     # launches of different slots overlap, so this is what rocprofv3 --stats reports for the same command)
     mean_kern_s = float(np.mean([a.elapsed_time(b) for a, b in launch_events])) * 1e-3
     iso_kern_s = float(np.mean(kern_ms)) * 1e-3  # the same launches replayed one at a time
-    mean_samples_launch = float(np.mean([samples_pose[i % len(poses)] for i in range(args.steps)]))
+    mean_samples_launch = float(np.mean(step_samples))
     gather_gbs = mean_samples_launch * BYTES_PER_SAMPLE / mean_kern_s / 1e9
     in_flight = mean_kern_s * 1e3 / ms_per_step
     traffic = None
@@ -220,7 +244,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "frames_per_s": round(1e3 / ms_per_step, 2),
+        "frames_per_s": round(V * 1e3 / ms_per_step, 2),
+        "ms_per_frame": round(ms_per_step / V, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -229,7 +254,7 @@ def main():
         "config": {"workload": f"synthetic Lego-like scene {W}x{H}, hash grid L=16 F=2 T=2^19 base 16, "
                                "density MLP 32-64-16 + rgb MLP 32-64-64-16, SH-4, 8 orbit cameras",
                    "samples_per_frame": None,
-                   "parallelism": f"tile{world}", "frames_in_flight": depth},
+                   "parallelism": f"tile{world}", "views_per_step": V, "steps_in_flight": depth},
         "roofline": {
             "kernel": "render_kernel",
             "bound": "hbm",
@@ -254,7 +279,7 @@ def main():
     if check is not None:
         out["sharded_frame_equals_unsharded"] = check
     if world == 1:
-        out["config"]["samples_per_frame"] = int(mean_samples_launch)
+        out["config"]["samples_per_frame"] = int(mean_samples_launch / V)
         with torch.cuda.stream(stream):
             out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
         if not args.no_cpu_baseline:

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 1
+#define NRF_ABI_VERSION 2
+#define NRF_MAX_VIEWS 8 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -157,6 +158,10 @@ typedef struct nrf_frame {
   /* layout: shard_count==1 -> row-major [H][W]; otherwise tile-major
    * [n_tiles][64] in ascending tile id, see nrf_untile.                      */
   int32_t tile_major;
+  /* batched renders (nrf_render_views): view i lives at rgba + i*view_stride_px
+   * pixels (depth likewise); n_views == 1 for nrf_render                      */
+  int32_t n_views;
+  int64_t view_stride_px;
 } nrf_frame;
 
 typedef struct nrf_stats {
@@ -199,6 +204,18 @@ int nrf_set_options(nrf_context* ctx, const nrf_options* o);
  * unless stream==NULL, in which case the call returns after completion.      */
 int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
                void* stream, nrf_frame* out);
+/* Batched multi-view render: n_views cameras (cams [n][4], poses [n][16], same
+ * model / resolution / shard) in ONE launch per NRF_MAX_VIEWS views, view-major,
+ * so the workgroups of view v+1 fill the wave slots the tail of view v leaves
+ * idle.  This is the path for a render_server with many concurrent camera
+ * requests (the reference serves them one render_frame at a time,
+ * render_server.cu:86-101) and for multi-GPU shards, which are too small to
+ * fill a GPU alone.  Every view is bit-identical to an nrf_render of that
+ * camera.  The context's own buffers hold nrf_set_max_views views (default 1);
+ * bound buffers (nrf_bind_output) must hold n_views * view_stride_px pixels.  */
+int nrf_set_max_views(nrf_context* ctx, int max_views);
+int nrf_render_views(nrf_context* ctx, int n_views, const float* cams, const float* poses,
+                     void* stream, nrf_frame* out);
 /* Binds caller-owned device buffers (e.g. a render buffer's RGBA plane or a
  * torch tensor) as the target of subsequent nrf_render calls: rgba float
  * [n_px][4], depth float [n_px], n_px as nrf_frame describes.  NULL, NULL
@@ -213,6 +230,8 @@ int nrf_sync(nrf_context* ctx);
 int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
 /* Host copy of the float buffers (row-major; single-shard frames only).      */
 int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
+/* nrf_read_f32 for view `view` of the last nrf_render_views.                  */
+int nrf_read_view_f32(nrf_context* ctx, int view, float* rgba, float* depth);
 /* Host copy of this context's shard as rendered: rgba [n_tiles*64][4], depth
  * [n_tiles*64] (tile-major when shard_count > 1, else the row-major frame).  */
 int nrf_read_shard_f32(nrf_context* ctx, float* rgba, float* depth);
@@ -223,6 +242,11 @@ int nrf_read_shard_f32(nrf_context* ctx, float* rgba, float* depth);
 int nrf_untile(nrf_context* ctx, const void* gathered, int shard_count,
                int tiles_per_shard, int channels, void* out_rowmajor,
                void* stream);
+/* Same for gathered batches of nrf_render_views: [shard][view][n_tiles_max][64][C]
+ * -> [view][H][W][C].                                                         */
+int nrf_untile_views(nrf_context* ctx, const void* gathered, int shard_count,
+                     int tiles_per_shard, int channels, int n_views,
+                     void* out_rowmajor, void* stream);
 int nrf_tiles_per_shard(int width, int height, int shard_count, int* n);
 int nrf_get_stats(nrf_context* ctx, nrf_stats* s);
 

@@ -154,7 +154,10 @@ struct nrf_context {
   nrf_options opt{};
   int W = 0, H = 0;
   int n_local_tiles = 0;
-  size_t n_out_px = 0;  // pixels in the frame buffers
+  int max_views = 1;    // views the context's own frame buffers hold (nrf_set_max_views)
+  int last_views = 1;
+  size_t n_out_px = 0;  // pixels of ONE view in the frame buffers (= the view stride)
+  size_t n_alloc_px = 0;
   void* d_rgba = nullptr;
   void* d_depth = nullptr;
   void* d_counters = nullptr;
@@ -212,8 +215,9 @@ int alloc_frame(nrf_context* c) {
   c->n_local_tiles = local_tiles(c->W, c->H, c->opt.shard_index, c->opt.shard_count);
   int tps = 0;
   nrf_tiles_per_shard(c->W, c->H, c->opt.shard_count, &tps);
-  const size_t need = tiled ? (size_t)tps * 64 : (size_t)c->W * c->H;
-  if (need == c->n_out_px && c->d_rgba) return NRF_OK;
+  const size_t per_view = tiled ? (size_t)tps * 64 : (size_t)c->W * c->H;
+  const size_t need = per_view * (size_t)c->max_views;
+  if (per_view == c->n_out_px && need == c->n_alloc_px && c->d_rgba) return NRF_OK;
   HIP_TRY(hipDeviceSynchronize());
   free_frame(c);
   HIP_TRY(hipMalloc(&c->d_rgba, need * 16));
@@ -221,7 +225,8 @@ int alloc_frame(nrf_context* c) {
   HIP_TRY(hipMemsetAsync(c->d_rgba, 0, need * 16, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_depth, 0, need * 4, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  c->n_out_px = need;
+  c->n_out_px = per_view;
+  c->n_alloc_px = need;
   return NRF_OK;
 }
 
@@ -320,8 +325,8 @@ int nrf_create(int device, nrf_context** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, 64));
-  HIP_TRY(hipMemset(c->d_counters, 0, 64));
+  HIP_TRY(hipMalloc(&c->d_counters, 128));
+  HIP_TRY(hipMemset(c->d_counters, 0, 128));
   *out = c;
   return NRF_OK;
 }
@@ -588,21 +593,45 @@ int nrf_set_options(nrf_context* c, const nrf_options* o) {
   return alloc_frame(c);
 }
 
-int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* stream, nrf_frame* out) {
+int nrf_set_max_views(nrf_context* c, int max_views) {
+  if (!c || max_views < 1) return fail(NRF_E_INVALID, "max_views must be >= 1");
+  int rc = set_device(c);
+  if (rc) return rc;
+  c->max_views = max_views;
+  return alloc_frame(c);
+}
+
+// One launch per NRF_MAX_VIEWS cameras; all launches of a batch go to the same stream back to back.
+int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float* poses, void* stream, nrf_frame* out) {
   int rc = need_model(c);
   if (rc) return rc;
-  if (!cam || !pose) return fail(NRF_E_INVALID, "null argument");
+  if (!cams || !poses) return fail(NRF_E_INVALID, "null argument");
+  if (n_views < 1) return fail(NRF_E_INVALID, "n_views must be >= 1");
   if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
+  if (!c->bound_rgba && n_views > c->max_views)
+    return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
   FrameParams P;
-  fill_frame_params(c, cam, pose, P);
+  fill_frame_params(c, cams, poses, P);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, st));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 128, st));
   HIP_TRY(hipEventRecord(c->ev0, st));
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
   void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
-  HIP_TRY(launch_render(c->dm, P, rgba, depth, c->d_counters, st));
+  for (int first = 0; first < n_views; first += MAX_VIEWS) {
+    ViewBatch VB;
+    std::memset(&VB, 0, sizeof(VB));
+    VB.n_views = n_views - first < MAX_VIEWS ? n_views - first : MAX_VIEWS;
+    VB.view_stride_px = c->n_out_px;
+    for (int v = 0; v < VB.n_views; ++v) {
+      nerf_matrix_to_ngp(poses + 16 * (size_t)(first + v), c->desc.scale, VB.v[v].R, VB.v[v].org);
+      for (int i = 0; i < 4; ++i) VB.v[v].cam[i] = cams[4 * (size_t)(first + v) + i];
+    }
+    HIP_TRY(launch_render(c->dm, P, VB, (char*)rgba + (size_t)first * c->n_out_px * 16, (char*)depth + (size_t)first * c->n_out_px * 4,
+                          c->d_counters, st));
+  }
   c->last_rgba = rgba;
   c->last_depth = depth;
+  c->last_views = n_views;
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->last_stream = st;
   c->rendered = true;
@@ -614,16 +643,23 @@ int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* s
     out->rgba = rgba;
     out->depth = depth;
     out->tile_major = P.tile_major;
+    out->n_views = n_views;
+    out->view_stride_px = (int64_t)c->n_out_px;
   }
   return NRF_OK;
 }
 
+int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* stream, nrf_frame* out) {
+  if (!cam || !pose) return fail(NRF_E_INVALID, "null argument");
+  return nrf_render_views(c, 1, cam, pose, stream, out);
+}
+
 // Diagnostic (not part of include/nerfhip.h): raw counters of the last render; slots 2..6 are
 // only filled by the NRF_PHASE_TIMING build (make prof).
-int nrf_debug_counters(nrf_context* c, unsigned long long out[8]) {
+int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
   if (!c || !out) return fail(NRF_E_INVALID, "null argument");
   HIP_TRY(hipEventSynchronize(c->ev1));
-  HIP_TRY(hipMemcpy(out, c->d_counters, 64, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->d_counters, 128, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
 
@@ -666,18 +702,21 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   return NRF_OK;
 }
 
-int nrf_read_f32(nrf_context* c, float* rgba, float* depth) {
+int nrf_read_view_f32(nrf_context* c, int view, float* rgba, float* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
   if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_f32 needs a single-shard (row-major) frame");
+  if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->last_stream));
   const size_t n = (size_t)c->W * c->H;
-  if (rgba) HIP_TRY(hipMemcpy(rgba, c->last_rgba, n * 16, hipMemcpyDeviceToHost));
-  if (depth) HIP_TRY(hipMemcpy(depth, c->last_depth, n * 4, hipMemcpyDeviceToHost));
+  if (rgba) HIP_TRY(hipMemcpy(rgba, (const char*)c->last_rgba + (size_t)view * c->n_out_px * 16, n * 16, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(hipMemcpy(depth, (const char*)c->last_depth + (size_t)view * c->n_out_px * 4, n * 4, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
+
+int nrf_read_f32(nrf_context* c, float* rgba, float* depth) { return nrf_read_view_f32(c, 0, rgba, depth); }
 
 int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
@@ -710,9 +749,9 @@ int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) {
   return NRF_OK;
 }
 
-int nrf_untile(nrf_context* c, const void* gathered, int shard_count, int tiles_per_shard, int channels, void* out,
-               void* stream) {
-  if (!c || !gathered || !out || shard_count < 1 || tiles_per_shard < 1 || channels < 1)
+int nrf_untile_views(nrf_context* c, const void* gathered, int shard_count, int tiles_per_shard, int channels, int n_views,
+                     void* out, void* stream) {
+  if (!c || !gathered || !out || shard_count < 1 || tiles_per_shard < 1 || channels < 1 || n_views < 1)
     return fail(NRF_E_INVALID, "bad argument");
   if (c->W <= 0) return fail(NRF_E_STATE, "set_resolution has not been called");
   int rc = set_device(c);
@@ -721,9 +760,14 @@ int nrf_untile(nrf_context* c, const void* gathered, int shard_count, int tiles_
   nrf_tiles_per_shard(c->W, c->H, shard_count, &tps);
   if (tps != tiles_per_shard) return fail(NRF_E_INVALID, "tiles_per_shard does not match the resolution");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(launch_untile(gathered, shard_count, tiles_per_shard, channels, c->W, c->H, out, st));
+  HIP_TRY(launch_untile(gathered, shard_count, tiles_per_shard, channels, c->W, c->H, n_views, out, st));
   if (!stream) HIP_TRY(hipStreamSynchronize(st));
   return NRF_OK;
+}
+
+int nrf_untile(nrf_context* c, const void* gathered, int shard_count, int tiles_per_shard, int channels, void* out,
+               void* stream) {
+  return nrf_untile_views(c, gathered, shard_count, tiles_per_shard, channels, 1, out, stream);
 }
 
 // ---- stage entry points ----

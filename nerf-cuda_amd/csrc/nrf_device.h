@@ -87,8 +87,22 @@ struct DevModel {
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
 };
 
-struct FrameParams {
+// One camera of a batched launch (nrf_render_views): what differs between the views of a batch.
+struct ViewParams {
   float R[9];    // rotation of nerf_matrix_to_ngp(pose)
+  float org[3];  // translation
+  float cam[4];  // fl_x, fl_y, cx, cy
+};
+constexpr int MAX_VIEWS = 8;  // == NRF_MAX_VIEWS: views of one render_kernel launch (by-value kernel argument)
+struct ViewBatch {
+  ViewParams v[MAX_VIEWS];
+  int n_views;
+  int blocks_per_view;                 // workgroups per view: block b renders view b / blocks_per_view
+  unsigned long long view_stride_px;   // pixels between consecutive views in the output planes
+};
+
+struct FrameParams {
+  float R[9];    // view 0 (stage kernels): rotation of nerf_matrix_to_ngp(pose)
   float org[3];  // translation
   float cam[4];  // fl_x, fl_y, cx, cy
   int W, H;

@@ -144,8 +144,9 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
 template <bool GEN, bool COARSE_LDS, bool UNIT>
-__global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, float4* __restrict__ rgba,
-                                                     float* __restrict__ depth, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
+                                                     float4* __restrict__ rgba, float* __restrict__ depth,
+                                                     unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
   LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
@@ -167,7 +168,13 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // that order interleaves the image over all 8 XCDs at strip granularity, which balances the load
   // (the object covers a few image bands only; an "XCD owns a contiguous band" remap left half of
   // the XCDs idle: 43 % wave-slot occupancy in profiles/r01/pmc_summary_c.txt).
-  const int swz = (int)blockIdx.x;
+  // A launch renders VB.n_views cameras of the same model / resolution / shard: view-major block
+  // order, so the workgroups of view v+1 fill the wave slots that the tail of view v leaves idle.
+  const int view = (int)blockIdx.x / VB.blocks_per_view;  // wave-uniform (SALU)
+  const ViewParams& V = VB.v[view];
+  rgba += (size_t)view * VB.view_stride_px;
+  depth += (size_t)view * VB.view_stride_px;
+  const int swz = (int)blockIdx.x - view * VB.blocks_per_view;
   const int k_local = swz * RENDER_WAVES + wave;
   if (k_local >= P.n_local_tiles) return;  // no barrier after this point
   // partition unit = a strip of 4 horizontally adjacent tiles (one workgroup): strip s belongs to
@@ -180,13 +187,13 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
-  unsigned n_tile_slots = 0;
+  unsigned n_tile_slots = 0, n_lane_trips = 0, n_wave_iters = 0;
 #endif
   NRF_STAMP(t_begin);
   // ---- ray generation + aabb
-  const float o[3] = {P.org[0], P.org[1], P.org[2]};
+  const float o[3] = {V.org[0], V.org[1], V.org[2]};
   float d[3];
-  ray_dir(P.R, P.cam, px, py, d);
+  ray_dir(V.R, V.cam, px, py, d);
   float near, far;
   near_far(M.aabb, o, d, P.min_near, near, far);
   const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
@@ -258,6 +265,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       if (mm == 0ull || S + __popcll(mm) > 64) break;
       float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
       bool found = false;
+#ifdef NRF_PHASE_TIMING
+      const int budget_before = budget;
+#endif
       if (marching) {
         const int r = COARSE_LDS ? march_next<true, UNIT>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                     rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt)
@@ -267,6 +277,14 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
         marching = found;
         ended = ended || r == MARCH_EXHAUSTED;
       }
+#ifdef NRF_PHASE_TIMING
+      {
+        int used = budget_before - budget;
+        n_lane_trips += (unsigned)used;
+        for (int o = 32; o; o >>= 1) used = max(used, __shfl_xor(used, o));
+        n_wave_iters += (unsigned)used;
+      }
+#endif
       const unsigned long long fm = __ballot(found);
       if (found) {
         const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
@@ -350,8 +368,16 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     atomicAdd(&counters[5], t_end - t_begin);
     atomicAdd(&counters[6], 1ull);
     atomicAdd(&counters[7], (unsigned long long)n_tile_slots);
+    atomicAdd(&counters[9], (unsigned long long)n_wave_iters);
 #endif
   }
+#ifdef NRF_PHASE_TIMING
+  {
+    unsigned lt = n_lane_trips;
+    for (int o = 32; o; o >>= 1) lt += __shfl_xor(lt, o);
+    if (lane == 0) atomicAdd(&counters[8], (unsigned long long)lt);
+  }
+#endif
 }
 
 // ------------------------------------------------------------ stage kernels ----
@@ -561,18 +587,20 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
   }
 }
 
-// gathered [shard][tiles_per_shard][64][C] -> row-major [H][W][C]
+// gathered [shard][view][tiles_per_shard][64][C] -> row-major [view][H][W][C]
 __global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ gathered, int shard_count, int tiles_per_shard,
-                                                     int C, int W, int H, int tiles_x, float* __restrict__ out) {
-  const size_t total = (size_t)W * H;
+                                                     int C, int W, int H, int tiles_x, int n_views, float* __restrict__ out) {
+  const size_t frame = (size_t)W * H, total = frame * (size_t)n_views;
   const int strips_x = (tiles_x + 3) >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)(i / W);
+    const int view = (int)(i / frame);
+    const size_t p = i - (size_t)view * frame;
+    const int px = (int)(p % W), py = (int)(p / W);
     const int tx = px >> 3, ty = py >> 3;
     const int strip = ty * strips_x + (tx >> 2);
     const int shard = strip % shard_count, k = (strip / shard_count) * 4 + (tx & 3);
     const int l = (py & 7) * 8 + (px & 7);
-    const float* src = gathered + (((size_t)shard * tiles_per_shard + k) * 64 + l) * C;
+    const float* src = gathered + ((((size_t)shard * n_views + view) * tiles_per_shard + k) * 64 + l) * C;
     for (int ch = 0; ch < C; ++ch) out[i * C + ch] = src[ch];
   }
 }
@@ -604,13 +632,17 @@ static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
   return (int)g;
 }
 
-hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st) {
-  const int blocks = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
-  if (blocks <= 0) return hipSuccess;
+hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
+                         hipStream_t st) {
+  ViewBatch VB = VBin;
+  VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
+  if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return hipSuccess;
+  if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
+  const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
   const int lds = LDS_FIXED_BYTES + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
 #define NRF_LAUNCH_RENDER(G, C, U)                                                                                       \
-  hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, (float4*)rgba,         \
+  hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, VB, (float4*)rgba,     \
                      (float*)depth, (unsigned long long*)counters)
   // hot instance: compile-time activations, march tables in LDS, single cascade with mip_bound == 1
   const bool unit = lds_tab && M.cascade == 1 && M.bound >= 1.0f;
@@ -691,9 +723,10 @@ hipError_t launch_composite(const void* sigmas, const void* rgbs, const void* de
   return hipGetLastError();
 }
 
-hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, void* out, hipStream_t st) {
-  hipLaunchKernelGGL(untile_kernel, dim3(grid_for((uint64_t)W * H)), dim3(256), 0, st, (const float*)gathered, shard_count,
-                     tiles_per_shard, C, W, H, (W + 7) / 8, (float*)out);
+hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, int n_views, void* out,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(untile_kernel, dim3(grid_for((uint64_t)W * H * n_views)), dim3(256), 0, st, (const float*)gathered, shard_count,
+                     tiles_per_shard, C, W, H, (W + 7) / 8, n_views, (float*)out);
   return hipGetLastError();
 }
 

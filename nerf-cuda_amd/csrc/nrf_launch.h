@@ -6,8 +6,11 @@
 namespace nrf {
 struct DevModel;
 struct FrameParams;
+struct ViewBatch;
 
-hipError_t launch_render(const DevModel& M, const FrameParams& P, void* rgba, void* depth, void* counters, hipStream_t st);
+// one launch for VB.n_views (<= MAX_VIEWS) cameras; blocks_per_view is filled in by the launcher
+hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VB, void* rgba, void* depth, void* counters,
+                         hipStream_t st);
 hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st);
 hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st);
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, hipStream_t st);
@@ -18,7 +21,8 @@ hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, c
                         const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st);
 hipError_t launch_composite(const void* sigmas, const void* rgbs, const void* deltas, uint32_t n, uint32_t n_step, void* rays_t,
                             void* state, hipStream_t st);
-hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, void* out, hipStream_t st);
+hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, int n_views, void* out,
+                         hipStream_t st);
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
 int render_lds_bytes();
 int render_lds_table_max_bytes();

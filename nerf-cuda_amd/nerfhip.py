@@ -23,7 +23,8 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
-NRF_ABI_VERSION = 1
+NRF_ABI_VERSION = 2
+NRF_MAX_VIEWS = 8
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
 
 ACT = {"none": 0, "relu": 1, "exponential": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5, "sine": 6}
@@ -95,6 +96,8 @@ class Frame(C.Structure):
         ("rgba", C.c_void_p),
         ("depth", C.c_void_p),
         ("tile_major", C.c_int32),
+        ("n_views", C.c_int32),
+        ("view_stride_px", C.c_int64),
     ]
 
 
@@ -136,6 +139,10 @@ _SIGS = {
     "nrf_set_resolution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nrf_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "nrf_render": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(Frame)]),
+    "nrf_set_max_views": (C.c_int, [C.c_void_p, C.c_int]),
+    "nrf_render_views": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
+                                   C.POINTER(Frame)]),
+    "nrf_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_render_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
     "nrf_sync": (C.c_int, [C.c_void_p]),
@@ -145,6 +152,7 @@ _SIGS = {
     "nrf_read_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_read_shard_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_untile_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "nrf_rb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -384,6 +392,25 @@ class NerfHip:
         _check(self.lib.nrf_render(self.h, _fptr(cam), _fptr(pose), C.c_void_p(stream or 0), C.byref(f)))
         return f
 
+    def set_max_views(self, n: int):
+        _check(self.lib.nrf_set_max_views(self.h, int(n)))
+
+    def render_views(self, cams, poses, stream=None) -> Frame:
+        """nrf_render_views: cams [n][4], poses [n][4][4]; one launch per NRF_MAX_VIEWS views."""
+        cams = np.ascontiguousarray(cams, dtype=np.float32).reshape(-1, 4)
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+        if len(cams) != len(poses):
+            raise ValueError("cams and poses must have the same length")
+        f = Frame()
+        _check(self.lib.nrf_render_views(self.h, len(cams), _fptr(cams), _fptr(poses), C.c_void_p(stream or 0), C.byref(f)))
+        return f
+
+    def read_view_f32(self, view: int):
+        rgba = np.empty((self.height, self.width, 4), np.float32)
+        depth = np.empty((self.height, self.width), np.float32)
+        _check(self.lib.nrf_read_view_f32(self.h, int(view), rgba.ctypes.data, depth.ctypes.data))
+        return rgba, depth
+
     def bind_output(self, rgba_ptr, depth_ptr):
         _check(self.lib.nrf_bind_output(self.h, C.c_void_p(rgba_ptr or 0), C.c_void_p(depth_ptr or 0)))
 
@@ -407,6 +434,10 @@ class NerfHip:
     def untile(self, gathered_ptr, shard_count, tiles, channels, out_ptr, stream=None):
         _check(self.lib.nrf_untile(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels,
                                    C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    def untile_views(self, gathered_ptr, shard_count, tiles, channels, n_views, out_ptr, stream=None):
+        _check(self.lib.nrf_untile_views(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels, n_views,
+                                         C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
 
     # ---- stage entry points; arguments are device pointers (ints) ----
     def encode_grid(self, pos01, n, out, stream=None):

@@ -16,12 +16,14 @@ for az in (0, 45, 90):
     for _ in range(3):
         ctx.render(cam, pose)
     st = ctx.stats()
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     ctx.lib.nrf_debug_counters(ctx.h, out)
     s, r, m, n, c, tot, waves = [int(x) for x in out[:7]]
     slots = int(out[7])
     other = tot - m - n - c
     print(f"az {az}: {st.render_ms:.3f} ms samples {s} rounds {r} waves {waves}  samples/round {s/max(r,1):.1f}")
     print(f"   cycles/wave {tot/waves:.0f}  march {100*m/tot:.1f}%  network {100*n/tot:.1f}%  composite {100*c/tot:.1f}%  setup+final {100*other/tot:.1f}%")
+    lt, wi = int(out[8]), int(out[9])
+    print(f"   march: lane trips {lt} ({lt/max(s,1):.1f}/sample), wave trip-iterations {wi} ({wi/max(r,1):.1f}/round), lane efficiency {100*lt/max(64*wi,1):.1f}%")
     print(f"   MFMA tile slots evaluated {slots} = {100*s/max(slots,1):.1f}% filled")
     print(f"   per round: march {m/r:.0f}  network {n/r:.0f}  composite {c/r:.0f} cycles")

@@ -468,3 +468,52 @@ def test_config5_batched_views_800x800(ctx):
         ccam = cam.copy(); ccam[2] -= x0; ccam[3] -= y0
         want, _, _ = o.render(ccam, p, cw, ch, schedule=op.SCHED_PER_RAY)
         assert np.abs(got[y0:y0 + ch, x0:x0 + cw] - want).max() <= 2.0 / 255.0
+
+
+def test_render_views_one_launch_equals_single_renders(ctx):
+    """nrf_render_views (BASELINE config 5, render_server batching): every view of a batched launch is
+    bit-identical to nrf_render of that camera -- 11 views (two launches: 8 + 3), different intrinsics
+    per view, unsharded and as a tile-major shard with the documented view stride."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    ctx.load_model(desc)
+    W, H = 200, 120
+    n = nh.NRF_MAX_VIEWS + 3
+    cams = np.stack([syn.default_camera(W, H) * np.float32(1.0 + 0.03 * i) for i in range(n)])
+    poses = np.stack([syn.orbit_pose(33.0 * i, 10.0 + 4.0 * i) for i in range(n)])
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    single = []
+    for i in range(n):
+        ctx.render(cams[i], poses[i])
+        single.append(tuple(x.copy() for x in ctx.read_f32()))
+    with pytest.raises(nh.NerfHipError):
+        ctx.render_views(cams, poses)  # the context's own buffers hold one view until set_max_views
+    ctx.set_max_views(n)
+    f = ctx.render_views(cams, poses)
+    assert f.n_views == n and f.view_stride_px == W * H and ctx.stats().n_samples > 0
+    for i in range(n):
+        rgba, depth = ctx.read_view_f32(i)
+        np.testing.assert_array_equal(rgba, single[i][0])
+        np.testing.assert_array_equal(depth, single[i][1])
+    # sharded: views are tile-major shards, view_stride_px apart, in caller-owned memory
+    opts = nh.default_options(); opts.shard_index, opts.shard_count = 1, 2
+    ctx.set_options(opts)
+    tps = nh.tiles_per_shard(W, H, 2)
+    want = []
+    for i in range(n):
+        fr = ctx.render(cams[i], poses[i])
+        assert fr.tile_major == 1 and fr.view_stride_px == tps * 64
+        s = torch.empty((tps * 64, 4), device="cuda")
+        sync(); _d2d(s.data_ptr(), fr.rgba, tps * 64 * 16)
+        want.append(s.cpu().numpy())
+    out = torch.zeros((n, tps * 64, 4), device="cuda"); outd = torch.zeros((n, tps * 64), device="cuda")
+    sync()
+    ctx.bind_output(out.data_ptr(), outd.data_ptr())
+    fb = ctx.render_views(cams, poses)
+    ctx.bind_output(None, None)
+    assert fb.n_views == n and fb.view_stride_px == tps * 64
+    got = out.cpu().numpy()
+    for i in range(n):
+        np.testing.assert_array_equal(got[i], want[i])
+    ctx.set_options(nh.default_options())
+    ctx.set_max_views(1)
