@@ -501,6 +501,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       for (size_t i = 0; i < extra * 2; ++i) grid16.push_back((_Float16)src[i % ((size_t)L.size * 2)]);
     }
   }
+  if ((uint64_t)grid16.size() * 2 >= (1ull << 32))  // level_gather addresses the table by 32-bit byte offsets
+    return fail(NRF_E_UNSUPPORTED, "hash tables of 4 GiB or more are not supported");
   // Uploads go through the context's own stream and the device is drained afterwards: the
   // render stream is non-blocking, so a NULL-stream hipMemcpy gives no ordering against it
   // (seen on MI355X as a few stale table entries in the first frame after a reload).
@@ -526,6 +528,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   DevModel& M = c->dm;
   std::memset(&M, 0, sizeof(M));
   M.grid = (const uint32_t*)c->d_grid;
+  M.grid_bytes = (uint32_t)(grid16.size() * 2);
   M.occ_bits = (const uint32_t*)c->d_occ;
   M.wfrag = (const uint4*)c->d_wfrag;
   M.lv = (const LevelParams*)c->d_lv;

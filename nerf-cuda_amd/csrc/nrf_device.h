@@ -64,6 +64,7 @@ struct DevModel {
   const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
   const uint32_t* occ_coarse;  // OR over 4x4x4 cell blocks, [C][(H/4)^3] bits; nullptr if H % 4 != 0
   const float* cell_bound;     // [C][H+1] cell-boundary table (see march_next)
+  uint32_t grid_bytes;         // size of the device hash table (< 4 GiB): num_records of its buffer resource
   const uint32_t* occ_dilated;  // coarse cells within one density cell of an occupied density cell; C == 1 only, else nullptr
   const uint4* wfrag;        // N_FRAGS * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
@@ -258,6 +259,8 @@ struct MarchConst {
   uint32_t H, C, HH, HHH;
   uint32_t coarse_shift;  // 2 when the coarse grid is present, else 0
   uint32_t Hc;            // H >> coarse_shift
+  uint32_t log2H;         // UNIT instances only (H is a power of two there)
+  float halfH;            // 0.5f * H
 };
 
 __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_gamma) {
@@ -275,6 +278,8 @@ __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_ga
   c.Hm1 = (float)(M.H - 1);
   c.coarse_shift = M.coarse_shift;
   c.Hc = M.H >> M.coarse_shift;
+  c.log2H = 31u - (uint32_t)__builtin_clz(M.H | 1u);
+  c.halfH = 0.5f * (float)M.H;
   return c;
 }
 
@@ -285,9 +290,10 @@ enum : int { MARCH_FOUND = 0, MARCH_EXHAUSTED = 1, MARCH_OUT_OF_BUDGET = 2 };
 // are spent (MARCH_OUT_OF_BUDGET, t rests on the next candidate).  One loop trip = one trip of the
 // `while (t < far && step < n_step)` loop of render_utils.h:593-653.
 //   occ      fine bitfield (global)     coarse  coarse bitfield or nullptr     ctab  cell_bound table
-// UNIT == true: single cascade with mip_bound == 1 (bound >= 1): level 0, `x * mip_rbound` is `x * 1`
-// (exact), so the level / mip arithmetic disappears.  clamp() is v_med3_f32 (same value as
-// fminf(hi, fmaxf(lo, x)) for non-NaN x), index arithmetic is 24-bit.
+// UNIT == true: single cascade with mip_bound == 1 (bound >= 1) and H a power of two: level 0,
+// `x * mip_rbound` is `x * 1` (exact), so the level / mip arithmetic disappears; (0.5f*(x+1))*H is
+// (x+1)*(0.5f*H) (both factors are powers of two, so neither product rounds); cell indices are
+// shifts and ors.  clamp() is v_med3_f32 (same value as fminf(hi, fmaxf(lo, x)) for non-NaN x).
 __device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 template <bool COARSE, bool UNIT>
@@ -304,10 +310,10 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     int level = 0;
     int nx, ny, nz;
     if (UNIT) {
-      // mip_bound == 1: (x * 1 + 1) == (x + 1)
-      nx = (int)clamp3((0.5f * (x + 1)) * c.Hf, 0.0f, c.Hm1);
-      ny = (int)clamp3((0.5f * (y + 1)) * c.Hf, 0.0f, c.Hm1);
-      nz = (int)clamp3((0.5f * (z + 1)) * c.Hf, 0.0f, c.Hm1);
+      // mip_bound == 1: (x * 1 + 1) == (x + 1); H = 2^k: (0.5f * v) * H == v * (0.5f * H), no rounding
+      nx = (int)clamp3((x + 1) * c.halfH, 0.0f, c.Hm1);
+      ny = (int)clamp3((y + 1) * c.halfH, 0.0f, c.Hm1);
+      nz = (int)clamp3((z + 1) * c.halfH, 0.0f, c.Hm1);
     } else {
       float mip_bound = fminf(1.0f, c.bound), mip_rbound;
       if (c.C > 1) {
@@ -326,13 +332,14 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     }
     // all loads of the trip are issued together (addresses depend only on the cell), so the
     // trip pays one memory latency instead of three dependent ones
-    const uint32_t cell = UNIT ? __umul24(__umul24((uint32_t)nx, c.H) + (uint32_t)ny, c.H) + (uint32_t)nz
+    const uint32_t cell = UNIT ? ((((uint32_t)nx << c.log2H) | (uint32_t)ny) << c.log2H) | (uint32_t)nz
                                : (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
     const float* tab = UNIT ? ctab : ctab + (uint32_t)level * (c.H + 1);
     const float bx = tab[nx + sx], by = tab[ny + sy], bz = tab[nz + sz];
     bool occupied;
     if (COARSE) {
-      const uint32_t cc = UNIT ? __umul24(__umul24((uint32_t)nx >> 2, c.Hc) + ((uint32_t)ny >> 2), c.Hc) + ((uint32_t)nz >> 2)
+      const uint32_t lc = c.log2H - 2u;
+      const uint32_t cc = UNIT ? (((((uint32_t)nx >> 2) << lc) | ((uint32_t)ny >> 2)) << lc) | ((uint32_t)nz >> 2)
                                : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
       const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
       occupied = coarse_occ;
@@ -387,8 +394,8 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 //   level_gather: corner indices + the 8 loads (results not touched) + the fractional position
 //   level_interp: trilinear weights and the fp16 accumulation in corner order
 template <bool GENERIC, int UNI = 0>
-__device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, const LevelParams L, float px, float py,
-                                             float pz, uint32_t (&v)[8], float (&frac)[3]) {
+__device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                             float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
   float fx = px * L.scale; fx = fx + 0.5f;
   float fy = py * L.scale; fy = fy + 0.5f;
   float fz = pz * L.scale; fz = fz + 0.5f;
@@ -397,9 +404,13 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   frac[0] = fx - flx;
   frac[1] = fy - fly;
   frac[2] = fz - flz;
-  const uint32_t* table = grid + L.offset;
 
-  uint32_t idx[8];
+  // The gathers are MUBUF loads: address = table base (buffer resource, SGPRs) + a 32-bit BYTE
+  // offset per lane, so no 64-bit address arithmetic is spent per corner.  The shift by 2 is folded
+  // into the per-axis terms ((a ^ b ^ d) << 2 == (a<<2) ^ (b<<2) ^ (d<<2), (g * P) << 2 == g * (P << 2)
+  // mod 2^32); nrf_load_model rejects tables of 4 GiB or more.
+  uint32_t off[8];
+  const uint32_t level_off = L.offset << 2;
   if (GENERIC && L.mode == LV_GENERIC) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -411,28 +422,34 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
       if (stride <= L.size) { index += p1 * stride; stride *= L.res; }
       if (stride <= L.size) { index += p2 * stride; stride *= L.res; }
       if (L.hashed && L.size < stride) index = p0 ^ (p1 * 2654435761u) ^ (p2 * 805459861u);
-      idx[c] = index % L.size;
+      off[c] = ((index % L.size) << 2) + level_off;
     }
   } else {
     // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
     const bool hashed = UNI == 2 || (UNI == 0 && L.mode == LV_HASH_POW2);
-    const uint32_t my = hashed ? 2654435761u : L.res;
-    const uint32_t mz = hashed ? 805459861u : L.res * L.res;
-    const uint32_t mask = hashed ? L.size - 1 : 0xffffffffu;
-    const uint32_t ax[2] = {gx, gx + 1};
+    const uint32_t my = hashed ? (2654435761u << 2) : (L.res << 2);
+    const uint32_t mz = hashed ? (805459861u << 2) : ((L.res * L.res) << 2);
+    const uint32_t mask = hashed ? ((L.size - 1) << 2) : 0xffffffffu;
+    const uint32_t ax0 = (gx << 2) + (hashed ? 0u : level_off);  // dense: the level offset rides on the x term
+    const uint32_t ax[2] = {ax0, ax0 + 4u};
     const uint32_t ay0 = gy * my, az0 = gz * mz;
     const uint32_t ay[2] = {ay0, ay0 + my};
     const uint32_t az[2] = {az0, az0 + mz};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
-      if (UNI == 1) idx[c] = a + b + d;
-      else if (UNI == 2) idx[c] = (a ^ b ^ d) & mask;
-      else idx[c] = (hashed ? (a ^ b ^ d) : (a + b + d)) & mask;
+      if (UNI == 1) off[c] = a + b + d;
+      else if (UNI == 2) off[c] = ((a ^ b ^ d) & mask) + level_off;
+      else {  // per-lane choice as a bit select (v_bfi_b32): a ?: here compiles to divergent branches
+        const uint32_t pick = hashed ? 0xffffffffu : 0u;
+        const uint32_t hsh = ((a ^ b ^ d) & mask) + level_off, lin = a + b + d;
+        off[c] = (hsh & pick) | (lin & ~pick);
+      }
     }
   }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = table[idx[c]];
+  for (int c = 0; c < 8; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[c], 0, 0);
 }
 
 __device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const float (&frac)[3]) {
@@ -450,11 +467,11 @@ __device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const f
 }
 
 template <bool GENERIC, int UNI = 0>
-__device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, const LevelParams L, float px,
-                                                 float py, float pz) {
+__device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L,
+                                                 float px, float py, float pz) {
   uint32_t v[8];
   float frac[3];
-  level_gather<GENERIC, UNI>(grid, L, px, py, pz, v, frac);
+  level_gather<GENERIC, UNI>(grid, grid_bytes, L, px, py, pz, v, frac);
   return level_interp(v, frac);
 }
 

@@ -100,9 +100,9 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       for (int jl = 0; jl < 4; ++jl) {
         const LevelParams L = lvs[4 * jl + g];
         const uint32_t uni = GEN ? 0u : (M.uni_modes >> (2 * jl)) & 3u;
-        if (uni == 2u) level_gather<GEN, 2>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
-        else if (uni == 1u) level_gather<GEN, 1>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
-        else level_gather<GEN, 0>(M.grid, L, px, py, pz, gv[jl], gf[jl]);
+        if (uni == 2u) level_gather<GEN, 2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else if (uni == 1u) level_gather<GEN, 1>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else level_gather<GEN, 0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
       }
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp(gv[jl], gf[jl]);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
   const uint64_t total = (uint64_t)n * 16u;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
-    out[i] = encode_level<true>(M.grid, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
+    out[i] = encode_level<true>(M.grid, M.grid_bytes, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
   }
 }
 
@@ -645,7 +645,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, VB, (float4*)rgba,     \
                      (float*)depth, (unsigned long long*)counters)
   // hot instance: compile-time activations, march tables in LDS, single cascade with mip_bound == 1
-  const bool unit = lds_tab && M.cascade == 1 && M.bound >= 1.0f;
+  const bool unit = lds_tab && M.cascade == 1 && M.bound >= 1.0f && (M.H & (M.H - 1)) == 0;
   if (M.generic_act) {
     if (lds_tab) NRF_LAUNCH_RENDER(true, true, false); else NRF_LAUNCH_RENDER(true, false, false);
   } else {
