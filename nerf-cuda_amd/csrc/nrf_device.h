@@ -399,11 +399,22 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   float fx = px * L.scale; fx = fx + 0.5f;
   float fy = py * L.scale; fy = fy + 0.5f;
   float fz = pz * L.scale; fz = fz + 0.5f;
-  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-  const uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
-  frac[0] = fx - flx;
-  frac[1] = fy - fly;
-  frac[2] = fz - flz;
+  uint32_t gx, gy, gz;
+  if (GENERIC) {
+    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    gx = (uint32_t)(int)flx; gy = (uint32_t)(int)fly; gz = (uint32_t)(int)flz;
+    frac[0] = fx - flx;
+    frac[1] = fy - fly;
+    frac[2] = fz - flz;
+  } else {
+    // hot path: positions are in [0,1] (march clamps to the aabb), so f >= 0.5: the truncating
+    // conversion is floor, and v_fract_f32 returns f - floor(f) exactly (the subtraction is exact
+    // for f >= 0; the instruction's clamp to 1-ulp only concerns tiny negative inputs)
+    gx = (uint32_t)(int)fx; gy = (uint32_t)(int)fy; gz = (uint32_t)(int)fz;
+    frac[0] = __builtin_amdgcn_fractf(fx);
+    frac[1] = __builtin_amdgcn_fractf(fy);
+    frac[2] = __builtin_amdgcn_fractf(fz);
+  }
 
   // The gathers are MUBUF loads: address = table base (buffer resource, SGPRs) + a 32-bit BYTE
   // offset per lane, so no 64-bit address arithmetic is spent per corner.  The shift by 2 is folded

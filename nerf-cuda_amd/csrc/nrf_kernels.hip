@@ -381,6 +381,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 }
 
 // ------------------------------------------------------------ stage kernels ----
+// GEN == false: the same per-level specialisation render_kernel uses (uni_modes of the level's
+// group of four), so the bit-exact encode test covers the hot path's index arithmetic.
+template <bool GEN>
 __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, const float* __restrict__ pos01, uint32_t n,
                                                           uint32_t* __restrict__ out) {
   __shared__ LevelParams lvs[16];
@@ -390,7 +393,15 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
   const uint64_t total = (uint64_t)n * 16u;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
-    out[i] = encode_level<true>(M.grid, M.grid_bytes, lvs[level], pos01[3 * (size_t)s], pos01[3 * (size_t)s + 1], pos01[3 * (size_t)s + 2]);
+    const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
+    if (GEN) {
+      out[i] = encode_level<true>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    } else {
+      const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
+      if (uni == 2u) out[i] = encode_level<false, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+      else if (uni == 1u) out[i] = encode_level<false, 1>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+      else out[i] = encode_level<false, 0>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    }
   }
 }
 
@@ -659,8 +670,12 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 
 hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(encode_grid_kernel, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
-                     (uint32_t*)out);
+  if (M.generic_act)
+    hipLaunchKernelGGL(encode_grid_kernel<true>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+                       (uint32_t*)out);
+  else
+    hipLaunchKernelGGL(encode_grid_kernel<false>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+                       (uint32_t*)out);
   return hipGetLastError();
 }
 
