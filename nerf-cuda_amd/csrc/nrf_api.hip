@@ -547,6 +547,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       M.lds_ctab_floats = (uint32_t)fl;
     }
   }
+  if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
   M.pos_w = (float)(1.0 / (2 * (double)d->bound));
   M.cascade = d->cascade;
   M.H = d->density_grid_size;

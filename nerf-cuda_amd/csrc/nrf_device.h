@@ -86,6 +86,7 @@ struct DevModel {
   uint32_t coarse_shift;    // 2 or 0
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
+  uint32_t lds_dilated_words;  // words of occ_dilated that fit the (not yet used) weight area of LDS during ray setup (0: global)
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.

@@ -150,7 +150,6 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
   LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
-  stage_weights(M, wl, lvs);
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
@@ -158,11 +157,20 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // march tables: coarse occupancy bits + cell-boundary table (staged once per workgroup)
   uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + LDS_FIXED_BYTES);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
+  // LDS timeline of a workgroup: (1) level table, march tables and -- borrowed from the weight area,
+  // which is not needed yet -- the dilated coarse occupancy of the per-ray visibility walk; (2) ray
+  // setup of the four tiles (the walk does ~40 dependent bit lookups per ray: from global memory that
+  // was 26 % of all wave cycles); (3) the weight fragments overwrite the borrowed area.
+  uint32_t* dil_lds = reinterpret_cast<uint32_t*>(wl);
+  const bool use_dil_lds = COARSE_LDS && M.occ_dilated != nullptr && M.lds_dilated_words > 0;
+  if (use_dil_lds)
+    for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
   if (COARSE_LDS) {
     for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
     for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
-    __syncthreads();
   }
+  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+  __syncthreads();
 
   // Block -> tile-strip order.  Consecutive blocks go to different XCDs (round-robin dispatch); keeping
   // that order interleaves the image over all 8 XCDs at strip granularity, which balances the load
@@ -176,14 +184,14 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   depth += (size_t)view * VB.view_stride_px;
   const int swz = (int)blockIdx.x - view * VB.blocks_per_view;
   const int k_local = swz * RENDER_WAVES + wave;
-  if (k_local >= P.n_local_tiles) return;  // no barrier after this point
+  const bool valid_tile = k_local < P.n_local_tiles;  // wave-uniform; padding waves still take the barriers below
   // partition unit = a strip of 4 horizontally adjacent tiles (one workgroup): strip s belongs to
   // rank s % shard_count, local strip index s / shard_count (nerfhip.h nrf_options)
   const int strips_x = (P.tiles_x + 3) >> 2;
   const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
   const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-  const bool in_img = px < P.W && py < P.H;
+  const bool in_img = valid_tile && px < P.W && py < P.H;
 
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
@@ -242,11 +250,20 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     if (M.occ_dilated != nullptr && alive && !nan) {
       float t_last;
       const float t0 = fmaxf(t_in, near);
-      const bool vis = coarse_visibility(M.occ_dilated, (int)(M.H >> 2), fminf(1.0f, M.bound), o, d, rdx, rdy, rdz, t0, far_m, t_last);
+      const int Hc = (int)(M.H >> 2);
+      const float mb = fminf(1.0f, M.bound);
+      const bool vis = use_dil_lds ? coarse_visibility(dil_lds, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_last)
+                                   : coarse_visibility(M.occ_dilated, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_last);
       alive = vis;
       if (t_last < far_m) far_m = t_last;
     }
   }
+  // ---- the weight fragments replace the dilated bitfield
+  __syncthreads();
+  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  __syncthreads();
+  if (!valid_tile) return;  // no barrier after this point
+  NRF_STAMP(t_setup_done);
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
   int n_ray_samples = 0;
   unsigned n_samples = 0, n_rounds = 0;
@@ -369,6 +386,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     atomicAdd(&counters[6], 1ull);
     atomicAdd(&counters[7], (unsigned long long)n_tile_slots);
     atomicAdd(&counters[9], (unsigned long long)n_wave_iters);
+    atomicAdd(&counters[10], t_setup_done - t_begin);
 #endif
   }
 #ifdef NRF_PHASE_TIMING

@@ -25,5 +25,6 @@ for az in (0, 45, 90):
     print(f"   cycles/wave {tot/waves:.0f}  march {100*m/tot:.1f}%  network {100*n/tot:.1f}%  composite {100*c/tot:.1f}%  setup+final {100*other/tot:.1f}%")
     lt, wi = int(out[8]), int(out[9])
     print(f"   march: lane trips {lt} ({lt/max(s,1):.1f}/sample), wave trip-iterations {wi} ({wi/max(r,1):.1f}/round), lane efficiency {100*lt/max(64*wi,1):.1f}%")
+    print(f"   setup (raygen, SH, box clip, coarse DDA) {100*int(out[10])/tot:.1f}% of wave cycles = {int(out[10])/waves:.0f} cycles/wave")
     print(f"   MFMA tile slots evaluated {slots} = {100*s/max(slots,1):.1f}% filled")
     print(f"   per round: march {m/r:.0f}  network {n/r:.0f}  composite {c/r:.0f} cycles")
