@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define NRF_ABI_VERSION 2
-#define NRF_MAX_VIEWS 8 /* cameras one launch of the fused kernel takes (nrf_render_views) */
+#define NRF_MAX_VIEWS 32 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
 enum {

@@ -325,8 +325,8 @@ int nrf_create(int device, nrf_context** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, 128));
-  HIP_TRY(hipMemset(c->d_counters, 0, 128));
+  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES));
+  HIP_TRY(hipMemset(c->d_counters, 0, COUNTER_BYTES));
   *out = c;
   return NRF_OK;
 }
@@ -617,7 +617,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   FrameParams P;
   fill_frame_params(c, cams, poses, P);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 128, st));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, COUNTER_BYTES, st));
   HIP_TRY(hipEventRecord(c->ev0, st));
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
   void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
@@ -663,7 +663,12 @@ int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* s
 int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
   if (!c || !out) return fail(NRF_E_INVALID, "null argument");
   HIP_TRY(hipEventSynchronize(c->ev1));
-  HIP_TRY(hipMemcpy(out, c->d_counters, 128, hipMemcpyDeviceToHost));
+  unsigned long long raw[COUNTER_SLOTS * 16];
+  HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) {
+    out[i] = 0;
+    for (int sl = 0; sl < COUNTER_SLOTS; ++sl) out[i] += raw[sl * 16 + i];
+  }
   return NRF_OK;
 }
 
@@ -695,8 +700,12 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipEventSynchronize(c->ev1));
-  unsigned long long cnt[2] = {0, 0};
-  HIP_TRY(hipMemcpy(cnt, c->d_counters, 16, hipMemcpyDeviceToHost));
+  unsigned long long raw[COUNTER_SLOTS * 16], cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
+  for (int sl = 0; sl < COUNTER_SLOTS; ++sl) {
+    cnt[0] += raw[sl * 16];
+    cnt[1] += raw[sl * 16 + 1];
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   s->n_rays = (uint64_t)c->n_local_tiles * 64;

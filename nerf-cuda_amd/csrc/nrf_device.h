@@ -95,7 +95,12 @@ struct ViewParams {
   float org[3];  // translation
   float cam[4];  // fl_x, fl_y, cx, cy
 };
-constexpr int MAX_VIEWS = 8;  // == NRF_MAX_VIEWS: views of one render_kernel launch (by-value kernel argument)
+// Statistics counters: COUNTER_SLOTS copies of 16 x u64 (one 128-byte line each); a workgroup adds to copy
+// blockIdx % COUNTER_SLOTS.  Device-scope atomics on ONE address serialise at ~12 ns each across the 8 XCDs:
+// two of them per wave made an all-background 1080p frame cost 0.79 ms.
+constexpr int COUNTER_SLOTS = 64;
+constexpr int COUNTER_BYTES = COUNTER_SLOTS * 16 * 8;
+constexpr int MAX_VIEWS = 32; // == NRF_MAX_VIEWS: views of one render_kernel launch (by-value kernel argument)
 struct ViewBatch {
   ViewParams v[MAX_VIEWS];
   int n_views;

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // the XCDs idle: 43 % wave-slot occupancy in profiles/r01/pmc_summary_c.txt).
   // A launch renders VB.n_views cameras of the same model / resolution / shard: view-major block
   // order, so the workgroups of view v+1 fill the wave slots that the tail of view v leaves idle.
+  // (Alternating the blocks of 2-8 views, each started at a different height of its frame, was
+  // measured 2-10 % slower: the views then compete for L1/L2 with disjoint table regions.)
   const int view = (int)blockIdx.x / VB.blocks_per_view;  // wave-uniform (SALU)
   const ViewParams& V = VB.v[view];
   rgba += (size_t)view * VB.view_stride_px;
@@ -258,10 +260,12 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       if (t_last < far_m) far_m = t_last;
     }
   }
-  // ---- the weight fragments replace the dilated bitfield
-  __syncthreads();
-  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
-  __syncthreads();
+  // ---- the weight fragments replace the dilated bitfield -- unless no ray of the four tiles can sample
+  // (background strips, 60-70 % of a typical frame): those workgroups store the background and leave
+  if (__syncthreads_or(alive ? 1 : 0) != 0) {
+    for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+    __syncthreads();
+  }
   if (!valid_tile) return;  // no barrier after this point
   NRF_STAMP(t_setup_done);
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
@@ -374,10 +378,13 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     depth[idx] = 0.f;
   }
-  if (lane == 0) {
+  counters += (blockIdx.x % COUNTER_SLOTS) * 16;  // see COUNTER_SLOTS
+  if (lane == 0 && n_rounds != 0) {           // waves that never sampled (background) add nothing
     atomicAdd(&counters[0], (unsigned long long)n_samples);
     atomicAdd(&counters[1], (unsigned long long)n_rounds);
+  }
 #ifdef NRF_PHASE_TIMING
+  if (lane == 0) {
     NRF_STAMP(t_end);
     atomicAdd(&counters[2], c_march);
     atomicAdd(&counters[3], c_net);
@@ -387,8 +394,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     atomicAdd(&counters[7], (unsigned long long)n_tile_slots);
     atomicAdd(&counters[9], (unsigned long long)n_wave_iters);
     atomicAdd(&counters[10], t_setup_done - t_begin);
-#endif
   }
+#endif
 #ifdef NRF_PHASE_TIMING
   {
     unsigned lt = n_lane_trips;

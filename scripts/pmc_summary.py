@@ -15,6 +15,7 @@ for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0]
         if "nrf::" not in k:
             continue
+        k = f"{k} grid={r['Grid_Size']}"  # launches of different sizes (8-view steps, single-view replays) apart
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["_dur_" + r["Counter_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         meta[k] = dict(grid=r["Grid_Size"], wg=r["Workgroup_Size"], lds=r["LDS_Block_Size"], vgpr=r["VGPR_Count"],
