@@ -11,9 +11,10 @@ The views of a batch are independent frames: batching only lets the workgroups
 of view v+1 take the wave slots that the few long-lived tiles of view v leave
 idle (one frame alone: 1.35 ms; in a batch: 0.90 ms per frame).  With N ranks
 every frame's tile strips are dealt round-robin to the ranks (strong scaling of
-the same frames), two steps are in flight, and the only exchange is one RCCL
-gather of the batch's RGBA shards to rank 0, followed by an untile kernel there
-(BASELINE.json configs[2]).
+the same frames), two steps are in flight, every rank quantises its shard to
+the reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only exchange
+is one RCCL gather of the batch's shards to rank 0, followed by an untile kernel
+there (BASELINE.json configs[2]; --gather-format f32 ships float RGBA instead).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (render_kernel), bound "hbm": algorithmic gather
@@ -68,6 +69,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default (3)")
     ap.add_argument("--views-per-step", type=int, default=0,
                     help="camera views rendered by ONE launch per step (nrf_render_views); 0 = default")
+    ap.add_argument("--gather-format", choices=("rgbd8", "f32"), default="rgbd8",
+                    help="N > 1: what the ranks send to rank 0 -- the reference's 8-bit image (r,g,b,depth: 4 B/px, "
+                         "quantised on the rendering GPU) or the float RGBA plane (16 B/px)")
     ap.add_argument("--lib", default=None, help="another build of libnerfhip.so (A/B comparisons on one box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -129,9 +133,15 @@ def main():
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
         if world > 1:
-            sl.all = torch.empty((world, V, tps * 64, 4), device=dev) if rank == 0 else None
+            if args.gather_format == "rgbd8":  # 4-byte pixels: one int32 "channel"
+                sl.send = torch.zeros((V, n_px), dtype=torch.int32, device=dev)
+                sl.all = torch.empty((world, V, tps * 64), dtype=torch.int32, device=dev) if rank == 0 else None
+                sl.frame = torch.empty((V, H, W), dtype=torch.int32, device=dev) if rank == 0 else None
+            else:
+                sl.send = sl.rgba
+                sl.all = torch.empty((world, V, tps * 64, 4), device=dev) if rank == 0 else None
+                sl.frame = torch.empty((V, H, W, 4), device=dev) if rank == 0 else None
             sl.parts = [sl.all[r] for r in range(world)] if rank == 0 else None
-            sl.frame = torch.empty((V, H, W, 4), device=dev) if rank == 0 else None
         slots.append(sl)
     ctx = slots[0].ctx
     comm = torch.cuda.Stream(dev)
@@ -154,12 +164,16 @@ def main():
         if world > 1:
             # the one exchange of the path: every rank's RGBA shard -> rank 0 (direct xGMI sends: xGMI is
             # point-to-point, so a gather moves 1/N-th of what an all-gather would), untile on rank 0
+            if args.gather_format == "rgbd8":  # nerf_render.cu:345-359 on the rendering GPU, 4 B/px on the wire
+                sl.ctx.quantize_rgbd8(sl.rgba.data_ptr(), sl.depth.data_ptr(), V * n_px, sl.send.data_ptr(),
+                                      stream=sl.stream.cuda_stream)
             sl.rendered.record(sl.stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(sl.rendered)
-                dist.gather(sl.rgba, sl.parts if rank == 0 else None, dst=0)
+                dist.gather(sl.send, sl.parts if rank == 0 else None, dst=0)
                 if rank == 0:
-                    sl.ctx.untile_views(sl.all.data_ptr(), world, tps, 4, V, sl.frame.data_ptr(), stream=comm.cuda_stream)
+                    sl.ctx.untile_views(sl.all.data_ptr(), world, tps, 4 if args.gather_format == "f32" else 1, V,
+                                        sl.frame.data_ptr(), stream=comm.cuda_stream)
                 sl.gathered.record(comm)
 
     def barrier():
@@ -214,8 +228,14 @@ def main():
             solo.load_model(desc)
             solo.set_resolution(W, H)
             solo.render(cam, poses[0])
-            want, _ = solo.read_f32()
-            check = bool(np.array_equal(frame.cpu().numpy(), want))
+            if args.gather_format == "rgbd8":
+                rgb8, d8 = solo.read_u8()
+                want = (rgb8[..., 0].astype(np.uint32) | (rgb8[..., 1].astype(np.uint32) << 8) |
+                        (rgb8[..., 2].astype(np.uint32) << 16) | (d8.astype(np.uint32) << 24))
+                check = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), want))
+            else:
+                want, _ = solo.read_f32()
+                check = bool(np.array_equal(frame.cpu().numpy(), want))
             solo.close()
         dist.barrier()
 
@@ -258,7 +278,8 @@ def main():
         "config": {"workload": f"synthetic Lego-like scene {W}x{H}, hash grid L=16 F=2 T=2^19 base 16, "
                                "density MLP 32-64-16 + rgb MLP 32-64-64-16, SH-4, 8 orbit cameras",
                    "samples_per_frame": None,
-                   "parallelism": f"tile{world}", "views_per_step": V, "steps_in_flight": depth},
+                   "parallelism": f"tile{world}", "views_per_step": V, "steps_in_flight": depth,
+                   "gather": (args.gather_format if world > 1 else None)},
         "roofline": {
             "kernel": "render_kernel",
             "bound": "hbm",

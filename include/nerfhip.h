@@ -228,6 +228,13 @@ int nrf_render_async(nrf_context* ctx, const float cam[4], const float pose[16],
 int nrf_sync(nrf_context* ctx);
 /* Host copy + quantisation, nerf_render.cu:345-359 (saturating, row-major). */
 int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
+/* The same quantisation on the device for any float frame / shard / batch of
+ * n_px pixels: out[i] = r | g << 8 | b << 16 | depth << 24.  Four bytes per
+ * pixel instead of twenty is what a multi-GPU gather should carry when the
+ * consumer wants the reference's 8-bit Image (common.h:75-89); 4-byte pixels go
+ * through nrf_untile(_views) with channels = 1.                               */
+int nrf_quantize_rgbd8(nrf_context* ctx, const void* rgba, const void* depth, uint64_t n_px,
+                       void* out_u32, void* stream);
 /* Host copy of the float buffers (row-major; single-shard frames only).      */
 int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
 /* nrf_read_f32 for view `view` of the last nrf_render_views.                  */

@@ -762,6 +762,16 @@ int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) {
   return NRF_OK;
 }
 
+int nrf_quantize_rgbd8(nrf_context* c, const void* rgba, const void* depth, uint64_t n_px, void* out_u32, void* stream) {
+  if (!c || !rgba || !depth || !out_u32) return fail(NRF_E_INVALID, "null argument");
+  int rc = set_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(launch_quantize_rgbd8(rgba, depth, n_px, out_u32, st));
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
 int nrf_untile_views(nrf_context* c, const void* gathered, int shard_count, int tiles_per_shard, int channels, int n_views,
                      void* out, void* stream) {
   if (!c || !gathered || !out || shard_count < 1 || tiles_per_shard < 1 || channels < 1 || n_views < 1)

@@ -770,6 +770,23 @@ hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_sh
   return hipGetLastError();
 }
 
+// The reference's output format packed per pixel: r | g << 8 | b << 16 | depth << 24 (any buffer layout)
+__global__ __launch_bounds__(256) void quantize_rgbd8_kernel(const float4* __restrict__ rgba, const float* __restrict__ depth,
+                                                             size_t n, uint32_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = rgba[i];
+    out[i] = (uint32_t)quant_u8(v.x) | ((uint32_t)quant_u8(v.y) << 8) | ((uint32_t)quant_u8(v.z) << 16) |
+             ((uint32_t)quant_u8(depth[i]) << 24);
+  }
+}
+
+hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n, void* out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(quantize_rgbd8_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float4*)rgba, (const float*)depth, (size_t)n,
+                     (uint32_t*)out);
+  return hipGetLastError();
+}
+
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st) {
   hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((uint64_t)n)), dim3(256), 0, st, (const float4*)rgba, (const float*)depth, n,
                      (unsigned char*)rgb8, (unsigned char*)depth8);

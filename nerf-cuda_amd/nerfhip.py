@@ -152,6 +152,7 @@ _SIGS = {
     "nrf_read_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_read_shard_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_quantize_rgbd8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "nrf_untile_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -434,6 +435,10 @@ class NerfHip:
     def untile(self, gathered_ptr, shard_count, tiles, channels, out_ptr, stream=None):
         _check(self.lib.nrf_untile(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels,
                                    C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    def quantize_rgbd8(self, rgba_ptr, depth_ptr, n_px, out_ptr, stream=None):
+        _check(self.lib.nrf_quantize_rgbd8(self.h, C.c_void_p(rgba_ptr), C.c_void_p(depth_ptr), int(n_px), C.c_void_p(out_ptr),
+                                           C.c_void_p(stream or 0)))
 
     def untile_views(self, gathered_ptr, shard_count, tiles, channels, n_views, out_ptr, stream=None):
         _check(self.lib.nrf_untile_views(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels, n_views,

@@ -517,3 +517,21 @@ def test_render_views_one_launch_equals_single_renders(ctx):
         np.testing.assert_array_equal(got[i], want[i])
     ctx.set_options(nh.default_options())
     ctx.set_max_views(1)
+
+
+def test_quantize_rgbd8_matches_reference_packing(ctx):
+    """nrf_quantize_rgbd8 = (unsigned char)(255.0 * x) of nerf_render.cu:352-359 (saturating, NaN -> 0) packed
+    r | g << 8 | b << 16 | depth << 24, bit for bit the oracle's nrfo_quantize_u8."""
+    rng = np.random.default_rng(5)
+    n = 10007
+    rgba = rng.uniform(-0.2, 1.2, (n, 4)).astype(np.float32)
+    depth = rng.uniform(-0.2, 1.2, n).astype(np.float32)
+    rgba[:8, 0] = [0.0, 1.0, np.nan, np.inf, -np.inf, 0.5, 1 / 255.0, 254.999 / 255.0]
+    rgb8, d8 = op.quantize_u8(rgba, depth)
+    want = (rgb8[:, 0].astype(np.uint32) | (rgb8[:, 1].astype(np.uint32) << 8) | (rgb8[:, 2].astype(np.uint32) << 16) |
+            (d8.astype(np.uint32) << 24))
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    r_d, d_d = dev(rgba), dev(depth)
+    sync()
+    ctx.quantize_rgbd8(r_d.data_ptr(), d_d.data_ptr(), n, out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want)
