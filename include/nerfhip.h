@@ -237,8 +237,9 @@ int nrf_quantize_rgbd8(nrf_context* ctx, const void* rgba, const void* depth, ui
                        void* out_u32, void* stream);
 /* Host copy of the float buffers (row-major; single-shard frames only).      */
 int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
-/* nrf_read_f32 for view `view` of the last nrf_render_views.                  */
+/* nrf_read_f32 / nrf_read_u8 for view `view` of the last nrf_render_views.    */
 int nrf_read_view_f32(nrf_context* ctx, int view, float* rgba, float* depth);
+int nrf_read_view_u8(nrf_context* ctx, int view, uint8_t* rgb, uint8_t* depth);
 /* Host copy of this context's shard as rendered: rgba [n_tiles*64][4], depth
  * [n_tiles*64] (tile-major when shard_count > 1, else the row-major frame).  */
 int nrf_read_shard_f32(nrf_context* ctx, float* rgba, float* depth);

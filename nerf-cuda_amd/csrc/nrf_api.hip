@@ -743,10 +743,11 @@ int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
   return NRF_OK;
 }
 
-int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) {
+int nrf_read_view_u8(nrf_context* c, int view, uint8_t* rgb, uint8_t* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
   if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_u8 needs a single-shard (row-major) frame");
+  if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);
   if (rc) return rc;
   const size_t n = (size_t)c->W * c->H;
@@ -755,12 +756,15 @@ int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) {
     HIP_TRY(hipMalloc(&c->d_depth8, n));
   }
   hipStream_t st = c->last_stream;
-  HIP_TRY(launch_quantize(c->last_rgba, c->last_depth, (int)n, c->d_rgb8, c->d_depth8, st));
+  HIP_TRY(launch_quantize((const char*)c->last_rgba + (size_t)view * c->n_out_px * 16,
+                          (const char*)c->last_depth + (size_t)view * c->n_out_px * 4, (int)n, c->d_rgb8, c->d_depth8, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (rgb) HIP_TRY(hipMemcpy(rgb, c->d_rgb8, n * 3, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(hipMemcpy(depth, c->d_depth8, n, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
+
+int nrf_read_u8(nrf_context* c, uint8_t* rgb, uint8_t* depth) { return nrf_read_view_u8(c, 0, rgb, depth); }
 
 int nrf_quantize_rgbd8(nrf_context* c, const void* rgba, const void* depth, uint64_t n_px, void* out_u32, void* stream) {
   if (!c || !rgba || !depth || !out_u32) return fail(NRF_E_INVALID, "null argument");

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <stdexcept>
 
@@ -258,6 +259,39 @@ Image NerfRender::render_frame(Camera cam, Matrix4f pos) {
     }
   }
   return Image(W, H, us_image.data(), us_depth.data());
+}
+
+std::vector<Image> NerfRender::render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses) {
+  if (!m_have_network) throw std::runtime_error{"render_frames: no network loaded"};
+  if (cams.size() != poses.size()) throw std::runtime_error{"render_frames: cams and poses differ in length"};
+  const int W = resolution[0], H = resolution[1], n = (int)cams.size();
+  const size_t px = (size_t)W * H;
+  m_batch_image.resize(px * 3 * (size_t)n);
+  m_batch_depth.resize(px * (size_t)n);
+  std::vector<Image> out;
+  if (m_ctx.size() != 1) {  // sharded instances: one frame at a time (the host gathers every frame's shards)
+    for (int v = 0; v < n; ++v) {
+      const Image img = render_frame(cams[v], poses[v]);
+      std::memcpy(m_batch_image.data() + px * 3 * v, img.rgb, px * 3);
+      std::memcpy(m_batch_depth.data() + px * v, img.depth, px);
+    }
+  } else if (n > 0) {
+    if (n > m_max_views) {
+      check(nrf_set_max_views(m_ctx[0], n), "nrf_set_max_views");
+      m_max_views = n;
+    }
+    std::vector<float> c4((size_t)4 * n), p16((size_t)16 * n);
+    for (int v = 0; v < n; ++v) {
+      const float c[4] = {cams[v].fl_x, cams[v].fl_y, cams[v].cx, cams[v].cy};
+      std::memcpy(&c4[4 * (size_t)v], c, sizeof(c));
+      std::memcpy(&p16[16 * (size_t)v], poses[v].m, sizeof(poses[v].m));
+    }
+    check(nrf_render_views(m_ctx[0], n, c4.data(), p16.data(), nullptr, nullptr), "nrf_render_views");
+    for (int v = 0; v < n; ++v)
+      check(nrf_read_view_u8(m_ctx[0], v, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v), "nrf_read_view_u8");
+  }
+  for (int v = 0; v < n; ++v) out.emplace_back(W, H, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v);
+  return out;
 }
 
 void NerfRender::generate_rays(Camera cam, Matrix4f pos, int threadid) {

@@ -56,6 +56,9 @@ class NerfRender {
   void reset_network();
   void set_resolution(Vector2i resolution);
   Image render_frame(Camera cam, Matrix4f pos);
+  // Batched form (addition): all views in one launch per NRF_MAX_VIEWS cameras (nrf_render_views); every
+  // returned Image equals render_frame of that camera.  The images stay valid until the next render call.
+  std::vector<Image> render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses);
   // device ray buffers of the reference are internal to the fused kernel; this fills host copies
   void generate_rays(Camera cam, Matrix4f pos, int threadid);
   void generate_density_grid();  // dead code in the reference (nerf_render.cu:388-429): throws
@@ -78,6 +81,8 @@ class NerfRender {
   std::vector<float> m_params, m_density_grid;
   Vector2i resolution;
   std::vector<unsigned char> us_image, us_depth;
+  std::vector<unsigned char> m_batch_image, m_batch_depth;  // render_frames
+  int m_max_views = 1;
   std::vector<float> m_shard_rgba, m_shard_depth, m_rays_o, m_rays_d;
   int m_tiles_per_shard = 0;
 };

@@ -2,6 +2,13 @@
 // on POSIX sockets (sockpp is not vendored).  Wire protocol, unchanged: the client sends 16
 // little-endian f32 = row-major 4x4 camera-to-world; the server answers exactly 3*W*H bytes of
 // RGB u8, row-major, no header.  Fixed camera {840, 840, 339, 590} and 1080x1080 as in the reference.
+//
+// Unlike the reference (one client at a time, one render_frame per request) any number of clients
+// may be connected: each connection has a reader thread that queues its pose, and ONE render
+// thread takes everything that is queued -- up to NRF_MAX_VIEWS poses -- into a single
+// render_frames call (one launch of the fused kernel).  Requests that arrive while a batch renders
+// form the next batch, so batching needs no timer and a lone client sees no added latency
+// (BASELINE config 5: many concurrent camera requests).
 //   usage: render_server [port=12345] [snapshot=./freality.msgpack] [width height]
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -9,11 +16,18 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "nerf_render.h"
 
@@ -40,6 +54,90 @@ static bool write_n(int fd, const void* buf, size_t n) {
   return true;
 }
 
+namespace {
+
+struct Request {
+  Matrix4f pose;
+  std::vector<unsigned char> rgb;  // filled by the render thread
+  bool done = false, failed = false;
+  std::mutex m;
+  std::condition_variable cv;
+};
+
+struct Batcher {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<Request>> queue;
+  std::atomic<bool> stop{false};
+  std::atomic<unsigned long> batches{0}, frames{0};
+};
+
+// the one thread that owns the renderer
+void render_loop(NerfRender& render, const Camera cam, const size_t frame_bytes, Batcher& b) {
+  while (true) {
+    std::vector<std::shared_ptr<Request>> batch;
+    {
+      std::unique_lock<std::mutex> lk(b.m);
+      b.cv.wait(lk, [&] { return b.stop.load() || !b.queue.empty(); });
+      if (b.stop.load() && b.queue.empty()) return;
+      while (!b.queue.empty() && batch.size() < (size_t)NRF_MAX_VIEWS) {
+        batch.push_back(b.queue.front());
+        b.queue.pop_front();
+      }
+    }
+    bool ok = true;
+    try {
+      std::vector<Camera> cams(batch.size(), cam);
+      std::vector<Matrix4f> poses;
+      for (const auto& r : batch) poses.push_back(r->pose);
+      const std::vector<Image> imgs = render.render_frames(cams, poses);
+      for (size_t i = 0; i < batch.size(); ++i) batch[i]->rgb.assign(imgs[i].rgb, imgs[i].rgb + frame_bytes);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "render error: %s\n", e.what());
+      ok = false;
+    }
+    b.batches++;
+    b.frames += batch.size();
+    for (const auto& r : batch) {
+      std::lock_guard<std::mutex> lk(r->m);
+      r->done = true;
+      r->failed = !ok;
+      r->cv.notify_one();
+    }
+  }
+}
+
+void serve_client(int sock, const std::string peer, const size_t frame_bytes, Batcher& b, int srv) {
+  std::cout << "Received a connection request from " << peer << std::endl;
+  float nerf_pos[16] = {0};
+  while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
+    if (std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {  // test hook
+      std::printf("\nbatches %lu frames %lu\n", b.batches.load(), b.frames.load());  // one write: other threads print too
+      std::fflush(stdout);
+      b.stop = true;
+      b.cv.notify_all();
+      ::shutdown(srv, SHUT_RDWR);  // wakes the acceptor
+      break;
+    }
+    auto req = std::make_shared<Request>();
+    for (int i = 0; i < 16; ++i) req->pose.m[i] = nerf_pos[i];
+    {
+      std::lock_guard<std::mutex> lk(b.m);
+      b.queue.push_back(req);
+    }
+    b.cv.notify_one();
+    {
+      std::unique_lock<std::mutex> lk(req->m);
+      req->cv.wait(lk, [&] { return req->done; });
+    }
+    if (req->failed || !write_n(sock, req->rgb.data(), frame_bytes)) break;
+  }
+  std::cout << "Connection closed" << std::endl;
+  ::close(sock);
+}
+
+}  // namespace
+
 int main(int argc, char** argv) {
   std::cout << "Hello, Metavese!" << std::endl;
   const int port = argc > 1 ? std::atoi(argv[1]) : 12345;
@@ -49,8 +147,9 @@ int main(int argc, char** argv) {
     NerfRender render;
     render.reload_network_from_file(config_path);  // Init Model
     const float s = (float)W / 1080.0f;
-    Camera cam = {840 * s, 840 * s, 339 * s, 590 * s};
+    const Camera cam = {840 * s, 840 * s, 339 * s, 590 * s};
     render.set_resolution(Vector2i(W, H));
+    const size_t frame_bytes = (size_t)3 * W * H;
 
     const int srv = ::socket(AF_INET, SOCK_STREAM, 0);
     int one = 1;
@@ -59,36 +158,32 @@ int main(int argc, char** argv) {
     addr.sin_family = AF_INET;
     addr.sin_addr.s_addr = htonl(INADDR_ANY);
     addr.sin_port = htons((uint16_t)port);
-    if (srv < 0 || ::bind(srv, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(srv, 4) != 0) {
+    if (srv < 0 || ::bind(srv, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(srv, 64) != 0) {
       std::cerr << "Error creating the acceptor: " << std::strerror(errno) << std::endl;
       return 1;
     }
+    Batcher batcher;
+    std::thread renderer(render_loop, std::ref(render), cam, frame_bytes, std::ref(batcher));
+    std::vector<std::thread> clients;
     std::cout << "Awaiting connections on port " << port << "..." << std::endl;
-    while (true) {
+    while (!batcher.stop.load()) {
       sockaddr_in peer{};
       socklen_t len = sizeof(peer);
       const int sock = ::accept(srv, (sockaddr*)&peer, &len);
       if (sock < 0) {
+        if (batcher.stop.load()) break;
         std::cerr << "Error accepting incoming connection: " << std::strerror(errno) << std::endl;
         continue;
       }
       ::setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      std::cout << "Received a connection request from " << inet_ntoa(peer.sin_addr) << std::endl;
-      float nerf_pos[16] = {0};
-      while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
-        if (std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {  // test hook
-          ::close(sock);
-          ::close(srv);
-          return 0;
-        }
-        Matrix4f pose;
-        for (int i = 0; i < 16; ++i) pose.m[i] = nerf_pos[i];
-        Image img = render.render_frame(cam, pose);
-        if (!write_n(sock, img.rgb, (size_t)3 * W * H)) break;
-      }
-      std::cout << "Connection closed" << std::endl;
-      ::close(sock);
+      clients.emplace_back(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), frame_bytes, std::ref(batcher), srv);
     }
+    batcher.stop = true;
+    batcher.cv.notify_all();
+    renderer.join();
+    for (auto& t : clients)
+      if (t.joinable()) t.detach();  // readers of still-open connections end with the process
+    ::close(srv);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -143,6 +143,7 @@ _SIGS = {
     "nrf_render_views": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
                                    C.POINTER(Frame)]),
     "nrf_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_render_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
     "nrf_sync": (C.c_int, [C.c_void_p]),
@@ -411,6 +412,12 @@ class NerfHip:
         depth = np.empty((self.height, self.width), np.float32)
         _check(self.lib.nrf_read_view_f32(self.h, int(view), rgba.ctypes.data, depth.ctypes.data))
         return rgba, depth
+
+    def read_view_u8(self, view: int):
+        rgb = np.empty((self.height, self.width, 3), np.uint8)
+        depth = np.empty((self.height, self.width), np.uint8)
+        _check(self.lib.nrf_read_view_u8(self.h, int(view), rgb.ctypes.data, depth.ctypes.data))
+        return rgb, depth
 
     def bind_output(self, rgba_ptr, depth_ptr):
         _check(self.lib.nrf_bind_output(self.h, C.c_void_p(rgba_ptr or 0), C.c_void_p(depth_ptr or 0)))

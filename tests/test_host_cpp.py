@@ -136,3 +136,76 @@ def test_render_server_wire_protocol(snapshot):
     finally:
         if srv.poll() is None:
             srv.kill()
+
+
+@pytest.mark.gpu
+def test_render_server_batches_concurrent_clients(snapshot):
+    """BASELINE config 5 shape: several clients connected at once, every one pipelining requests.  The
+    server folds whatever is queued into one nrf_render_views launch; every answer must equal the
+    single-request render of that pose, and fewer launches than frames must have been used."""
+    import threading
+
+    path, desc, keep, cfg = snapshot
+    W, H, port = 96, 64, 23459
+    srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    n_clients, per_client = 6, 5
+    try:
+        socks = []
+        for c in range(n_clients):
+            s = None
+            for _ in range(200):
+                try:
+                    s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                    break
+                except OSError:
+                    time.sleep(0.1)
+            assert s is not None, "server did not come up"
+            s.settimeout(60)
+            socks.append(s)
+        poses = [[syn.orbit_pose(37.0 * (c * per_client + i), -10.0 + 9.0 * i) for i in range(per_client)]
+                 for c in range(n_clients)]
+        got = [[None] * per_client for _ in range(n_clients)]
+        errors = []
+
+        def client(c):
+            try:
+                for i in range(per_client):
+                    socks[c].sendall(np.ascontiguousarray(poses[c][i], np.float32).tobytes())
+                    buf = bytearray()
+                    while len(buf) < 3 * W * H:
+                        chunk = socks[c].recv(3 * W * H - len(buf))
+                        if not chunk:
+                            raise RuntimeError("connection closed early")
+                        buf += chunk
+                    got[c][i] = np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3)
+            except Exception as e:  # noqa: BLE001
+                errors.append((c, repr(e)))
+
+        threads = [threading.Thread(target=client, args=(c,)) for c in range(n_clients)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        ctx = nh.NerfHip(0)
+        ctx.load_model(desc)
+        ctx.set_resolution(W, H)
+        cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
+        for c in range(n_clients):
+            for i in range(per_client):
+                ctx.render(cam, poses[c][i])
+                np.testing.assert_array_equal(got[c][i], ctx.read_u8()[0])
+        ctx.close()
+        quit_msg = np.zeros(16, np.float32)
+        quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
+        socks[0].sendall(quit_msg.tobytes())
+        for s in socks:
+            s.close()
+        out, _ = srv.communicate(timeout=30)
+        line = [ln for ln in out.splitlines() if ln.startswith("batches ")][-1].split()
+        batches, frames = int(line[1]), int(line[3])
+        assert frames == n_clients * per_client and batches < frames, (batches, frames)
+    finally:
+        if srv.poll() is None:
+            srv.kill()
