@@ -103,7 +103,7 @@ int expected_params(const nrf_model_desc& d, const nrf_level_table& t, uint64_t&
 //                  kmap(g,j) = j<4 ? 4g+j : 16+4g+(j-4)    (rgb: [density out | dir enc])
 //   hidden->next   kmap(s,g,j) = 16(2s + (j>>2)) + 4g + (j&3)   (a D fragment re-used in-lane as B)
 void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& frags) {
-  frags.assign((size_t)N_FRAGS * 64 * 8, (_Float16)0.0f);
+  frags.assign((size_t)N_FRAGS_ALL * 64 * 8, (_Float16)0.0f);
   const _Float16* D0 = w16.data();              // [64][32]
   const _Float16* D1 = D0 + 64 * 32;            // [16][64]
   const _Float16* R0 = D1 + 16 * 64;            // [64][32]
@@ -115,6 +115,7 @@ void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& fra
       for (int j = 0; j < 8; ++j) frags[((size_t)f * 64 + l) * 8 + j] = Wm[(size_t)(16 * m + (l & 15)) * in + kmap(l >> 4, j)];
   };
   for (int m = 0; m < 4; ++m) put(FRAG_D0 + m, D0, 32, m, [](int g, int j) { return 2 * (4 * (j >> 1) + g) + (j & 1); });
+  for (int m = 0; m < 4; ++m) put(FRAG_D0_NATURAL + m, D0, 32, m, [](int g, int j) { return 8 * g + j; });
   for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
   for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
   for (int m = 0; m < 4; ++m)

@@ -56,7 +56,10 @@ enum : int {
   FRAG_R0 = 6,   // rgb 32->64     : m = 0..3
   FRAG_R1 = 10,  // rgb 64->64     : (m,s) -> 10 + 2*m + s
   FRAG_R2 = 18,  // rgb 64->16     : s = 0..1
-  N_FRAGS = 20
+  N_FRAGS = 20,       // what render_kernel / network_kernel keep in LDS
+  FRAG_D0_NATURAL = 20,  // density 32->64 again with the natural K order (k = 8g + j): mlp_forward_kernel reads its
+                         // [n][32] input rows as one 16-byte load per lane
+  N_FRAGS_ALL = 24
 };
 
 struct DevModel {
@@ -66,7 +69,7 @@ struct DevModel {
   const float* cell_bound;     // [C][H+1] cell-boundary table (see march_next)
   uint32_t grid_bytes;         // size of the device hash table (< 4 GiB): num_records of its buffer resource
   const uint32_t* occ_dilated;  // coarse cells within one density cell of an occupied density cell; C == 1 only, else nullptr
-  const uint4* wfrag;        // N_FRAGS * 64 uint4
+  const uint4* wfrag;        // N_FRAGS_ALL * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];
   float occ_box[6];  // world-space box around every occupied cell, inflated by 2 cells; min > max when nothing is occupied
@@ -614,7 +617,7 @@ __device__ __forceinline__ half8_t pack_acc(uint32_t act, float4_t lo, float4_t 
 // feat[n]  : B fragment of the density MLP input  (hash features 8g..8g+7 of sample c, tile n)
 // dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
 // out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
-template <int NT, bool GEN>
+template <int NT, bool GEN, int D0_BASE = FRAG_D0>
 __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, int lane, const half8_t (&feat)[NT],
                                           const half4_t (&dirf)[NT], float4_t (&out)[NT]) {
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
@@ -623,7 +626,7 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   // ---- density layer 0: 32 -> 64
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const half8_t a = frag_load(wl, FRAG_D0 + m, lane);
+    const half8_t a = frag_load(wl, D0_BASE + m, lane);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, feat[n], zero);
   }

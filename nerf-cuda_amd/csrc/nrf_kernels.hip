@@ -447,44 +447,62 @@ __global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const
 
 // Both MLPs on pre-encoded inputs: one wave = 64 samples per trip.
 // feat fp16 [n][32], dirfeat fp16 [n][16] -> out fp16 [n][4] = (r, g, b, sigma)
+// HBM-bound (104 B and 20 480 FLOP per sample): every lane reads 16 B of its sample's feature row and 8 B
+// of its direction row (the natural-K-order copy of the first weight matrix makes that the B fragment),
+// a wave reads 1 KiB + 512 B contiguous per 16-sample tile, and the next chunk's rows are in flight
+// while the current one goes through the 80 MFMAs.
+constexpr int LDS_WFRAG_ALL_BYTES = N_FRAGS_ALL * 64 * 16;  // 24576
+constexpr int MLP_TILES = 2;  // 16-sample tiles per trip
 template <bool GEN>
-__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
+__global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
                                                           uint2* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
-  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  for (int i = threadIdx.x; i < N_FRAGS_ALL * 64; i += blockDim.x) wl[i] = M.wfrag[i];
   __syncthreads();
+  constexpr int T = MLP_TILES, CH = 16 * T;
   const int lane = lane_id(), g = lane >> 4, c = lane & 15;
   const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t n_chunks = (n + 63u) >> 6;
-  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
-    const uint32_t base = chunk << 6;
-    half8_t f[4];
-    half4_t df[4];
+  const uint32_t n_chunks = (n + CH - 1) / CH;
+  uint4 fv[T], fnext[T];
+  uint2 dv[T], dnext[T];
+  auto load_chunk = [&](uint32_t chunk, uint4 (&f)[T], uint2 (&d)[T]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t s = base + 16u * t + c;
-      uint4 fv = make_uint4(0u, 0u, 0u, 0u);
-      uint2 dv = make_uint2(0u, 0u);
-      if (s < n) {
-        // element pair jl of the B fragment = level 4*jl + g (the fused kernel's lane mapping)
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(feat) + (size_t)s * 16;
-        fv = make_uint4(row[g], row[4 + g], row[8 + g], row[12 + g]);
-        dv = dirfeat[(size_t)s * 4 + g];  // entries 4g..4g+3
+    for (int t = 0; t < T; ++t) {
+      const uint32_t s = chunk * CH + 16u * t + c;
+      f[t] = make_uint4(0u, 0u, 0u, 0u);
+      d[t] = make_uint2(0u, 0u);
+      if (chunk < n_chunks && s < n) {
+        f[t] = feat[(size_t)s * 4 + g];     // halves 8g..8g+7 of the row
+        d[t] = dirfeat[(size_t)s * 4 + g];  // entries 4g..4g+3
       }
-      f[t] = __builtin_bit_cast(half8_t, fv);
-      df[t] = __builtin_bit_cast(half4_t, dv);
     }
-    float4_t o[4];
-    mlp_tiles<4, GEN>(M, wl, lane, f, df, o);
+  };
+  load_chunk(wave_global, fv, dv);
+  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
+    load_chunk(chunk + n_waves, fnext, dnext);  // in flight during the MFMAs below
+    half8_t f[T];
+    half4_t df[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f[t] = __builtin_bit_cast(half8_t, fv[t]);
+      df[t] = __builtin_bit_cast(half4_t, dv[t]);
+    }
+    float4_t o[T];
+    mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
     if (g == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t s = base + 16u * t + c;
+      for (int t = 0; t < T; ++t) {
+        const uint32_t s = chunk * CH + 16u * t + c;
         if (s < n) out[s] = make_uint2(pack_h2(o[t][0], o[t][1]), pack_h2(o[t][2], o[t][3]));
       }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      fv[t] = fnext[t];
+      dv[t] = dnext[t];
     }
   }
 }
@@ -712,12 +730,12 @@ hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, v
 
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, hipStream_t st) {
   if (!n) return hipSuccess;
-  const uint64_t chunks = ((uint64_t)n + 63) / 64;
+  const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
   if (M.generic_act)
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M,
                        (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
   else
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_WFRAG_BYTES, st, M,
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M,
                        (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
   return hipGetLastError();
 }
