@@ -182,6 +182,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if world > 1:
+        # RCCL sets up its peer-to-peer channels on the first send/recv of every pair: open them now, so that the
+        # timed region never pays for connection set-up whatever --warmup is
+        with torch.cuda.stream(comm):
+            probe = torch.zeros((256,), dtype=torch.int32, device=dev)
+            dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
     for i in range(args.warmup):
         step(i)
     barrier()

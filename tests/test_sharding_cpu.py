@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: two gloo ranks shard one frame by 8x8 tiles exactly as bench.py does
-(tile_id % world == rank), exchange their tile-major shards with ONE all_gather, and rank 0 untiles.
-The GPU kernels are replaced by a per-pixel function, so this covers the host-side partition,
-padding and gather logic (the device untile kernel is checked against the same mapping on the GPU)."""
+"""The N > 1 path on CPU: two gloo ranks shard the frames of a step by strips of four 8x8 tiles exactly
+as bench.py does (strip_id % world == rank), send their tile-major shards of all views of the step --
+4-byte packed pixels, like nrf_quantize_rgbd8's -- with ONE dist.gather to rank 0, and rank 0 untiles.
+The GPU kernels are replaced by a per-pixel function, so this covers the host-side partition, padding
+and gather logic (the device untile kernel is checked against the same mapping on the GPU)."""
 import os
 import socket
 import sys
@@ -33,19 +34,22 @@ def _worker(rank, world, port, W, H, q):
     tps = nh.tiles_per_shard(W, H, world)
     tiles = nh.shard_tile_ids(W, H, rank, world)
     tiles_x = (W + 7) // 8
-    shard = torch.zeros((tps * 64, 4))
-    for k, (tx, ty) in enumerate(tiles):  # "render": pixel value = f(x, y), zeros outside the image
-        for l in range(64):
-            px, py = tx * 8 + (l & 7), ty * 8 + (l >> 3)
-            if px < W and py < H:
-                shard[k * 64 + l] = torch.tensor([px, py, px * 0.5 + py, 1.0])
-    gathered = torch.empty((world, tps * 64, 4))
-    dist.all_gather_into_tensor(gathered.view(-1), shard.view(-1))
+    V = 3  # views per step
+    shard = torch.zeros((V, tps * 64), dtype=torch.int32)
+    for v in range(V):
+        for k, (tx, ty) in enumerate(tiles):  # "render": packed pixel = f(x, y, view), zeros outside the image
+            for l in range(64):
+                px, py = tx * 8 + (l & 7), ty * 8 + (l >> 3)
+                if px < W and py < H:
+                    shard[v, k * 64 + l] = px | (py << 10) | ((v + 1) << 20)
+    gathered = torch.empty((world, V, tps * 64), dtype=torch.int32) if rank == 0 else None
+    dist.gather(shard, [gathered[r] for r in range(world)] if rank == 0 else None, dst=0)
     in_image = [t for t in tiles if t[0] < tiles_x and t[1] < (H + 7) // 8]
     samples = torch.tensor([len(in_image) * 10], dtype=torch.int64)
     dist.all_reduce(samples)
     if rank == 0:
-        q.put((nh.untile_numpy(gathered.numpy(), W, H), int(samples.item())))
+        g = gathered.numpy()
+        q.put((np.stack([nh.untile_numpy(g[:, v, :, None], W, H)[..., 0] for v in range(V)]), int(samples.item())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,9 +69,9 @@ def test_two_rank_tile_sharding_gloo(W, H):
         p.join(timeout=60)
         assert p.exitcode == 0
     ys, xs = np.mgrid[0:H, 0:W]
-    np.testing.assert_array_equal(img[..., 0], xs)
-    np.testing.assert_array_equal(img[..., 1], ys)
-    np.testing.assert_array_equal(img[..., 2], xs * 0.5 + ys)
+    assert img.shape == (3, H, W)
+    for v in range(3):
+        np.testing.assert_array_equal(img[v], xs | (ys << 10) | ((v + 1) << 20))
     total_tiles = ((W + 7) // 8) * ((H + 7) // 8)
     assert samples == total_tiles * 10  # every tile owned by exactly one rank
 
