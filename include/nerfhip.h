@@ -258,6 +258,30 @@ int nrf_untile_views(nrf_context* ctx, const void* gathered, int shard_count,
 int nrf_tiles_per_shard(int width, int height, int shard_count, int* n);
 int nrf_get_stats(nrf_context* ctx, nrf_stats* s);
 
+/* ---- device groups: several GPUs driven by one process ---------------------
+ * The reference's NGPU threads + D2H gather + host de-interleave loop
+ * (nerf_render.cu:252-362, common.h:91) as one object: every member renders
+ * its strips of every view, ships the shard device-to-device to devices[0]
+ * (xGMI peer copies) and devices[0] untiles.  devices == NULL means 0..n-1; a
+ * device may be listed more than once.  The frames of nrf_group_render_views
+ * are row-major float planes on devices[0] (nrf_frame, view_stride_px = W*H),
+ * bit-identical to nrf_render_views on a single context.  The one-process-per-
+ * GPU form (torch.distributed / RCCL gather) is bench.py.                      */
+typedef struct nrf_group nrf_group;
+int nrf_group_create(int n_devices, const int* devices, nrf_group** out);
+int nrf_group_destroy(nrf_group* grp);
+int nrf_group_size(const nrf_group* grp);
+/* member i's context (owned by the group): stage entry points, per-device statistics */
+nrf_context* nrf_group_member(nrf_group* grp, int index);
+int nrf_group_load_model(nrf_group* grp, const nrf_model_desc* d);
+int nrf_group_set_options(nrf_group* grp, const nrf_options* o); /* shard_* are set by the group */
+int nrf_group_set_resolution(nrf_group* grp, int width, int height);
+int nrf_group_render_views(nrf_group* grp, int n_views, const float* cams, const float* poses,
+                           nrf_frame* out);
+int nrf_group_read_view_f32(nrf_group* grp, int view, float* rgba, float* depth);
+int nrf_group_read_view_u8(nrf_group* grp, int view, uint8_t* rgb, uint8_t* depth);
+int nrf_group_get_stats(nrf_group* grp, nrf_stats* s); /* sums; render_ms = slowest member */
+
 /* ---- stage entry points (unit parity against the oracle) -----------------
  * All pointers are DEVICE pointers, n = number of samples / rays.            */
 /* kernel_grid<half,3,2>, grid.h:139-268.  pos01 [n][3] in [0,1];

@@ -1,0 +1,257 @@
+// nrf_group.hip -- several GPUs driven by ONE process behind the C ABI (include/nerfhip.h "device groups").
+//
+// The reference renders on NGPU devices from one process: a std::thread per device, pixel-interleaved
+// shards, a D2H copy of every shard and a single-threaded de-interleave loop on the host
+// (R/src/nerf_render.cu:252-362).  Here every member context renders its strips of every view of the
+// batch on its own stream, copies the tile-major shard device-to-device to the first member (xGMI
+// peer-to-peer: point-to-point links, so the n-1 copies into device 0 run on n-1 different links)
+// and the first member untiles all views in one launch.  No host thread, no host copy, no RCCL
+// (RCCL is the exchange of the one-process-per-GPU form, bench.py).
+// Built only on the public ABI plus HIP peer copies.
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nerfhip.h"
+
+extern "C" void nrf_set_last_error_(const char* msg);
+
+namespace {
+int gfail(int code, const std::string& msg) {
+  nrf_set_last_error_(msg.c_str());
+  return code;
+}
+#define GHIP(expr)                                                                        \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) return gfail(NRF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+#define GTRY(expr)          \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != NRF_OK) return _rc; \
+  } while (0)
+}  // namespace
+
+struct nrf_group {
+  std::vector<int> devices;
+  std::vector<nrf_context*> ctx;
+  std::vector<hipStream_t> stream;  // one per member, on its device
+  std::vector<hipEvent_t> done;     // shard of member i has arrived on devices[0]
+  nrf_options opt{};
+  int W = 0, H = 0, tps = 0, max_views = 0, last_views = 0;
+  void* gathered_rgba = nullptr;  // on devices[0]: [member][view][tps*64][4] f32
+  void* gathered_depth = nullptr; //                [member][view][tps*64]    f32
+  void* frame_rgba = nullptr;     // on devices[0]: [view][H][W][4]
+  void* frame_depth = nullptr;    //                [view][H][W]
+  void* packed = nullptr;         // readback scratch: [H][W] u32
+};
+
+namespace {
+void free_buffers(nrf_group* g) {
+  if (g->devices.empty()) return;
+  (void)hipSetDevice(g->devices[0]);
+  for (void** p : {&g->gathered_rgba, &g->gathered_depth, &g->frame_rgba, &g->frame_depth, &g->packed}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+}
+
+int ensure_buffers(nrf_group* g, int n_views) {
+  if (n_views <= g->max_views && (g->frame_rgba || g->ctx.size() == 1)) return NRF_OK;
+  const size_t n = g->ctx.size();
+  for (nrf_context* c : g->ctx) GTRY(nrf_set_max_views(c, n_views));
+  g->max_views = n_views;
+  if (n == 1) return NRF_OK;  // a single member renders row-major frames itself
+  free_buffers(g);
+  GHIP(hipSetDevice(g->devices[0]));
+  const size_t shard_px = (size_t)g->tps * 64, frame_px = (size_t)g->W * g->H;
+  GHIP(hipMalloc(&g->gathered_rgba, n * n_views * shard_px * 16));
+  GHIP(hipMalloc(&g->gathered_depth, n * n_views * shard_px * 4));
+  GHIP(hipMalloc(&g->frame_rgba, (size_t)n_views * frame_px * 16));
+  GHIP(hipMalloc(&g->frame_depth, (size_t)n_views * frame_px * 4));
+  GHIP(hipMalloc(&g->packed, frame_px * 4));
+  return NRF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nrf_group_create(int n_devices, const int* devices, nrf_group** out) {
+  if (!out || n_devices < 1) return gfail(NRF_E_INVALID, "nrf_group_create: bad argument");
+  nrf_group* g = new nrf_group;
+  nrf_default_options(&g->opt);
+  for (int i = 0; i < n_devices; ++i) g->devices.push_back(devices ? devices[i] : i);
+  for (int i = 0; i < n_devices; ++i) {
+    nrf_context* c = nullptr;
+    const int rc = nrf_create(g->devices[i], &c);
+    if (rc != NRF_OK) {
+      nrf_group_destroy(g);
+      return rc;
+    }
+    g->ctx.push_back(c);
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    if (hipSetDevice(g->devices[i]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      nrf_group_destroy(g);
+      return gfail(NRF_E_HIP, "nrf_group_create: stream / event creation failed");
+    }
+    g->stream.push_back(s);
+    g->done.push_back(e);
+    // peer access from the first device to this one (and back): without it the copies are staged through the host
+    if (g->devices[i] != g->devices[0]) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, g->devices[i], g->devices[0]) == hipSuccess && can) {
+        (void)hipDeviceEnablePeerAccess(g->devices[0], 0);  // current device is devices[i]
+        (void)hipGetLastError();                            // "already enabled" is fine
+      }
+    }
+  }
+  *out = g;
+  return NRF_OK;
+}
+
+int nrf_group_destroy(nrf_group* g) {
+  if (!g) return NRF_OK;
+  for (size_t i = 0; i < g->ctx.size(); ++i) {
+    (void)hipSetDevice(g->devices[i]);
+    (void)hipDeviceSynchronize();
+  }
+  free_buffers(g);
+  for (size_t i = 0; i < g->stream.size(); ++i) {
+    (void)hipSetDevice(g->devices[i]);
+    if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+    if (g->stream[i]) (void)hipStreamDestroy(g->stream[i]);
+  }
+  for (nrf_context* c : g->ctx) (void)nrf_destroy(c);
+  delete g;
+  return NRF_OK;
+}
+
+int nrf_group_size(const nrf_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+nrf_context* nrf_group_member(nrf_group* g, int index) {
+  return (g && index >= 0 && index < (int)g->ctx.size()) ? g->ctx[index] : nullptr;
+}
+
+int nrf_group_load_model(nrf_group* g, const nrf_model_desc* d) {
+  if (!g || !d) return gfail(NRF_E_INVALID, "null argument");
+  for (nrf_context* c : g->ctx) GTRY(nrf_load_model(c, d));  // replicated: 24 MB table + occupancy per device
+  return NRF_OK;
+}
+
+int nrf_group_set_options(nrf_group* g, const nrf_options* o) {
+  if (!g || !o) return gfail(NRF_E_INVALID, "null argument");
+  g->opt = *o;
+  for (size_t i = 0; i < g->ctx.size(); ++i) {
+    nrf_options m = *o;
+    m.shard_index = (int)i;  // the partition is the group's business
+    m.shard_count = (int)g->ctx.size();
+    GTRY(nrf_set_options(g->ctx[i], &m));
+  }
+  return NRF_OK;
+}
+
+int nrf_group_set_resolution(nrf_group* g, int width, int height) {
+  if (!g || width <= 0 || height <= 0) return gfail(NRF_E_INVALID, "bad resolution");
+  GTRY(nrf_group_set_options(g, &g->opt));
+  for (nrf_context* c : g->ctx) GTRY(nrf_set_resolution(c, width, height));
+  g->W = width;
+  g->H = height;
+  GTRY(nrf_tiles_per_shard(width, height, (int)g->ctx.size(), &g->tps));
+  free_buffers(g);
+  g->max_views = 0;
+  return ensure_buffers(g, 1);
+}
+
+int nrf_group_render_views(nrf_group* g, int n_views, const float* cams, const float* poses, nrf_frame* out) {
+  if (!g || !cams || !poses || n_views < 1) return gfail(NRF_E_INVALID, "bad argument");
+  if (g->W <= 0) return gfail(NRF_E_STATE, "nrf_group_set_resolution has not been called");
+  GTRY(ensure_buffers(g, n_views));
+  const size_t n = g->ctx.size();
+  g->last_views = n_views;
+  if (n == 1) {
+    GTRY(nrf_render_views(g->ctx[0], n_views, cams, poses, (void*)g->stream[0], out));
+    GHIP(hipStreamSynchronize(g->stream[0]));
+    return NRF_OK;
+  }
+  const size_t shard_px = (size_t)g->tps * 64;
+  for (size_t i = 0; i < n; ++i) {  // every device renders and ships its shards on its own stream
+    nrf_frame f;
+    GTRY(nrf_render_views(g->ctx[i], n_views, cams, poses, (void*)g->stream[i], &f));
+    GHIP(hipSetDevice(g->devices[i]));
+    char* dst_rgba = (char*)g->gathered_rgba + i * n_views * shard_px * 16;
+    char* dst_depth = (char*)g->gathered_depth + i * n_views * shard_px * 4;
+    GHIP(hipMemcpyPeerAsync(dst_rgba, g->devices[0], f.rgba, g->devices[i], (size_t)n_views * shard_px * 16, g->stream[i]));
+    GHIP(hipMemcpyPeerAsync(dst_depth, g->devices[0], f.depth, g->devices[i], (size_t)n_views * shard_px * 4, g->stream[i]));
+    GHIP(hipEventRecord(g->done[i], g->stream[i]));
+  }
+  GHIP(hipSetDevice(g->devices[0]));
+  for (size_t i = 1; i < n; ++i) GHIP(hipStreamWaitEvent(g->stream[0], g->done[i], 0));
+  GTRY(nrf_untile_views(g->ctx[0], g->gathered_rgba, (int)n, g->tps, 4, n_views, g->frame_rgba, (void*)g->stream[0]));
+  GTRY(nrf_untile_views(g->ctx[0], g->gathered_depth, (int)n, g->tps, 1, n_views, g->frame_depth, (void*)g->stream[0]));
+  GHIP(hipStreamSynchronize(g->stream[0]));
+  if (out) {
+    out->width = g->W;
+    out->height = g->H;
+    out->n_tiles = ((g->W + 7) / 8) * ((g->H + 7) / 8);
+    out->rgba = g->frame_rgba;
+    out->depth = g->frame_depth;
+    out->tile_major = 0;
+    out->n_views = n_views;
+    out->view_stride_px = (int64_t)g->W * g->H;
+  }
+  return NRF_OK;
+}
+
+int nrf_group_read_view_f32(nrf_group* g, int view, float* rgba, float* depth) {
+  if (!g || view < 0 || view >= g->last_views) return gfail(NRF_E_INVALID, "view index out of range");
+  if (g->ctx.size() == 1) return nrf_read_view_f32(g->ctx[0], view, rgba, depth);
+  const size_t px = (size_t)g->W * g->H;
+  GHIP(hipSetDevice(g->devices[0]));
+  if (rgba) GHIP(hipMemcpy(rgba, (const char*)g->frame_rgba + (size_t)view * px * 16, px * 16, hipMemcpyDeviceToHost));
+  if (depth) GHIP(hipMemcpy(depth, (const char*)g->frame_depth + (size_t)view * px * 4, px * 4, hipMemcpyDeviceToHost));
+  return NRF_OK;
+}
+
+int nrf_group_read_view_u8(nrf_group* g, int view, uint8_t* rgb, uint8_t* depth) {
+  if (!g || view < 0 || view >= g->last_views) return gfail(NRF_E_INVALID, "view index out of range");
+  if (g->ctx.size() == 1) return nrf_read_view_u8(g->ctx[0], view, rgb, depth);
+  const size_t px = (size_t)g->W * g->H;
+  GHIP(hipSetDevice(g->devices[0]));
+  GTRY(nrf_quantize_rgbd8(g->ctx[0], (const char*)g->frame_rgba + (size_t)view * px * 16,
+                          (const char*)g->frame_depth + (size_t)view * px * 4, px, g->packed, (void*)g->stream[0]));
+  GHIP(hipStreamSynchronize(g->stream[0]));
+  std::vector<uint32_t> host(px);
+  GHIP(hipMemcpy(host.data(), g->packed, px * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < px; ++i) {
+    const uint32_t v = host[i];
+    if (rgb) {
+      rgb[3 * i] = (uint8_t)(v & 0xffu);
+      rgb[3 * i + 1] = (uint8_t)((v >> 8) & 0xffu);
+      rgb[3 * i + 2] = (uint8_t)((v >> 16) & 0xffu);
+    }
+    if (depth) depth[i] = (uint8_t)(v >> 24);
+  }
+  return NRF_OK;
+}
+
+int nrf_group_get_stats(nrf_group* g, nrf_stats* s) {
+  if (!g || !s) return gfail(NRF_E_INVALID, "null argument");
+  std::memset(s, 0, sizeof(*s));
+  for (nrf_context* c : g->ctx) {
+    nrf_stats m;
+    GTRY(nrf_get_stats(c, &m));
+    s->n_rays += m.n_rays;
+    s->n_samples += m.n_samples;
+    s->n_rounds += m.n_rounds;
+    if (m.render_ms > s->render_ms) s->render_ms = m.render_ms;  // members run concurrently
+  }
+  return NRF_OK;
+}
+
+}  // extern "C"

@@ -42,13 +42,6 @@ uint32_t activation(const mpk::Value& block, const char* key, const char* dflt) 
   if (s == "sine") return NRF_ACT_SINE;
   throw std::runtime_error{"Invalid activation name: " + s};
 }
-unsigned char quant(float v) {  // nerf_render.cu:355-358, saturating (deviation D-2)
-  const double s = 255.0 * (double)v;
-  if (!(s > 0.0)) return 0;
-  if (s >= 255.0) return 255;
-  return (unsigned char)s;
-}
-
 }  // namespace
 
 void NerfRender::check(int rc, const char* what) const {
@@ -61,15 +54,24 @@ NerfRender::NerfRender(int n_gpus) {
     const char* e = std::getenv("NERF_NGPU");
     n_gpus = e ? std::max(1, std::atoi(e)) : 1;
   }
-  for (int gpu = 0; gpu < n_gpus; ++gpu) {  // nerf_render.cu:49-56: one stream / state per device
-    nrf_context* c = nullptr;
-    check(nrf_create(gpu, &c), "nrf_create");
-    m_ctx.push_back(c);
+  std::vector<int> devices;
+  if (const char* list = std::getenv("NERF_DEVICES")) {  // e.g. "0,0" rehearses two members on one device
+    for (const char* p = list; *p;) {
+      devices.push_back(std::atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
   }
+  if ((int)devices.size() != n_gpus) {
+    devices.clear();
+    for (int gpu = 0; gpu < n_gpus; ++gpu) devices.push_back(gpu);  // nerf_render.cu:49-56: one stream / state per device
+  }
+  check(nrf_group_create(n_gpus, devices.data(), &m_group), "nrf_group_create");
+  for (int i = 0; i < n_gpus; ++i) m_ctx.push_back(nrf_group_member(m_group, i));
 }
 
 NerfRender::~NerfRender() {
-  for (nrf_context* c : m_ctx) nrf_destroy(c);
+  if (m_group) nrf_group_destroy(m_group);
 }
 
 mpk::Value NerfRender::load_network_config(const std::string& network_config_path) {
@@ -96,7 +98,7 @@ void NerfRender::reload_network_from_file(const std::string& network_config_path
     load_snapshot(network_config_path);
     reset_network();
     // NerfNetwork::deserialize (nerf_network.h:424-443): size check + fp32 -> fp16 + upload
-    for (nrf_context* c : m_ctx) check(nrf_load_model(c, &m_desc), "Can't set params");
+    if (m_group) check(nrf_group_load_model(m_group, &m_desc), "Can't set params");
   } else {
     throw std::runtime_error{"Input file with wrong extension!"};
   }
@@ -210,55 +212,19 @@ void NerfRender::reset_network() {
 
 void NerfRender::set_resolution(Vector2i res) {
   resolution = res;
-  const int n = (int)m_ctx.size();
-  for (int gpu = 0; gpu < n; ++gpu) {
-    nrf_options o;
-    nrf_default_options(&o);
-    o.shard_index = gpu;
-    o.shard_count = n;
-    check(nrf_set_options(m_ctx[gpu], &o), "nrf_set_options");
-    check(nrf_set_resolution(m_ctx[gpu], res[0], res[1]), "nrf_set_resolution");
-  }
-  check(nrf_tiles_per_shard(res[0], res[1], n, &m_tiles_per_shard), "nrf_tiles_per_shard");
+  if (m_group) check(nrf_group_set_resolution(m_group, res[0], res[1]), "nrf_group_set_resolution");
   us_image.assign((size_t)res[0] * res[1] * 3, 0);  // nerf_render.cu:232-235
   us_depth.assign((size_t)res[0] * res[1], 0);
-  if (n > 1) {
-    m_shard_rgba.assign((size_t)m_tiles_per_shard * 64 * 4, 0.f);
-    m_shard_depth.assign((size_t)m_tiles_per_shard * 64, 0.f);
-  }
 }
 
 Image NerfRender::render_frame(Camera cam, Matrix4f pos) {
   if (!m_have_network) throw std::runtime_error{"render_frame: no network loaded"};
   const float c4[4] = {cam.fl_x, cam.fl_y, cam.cx, cam.cy};
-  const int W = resolution[0], H = resolution[1], n = (int)m_ctx.size();
-  if (n == 1) {
-    check(nrf_render(m_ctx[0], c4, pos.m, nullptr, nullptr), "nrf_render");
-    check(nrf_read_u8(m_ctx[0], us_image.data(), us_depth.data()), "nrf_read_u8");
-    return Image(W, H, us_image.data(), us_depth.data());
-  }
-  // every device renders its tiles concurrently on its own stream; the host gathers the shards
-  // (the reference's D2H + de-interleave loop, nerf_render.cu:345-359)
-  std::vector<nrf_frame> frames(n);
-  for (int gpu = 0; gpu < n; ++gpu) check(nrf_render_async(m_ctx[gpu], c4, pos.m, &frames[gpu]), "nrf_render_async");
-  for (int gpu = 0; gpu < n; ++gpu) check(nrf_sync(m_ctx[gpu]), "nrf_sync");
-  const int strips_x = ((W + 7) / 8 + 3) / 4;
-  for (int gpu = 0; gpu < n; ++gpu) {
-    check(nrf_read_shard_f32(m_ctx[gpu], m_shard_rgba.data(), m_shard_depth.data()), "nrf_read_shard_f32");
-    for (int k = 0; k < frames[gpu].n_tiles; ++k) {
-      const int strip = (k / 4) * n + gpu, tx = (strip % strips_x) * 4 + k % 4, ty = strip / strips_x;
-      for (int l = 0; l < 64; ++l) {
-        const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
-        if (px >= W || py >= H) continue;
-        const size_t src = (size_t)k * 64 + l, dst = (size_t)py * W + px;
-        us_image[dst * 3 + 0] = quant(m_shard_rgba[src * 4 + 0]);
-        us_image[dst * 3 + 1] = quant(m_shard_rgba[src * 4 + 1]);
-        us_image[dst * 3 + 2] = quant(m_shard_rgba[src * 4 + 2]);
-        us_depth[dst] = quant(m_shard_depth[src]);
-      }
-    }
-  }
-  return Image(W, H, us_image.data(), us_depth.data());
+  // every member renders its strips concurrently on its own stream; the shards meet on the first device
+  // (the reference's threads + D2H + de-interleave loop, nerf_render.cu:252-362)
+  check(nrf_group_render_views(m_group, 1, c4, pos.m, nullptr), "nrf_group_render_views");
+  check(nrf_group_read_view_u8(m_group, 0, us_image.data(), us_depth.data()), "nrf_group_read_view_u8");
+  return Image(resolution[0], resolution[1], us_image.data(), us_depth.data());
 }
 
 std::vector<Image> NerfRender::render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses) {
@@ -269,26 +235,17 @@ std::vector<Image> NerfRender::render_frames(const std::vector<Camera>& cams, co
   m_batch_image.resize(px * 3 * (size_t)n);
   m_batch_depth.resize(px * (size_t)n);
   std::vector<Image> out;
-  if (m_ctx.size() != 1) {  // sharded instances: one frame at a time (the host gathers every frame's shards)
-    for (int v = 0; v < n; ++v) {
-      const Image img = render_frame(cams[v], poses[v]);
-      std::memcpy(m_batch_image.data() + px * 3 * v, img.rgb, px * 3);
-      std::memcpy(m_batch_depth.data() + px * v, img.depth, px);
-    }
-  } else if (n > 0) {
-    if (n > m_max_views) {
-      check(nrf_set_max_views(m_ctx[0], n), "nrf_set_max_views");
-      m_max_views = n;
-    }
+  if (n > 0) {
     std::vector<float> c4((size_t)4 * n), p16((size_t)16 * n);
     for (int v = 0; v < n; ++v) {
       const float c[4] = {cams[v].fl_x, cams[v].fl_y, cams[v].cx, cams[v].cy};
       std::memcpy(&c4[4 * (size_t)v], c, sizeof(c));
       std::memcpy(&p16[16 * (size_t)v], poses[v].m, sizeof(poses[v].m));
     }
-    check(nrf_render_views(m_ctx[0], n, c4.data(), p16.data(), nullptr, nullptr), "nrf_render_views");
+    check(nrf_group_render_views(m_group, n, c4.data(), p16.data(), nullptr), "nrf_group_render_views");
     for (int v = 0; v < n; ++v)
-      check(nrf_read_view_u8(m_ctx[0], v, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v), "nrf_read_view_u8");
+      check(nrf_group_read_view_u8(m_group, v, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v),
+            "nrf_group_read_view_u8");
   }
   for (int v = 0; v < n; ++v) out.emplace_back(W, H, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v);
   return out;

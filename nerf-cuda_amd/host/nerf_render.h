@@ -43,8 +43,10 @@ struct Matrix4f {  // row-major 4x4, camera-to-world in the NeRF/Blender convent
 class NerfRender {
  public:
   // The reference fixes the device count with the NGPU macro (common.h:91); here it is a
-  // constructor argument (or the NERF_NGPU environment variable).  Device i renders the 8x8
-  // tiles with tile_id % n == i; the shards are gathered on the host like nerf_render.cu:345-359.
+  // constructor argument (or the NERF_NGPU environment variable; NERF_DEVICES="0,1,..." names the
+  // devices, repeats allowed).  The devices form an nrf_group: member i renders the tile strips with
+  // strip_id % n == i, the shards travel device-to-device to the first member, which untiles
+  // (the reference: one thread per device, D2H copies, host de-interleave, nerf_render.cu:252-362).
   // n_gpus < 0: host-only instance that can load and inspect snapshots but not render.
   explicit NerfRender(int n_gpus = 0);
   ~NerfRender();
@@ -73,7 +75,8 @@ class NerfRender {
 
  private:
   void check(int rc, const char* what) const;
-  std::vector<nrf_context*> m_ctx;
+  nrf_group* m_group = nullptr;
+  std::vector<nrf_context*> m_ctx;  // the group's members (owned by the group)
   mpk::Value m_network_config;
   std::string m_network_config_path;
   nrf_model_desc m_desc{};
@@ -82,9 +85,7 @@ class NerfRender {
   Vector2i resolution;
   std::vector<unsigned char> us_image, us_depth;
   std::vector<unsigned char> m_batch_image, m_batch_depth;  // render_frames
-  int m_max_views = 1;
-  std::vector<float> m_shard_rgba, m_shard_depth, m_rays_o, m_rays_d;
-  int m_tiles_per_shard = 0;
+  std::vector<float> m_rays_o, m_rays_d;
 };
 
 }  // namespace ngp

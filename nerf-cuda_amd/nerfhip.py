@@ -154,6 +154,17 @@ _SIGS = {
     "nrf_read_shard_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_quantize_rgbd8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "nrf_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "nrf_group_destroy": (C.c_int, [C.c_void_p]),
+    "nrf_group_size": (C.c_int, [C.c_void_p]),
+    "nrf_group_member": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "nrf_group_load_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
+    "nrf_group_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "nrf_group_set_resolution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nrf_group_render_views": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
+    "nrf_group_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_group_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "nrf_untile_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -484,6 +495,63 @@ class NerfHip:
 
 CS_LINEAR, CS_SRGB, CS_VISPOSNEG = 0, 1, 2
 TM_IDENTITY, TM_ACES, TM_HABLE, TM_REINHARD = 0, 1, 2, 3
+
+
+class NerfGroup:
+    """nrf_group: several devices driven by this process (the reference's NGPU, common.h:91)."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(self.lib.nrf_group_create(len(devices), devs, C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+
+    def close(self):
+        if self.h:
+            self.lib.nrf_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def load_model(self, desc):
+        _check(self.lib.nrf_group_load_model(self.h, C.byref(desc)))
+
+    def set_options(self, opts):
+        _check(self.lib.nrf_group_set_options(self.h, C.byref(opts)))
+
+    def set_resolution(self, width, height):
+        _check(self.lib.nrf_group_set_resolution(self.h, width, height))
+        self.width, self.height = width, height
+
+    def render_views(self, cams, poses) -> Frame:
+        cams = np.ascontiguousarray(cams, dtype=np.float32).reshape(-1, 4)
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+        f = Frame()
+        _check(self.lib.nrf_group_render_views(self.h, len(cams), _fptr(cams), _fptr(poses), C.byref(f)))
+        return f
+
+    def read_view_f32(self, view):
+        rgba = np.empty((self.height, self.width, 4), np.float32)
+        depth = np.empty((self.height, self.width), np.float32)
+        _check(self.lib.nrf_group_read_view_f32(self.h, int(view), rgba.ctypes.data, depth.ctypes.data))
+        return rgba, depth
+
+    def read_view_u8(self, view):
+        rgb = np.empty((self.height, self.width, 3), np.uint8)
+        depth = np.empty((self.height, self.width), np.uint8)
+        _check(self.lib.nrf_group_read_view_u8(self.h, int(view), rgb.ctypes.data, depth.ctypes.data))
+        return rgb, depth
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(self.lib.nrf_group_get_stats(self.h, C.byref(s)))
+        return s
 
 
 class RenderBuffer:

@@ -95,6 +95,15 @@ def test_testbed_matches_python_binding(tmp_path, snapshot):
     np.testing.assert_array_equal(got, rgb8)
     assert rgb8.min() < 250  # the object is in view
     ctx.close()
+    # the NGPU form of the class (nrf_group underneath): three members, all on the one device of this box
+    import os
+    out3 = tmp_path / "n3"
+    out3.mkdir()
+    env = dict(os.environ, NERF_NGPU="3", NERF_DEVICES="0,0,0")
+    r = subprocess.run([str(HOST / "testbed"), str(path), str(W), str(H), str(out3) + "/"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    np.testing.assert_array_equal(np.fromfile(out3 / "image.rgb", np.uint8).reshape(H, W, 3), rgb8)
 
 
 @pytest.mark.gpu

@@ -535,3 +535,38 @@ def test_quantize_rgbd8_matches_reference_packing(ctx):
     sync()
     ctx.quantize_rgbd8(r_d.data_ptr(), d_d.data_ptr(), n, out.data_ptr())
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), want)
+
+
+def test_device_group_equals_single_context(ctx):
+    """nrf_group_*: the one-process multi-device form (the reference's NGPU).  Two and three members --
+    all on device 0, the only one this box has -- render their strips, ship them device-to-device and
+    untile; frames, u8 images and sample counts must equal a single context's, bit for bit."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    W, H = 328, 200  # ragged strips (41 tiles per row) and rows (25 tile rows)
+    n = 5
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    poses = np.stack([syn.orbit_pose(50.0 * i, 20.0) for i in range(n)])
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    ctx.set_max_views(n)
+    ctx.render_views(cams, poses)
+    want = [ctx.read_view_f32(i) for i in range(n)]
+    want_u8 = [ctx.read_view_u8(i) for i in range(n)]
+    want_samples = ctx.stats().n_samples
+    ctx.set_max_views(1)
+    for members in (1, 2, 3):
+        g = nh.NerfGroup([0] * members)
+        g.load_model(desc)
+        g.set_resolution(W, H)
+        f = g.render_views(cams, poses)
+        assert f.n_views == n and f.tile_major == 0 and f.view_stride_px == W * H
+        assert g.stats().n_samples == want_samples
+        for i in range(n):
+            rgba, depth = g.read_view_f32(i)
+            np.testing.assert_array_equal(rgba, want[i][0])
+            np.testing.assert_array_equal(depth, want[i][1])
+            rgb8, d8 = g.read_view_u8(i)
+            np.testing.assert_array_equal(rgb8, want_u8[i][0])
+            np.testing.assert_array_equal(d8, want_u8[i][1])
+        g.close()
