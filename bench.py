@@ -22,6 +22,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 kernel's mean duration measured with HIP events on its stream.
   cpu_baseline  the CPU oracle (a port, not the reference binary: the reference
                 is CUDA-only) timed on this host on a bounded sample.
+  parity        the metric's image-quality leg: PSNR / max |d| of the HIP frame
+                against the oracle's frame of that sample.
 """
 from __future__ import annotations
 
@@ -317,7 +319,7 @@ def main():
         with torch.cuda.stream(stream):
             out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, cam, poses[0], W, H, args.cpu_sample_div)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(nh, dev, desc, cam, poses[0], W, H, args.cpu_sample_div)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -349,8 +351,9 @@ def mlp_microbench(ctx, torch, dev):
             "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "hbm_gbs": round(gbs, 1)}
 
 
-def cpu_baseline(desc, cam, pose, W, H, div):
-    """The CPU oracle on this host's cores, on a (W/div)x(H/div) frame of the same view."""
+def cpu_baseline(nh, dev, desc, cam, pose, W, H, div):
+    """The CPU oracle on this host's cores, on a (W/div)x(H/div) frame of the same view -- and, since the oracle's
+    frame is there anyway, the image-quality leg of the metric: PSNR / max |d| of the HIP frame against it."""
     import oracle_py as op
 
     w, h = max(8, W // div), max(8, H // div)
@@ -358,11 +361,23 @@ def cpu_baseline(desc, cam, pose, W, H, div):
     o = op.Oracle(desc)
     threads = op.lib().nrfo_max_threads()
     t0 = time.perf_counter()
-    _, _, st = o.render(c, pose, w, h, schedule=op.SCHED_REFERENCE)
+    want, want_depth, st = o.render(c, pose, w, h, schedule=op.SCHED_REFERENCE)
     dt = time.perf_counter() - t0
-    return {"value": round(st.n_samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
+    base = {"value": round(st.n_samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": int(threads), "kind": "port",
             "sample": f"one {w}x{h} frame of the same camera ({st.n_samples} samples, {dt:.1f} s), reference schedule",
             "frames_per_s_1080p_equiv": round(1.0 / (dt * div * div), 5)}
+    g = nh.NerfHip(dev.index)
+    g.load_model(desc)
+    g.set_resolution(w, h)
+    g.render(c, pose)
+    got, got_depth = g.read_f32()
+    g.close()
+    mse = float(np.mean((got.astype(np.float64) - want.astype(np.float64)) ** 2))
+    parity = {"against": f"CPU oracle (port of the reference path), same {w}x{h} frame, float RGBA",
+              "psnr_db": round(99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse), 2),
+              "max_abs": float(np.abs(got - want).max()), "max_abs_depth": float(np.abs(got_depth - want_depth).max()),
+              "tolerance": "max_abs <= 2/255 and PSNR >= 45 dB (tests/test_parity_gpu.py)"}
+    return base, parity
 
 
 if __name__ == "__main__":
