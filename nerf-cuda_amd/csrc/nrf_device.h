@@ -210,11 +210,13 @@ __device__ __forceinline__ void box_interval(const float* box, const float o[3],
 // f.  The DDA visits the coarse cell containing that point or, when the point sits within fp error
 // of a coarse boundary, its neighbour across that boundary -- which is then within one density
 // cell of f.  Either way the visited cell's bit is set.  So: no set bit on the way -> the ray
-// cannot produce a sample; otherwise no sample exists beyond the exit of the last set cell.  Returns false when the ray is sample-free; t_last is
-// the exit parameter of the last dilated cell otherwise.
+// cannot produce a sample; otherwise no sample exists beyond the exit of the last set cell.  Returns false when the ray
+// is sample-free; otherwise t_last is the exit parameter of the last set cell and t_first the entry parameter of
+// the first one: a march trip at t < t_first tests a density cell that is certainly empty (same argument), so
+// march_next skips the occupancy lookups there (the hop arithmetic of the trip is unchanged).
 __device__ __forceinline__ bool coarse_visibility(const uint32_t* __restrict__ dil, int Hc, float mip_bound, const float o[3],
                                                   const float d[3], float rdx, float rdy, float rdz, float t0, float t1,
-                                                  float& t_last) {
+                                                  float& t_first, float& t_last) {
   const float cs = 2.0f * mip_bound / (float)Hc, rcs = (float)Hc / (2.0f * mip_bound);
   const float rd[3] = {rdx, rdy, rdz};
   int i[3], step[3];
@@ -234,10 +236,12 @@ __device__ __forceinline__ bool coarse_visibility(const uint32_t* __restrict__ d
   bool any = false;
   float t = t0;
   t_last = t0;
+  t_first = t0;
   for (int guard = 0; guard < 3 * Hc + 3; ++guard) {
     const uint32_t cc = ((uint32_t)i[0] * Hc + (uint32_t)i[1]) * Hc + (uint32_t)i[2];
     const float t_exit = fminf(tmax[0], fminf(tmax[1], tmax[2]));
     if ((dil[cc >> 5] >> (cc & 31u)) & 1u) {
+      if (!any) t_first = t;  // entry of the first cell that can hold a sample
       any = true;
       t_last = t_exit;
     }
@@ -249,7 +253,6 @@ __device__ __forceinline__ bool coarse_visibility(const uint32_t* __restrict__ d
     if (tmax[2] <= t_exit) { i[2] += step[2]; tmax[2] += tdelta[2]; }
     if ((unsigned)i[0] >= (unsigned)Hc || (unsigned)i[1] >= (unsigned)Hc || (unsigned)i[2] >= (unsigned)Hc) break;
   }
-  (void)t;
   return any;
 }
 
@@ -308,8 +311,8 @@ __device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __
 template <bool COARSE, bool UNIT>
 __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* __restrict__ occ, const uint32_t* coarse,
                                           const float* ctab, float ox, float oy, float oz, float dx, float dy, float dz,
-                                          float rdx, float rdy, float rdz, int sx, int sy, int sz, float far, int& budget,
-                                          float& t, float& x, float& y, float& z, float& dt_out) {
+                                          float rdx, float rdy, float rdz, int sx, int sy, int sz, float far, float t_skip,
+                                          int& budget, float& t, float& x, float& y, float& z, float& dt_out) {
   while (t < far) {
     if (budget <= 0) return MARCH_OUT_OF_BUDGET;
     --budget;
@@ -345,16 +348,17 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
                                : (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
     const float* tab = UNIT ? ctab : ctab + (uint32_t)level * (c.H + 1);
     const float bx = tab[nx + sx], by = tab[ny + sy], bz = tab[nz + sz];
-    bool occupied;
-    if (COARSE) {
-      const uint32_t lc = c.log2H - 2u;
-      const uint32_t cc = UNIT ? (((((uint32_t)nx >> 2) << lc) | ((uint32_t)ny >> 2)) << lc) | ((uint32_t)nz >> 2)
-                               : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
-      const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
-      occupied = coarse_occ;
-      if (coarse_occ) occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
-    } else {
-      occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+    bool occupied = false;
+    if (!(t < t_skip)) {  // before t_skip the cell is known to be empty (coarse_visibility)
+      if (COARSE) {
+        const uint32_t lc = c.log2H - 2u;
+        const uint32_t cc = UNIT ? (((((uint32_t)nx >> 2) << lc) | ((uint32_t)ny >> 2)) << lc) | ((uint32_t)nz >> 2)
+                                 : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
+        const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
+        if (coarse_occ) occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+      } else {
+        occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
+      }
     }
     if (occupied) {
       dt_out = clamp3(t * c.dt_gamma, c.dt_min, c.dt_max);

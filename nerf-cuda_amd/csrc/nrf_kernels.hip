@@ -240,6 +240,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // No sample can lie outside the (inflated) box of occupied cells: rays that miss it are done,
   // the others stop marching where they leave it.  NaN-safe: a 0*inf in the slab test fails `<`.
   float far_m = far;
+  float t_skip = near;  // march trips before t_skip test a cell that is known to be empty; near: no such trip
   {
     float t_in, t_out;
     box_interval(M.occ_box, o, rdx, rdy, rdz, t_in, t_out);
@@ -250,14 +251,15 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     alive = alive && (hits || nan);
     // finer, still exact: walk the dilated coarse occupancy between the box entry and exit
     if (M.occ_dilated != nullptr && alive && !nan) {
-      float t_last;
+      float t_last, t_first;
       const float t0 = fmaxf(t_in, near);
       const int Hc = (int)(M.H >> 2);
       const float mb = fminf(1.0f, M.bound);
-      const bool vis = use_dil_lds ? coarse_visibility(dil_lds, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_last)
-                                   : coarse_visibility(M.occ_dilated, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_last);
+      const bool vis = use_dil_lds ? coarse_visibility(dil_lds, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_first, t_last)
+                                   : coarse_visibility(M.occ_dilated, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_first, t_last);
       alive = vis;
       if (t_last < far_m) far_m = t_last;
+      if (vis) t_skip = t_first;
     }
   }
   // ---- the weight fragments replace the dilated bitfield -- unless no ray of the four tiles can sample
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 #endif
       if (marching) {
         const int r = COARSE_LDS ? march_next<true, UNIT>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                    rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt)
+                                                    rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt)
                                  : march_next<false, false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                     rdy, rdz, sx, sy, sz, far_m, budget, t, x, y, z, dt);
+                                                     rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt);
         found = r == MARCH_FOUND;
         marching = found;
         ended = ended || r == MARCH_EXHAUSTED;
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
       if (marching) {
         int budget = 0x7fffffff;
         found = march_next<COARSE, false>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
-                                   far, budget, t, x, y, z, dt) == MARCH_FOUND;
+                                   far, -3.402823466e+38f, budget, t, x, y, z, dt) == MARCH_FOUND;
       }
       marching = found;
       if (found) t += dt;

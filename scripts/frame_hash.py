@@ -1,0 +1,19 @@
+"""Bit-level fingerprint of frames rendered with a given library build: two builds that claim the same
+semantics must print identical lines (used after every "exact" optimisation of the kernel).
+usage: scripts/frame_hash.py [path/to/libnerfhip.so]"""
+import hashlib, pathlib, sys
+sys.path[:0] = ["nerf-cuda_amd", "tests"]
+import numpy as np
+import models, nerfhip as nh, synthetic as syn
+if len(sys.argv) > 1:
+    nh.LIB_PATH = pathlib.Path(sys.argv[1]).resolve()
+desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
+c = nh.NerfHip(0); c.load_model(desc)
+for (W, H) in ((1920, 1080), (800, 800), (333, 211)):
+    c.set_resolution(W, H)
+    cam = syn.default_camera(W, H)
+    for az, el in ((0, 30), (45, 30), (90, 30), (135, -20), (200, 60), (290, 5)):
+        c.render(cam, syn.orbit_pose(az, el))
+        rgba, depth = c.read_f32()
+        print(W, H, az, el, hashlib.sha1(rgba.tobytes()).hexdigest()[:16], hashlib.sha1(depth.tobytes()).hexdigest()[:16],
+              c.stats().n_samples)
