@@ -157,20 +157,16 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // march tables: coarse occupancy bits + cell-boundary table (staged once per workgroup)
   uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + LDS_FIXED_BYTES);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
-  // LDS timeline of a workgroup: (1) level table, march tables and -- borrowed from the weight area,
-  // which is not needed yet -- the dilated coarse occupancy of the per-ray visibility walk; (2) ray
-  // setup of the four tiles (the walk does ~40 dependent bit lookups per ray: from global memory that
-  // was 26 % of all wave cycles); (3) the weight fragments overwrite the borrowed area.
+  // LDS timeline of a workgroup:
+  //  (1) nothing: ray generation and the slab test against the box of occupied cells need no table; if no
+  //      ray of the four tiles enters the box (background strips, 60-70 % of a typical frame) the
+  //      workgroup stores the background and leaves;
+  //  (2) level table, march tables and -- borrowed from the weight area, which is not needed yet -- the
+  //      dilated coarse occupancy of the per-ray visibility walk (~40 dependent bit lookups per ray: from
+  //      global memory that was 26 % of all wave cycles); direction encoding of the surviving rays;
+  //  (3) the weight fragments overwrite the borrowed area, unless the walk left no ray alive.
   uint32_t* dil_lds = reinterpret_cast<uint32_t*>(wl);
   const bool use_dil_lds = COARSE_LDS && M.occ_dilated != nullptr && M.lds_dilated_words > 0;
-  if (use_dil_lds)
-    for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
-  if (COARSE_LDS) {
-    for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
-    for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
-  }
-  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
-  __syncthreads();
 
   // Block -> tile-strip order.  Consecutive blocks go to different XCDs (round-robin dispatch); keeping
   // that order interleaves the image over all 8 XCDs at strip granularity, which balances the load
@@ -207,20 +203,6 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   float near, far;
   near_far(M.aabb, o, d, P.min_near, near, far);
   const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
-  {
-    half_t e[16];
-    float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
-    float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
-    float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
-    encode_dir16(M, u0, u1, u2, e);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      half2_t h;
-      h.x = e[2 * j];
-      h.y = e[2 * j + 1];
-      W->dirf[lane][j] = h2_bits(h);
-    }
-  }
   const MarchConst mc = march_const(M, P.dt_gamma);
   const int sx = __builtin_signbitf(d[0]) ? 0 : 1;  // copysignf(1, d) > 0: the far face of the cell
   const int sy = __builtin_signbitf(d[1]) ? 0 : 1;
@@ -241,14 +223,26 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   // the others stop marching where they leave it.  NaN-safe: a 0*inf in the slab test fails `<`.
   float far_m = far;
   float t_skip = near;  // march trips before t_skip test a cell that is known to be empty; near: no such trip
+  float t_in, t_out;
+  box_interval(M.occ_box, o, rdx, rdy, rdz, t_in, t_out);
+  const bool nan = !(t_in == t_in) || !(t_out == t_out);
   {
-    float t_in, t_out;
-    box_interval(M.occ_box, o, rdx, rdy, rdz, t_in, t_out);
     const bool hits = (M.occ_box[0] <= M.occ_box[3]) && (t_in <= t_out) && (t_out > near);
     if (t_out < far_m) far_m = t_out;
-    const bool nan = !(t_in == t_in) || !(t_out == t_out);
     if (nan) far_m = far;  // degenerate direction: fall back to the plain aabb range
     alive = alive && (hits || nan);
+  }
+  const bool wg_live = __syncthreads_or(alive ? 1 : 0) != 0;  // (1): does any ray of the workgroup enter the box?
+  if (wg_live) {
+    // ---- (2) tables
+    if (use_dil_lds)
+      for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
+    if (COARSE_LDS) {
+      for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
+      for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
+    }
+    if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+    __syncthreads();
     // finer, still exact: walk the dilated coarse occupancy between the box entry and exit
     if (M.occ_dilated != nullptr && alive && !nan) {
       float t_last, t_first;
@@ -261,12 +255,25 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       if (t_last < far_m) far_m = t_last;
       if (vis) t_skip = t_first;
     }
-  }
-  // ---- the weight fragments replace the dilated bitfield -- unless no ray of the four tiles can sample
-  // (background strips, 60-70 % of a typical frame): those workgroups store the background and leave
-  if (__syncthreads_or(alive ? 1 : 0) != 0) {
-    for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
-    __syncthreads();
+    if (alive) {  // direction encoding: only rays that will evaluate the network need it
+      half_t e[16];
+      float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
+      float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
+      float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
+      encode_dir16(M, u0, u1, u2, e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        half2_t h;
+        h.x = e[2 * j];
+        h.y = e[2 * j + 1];
+        W->dirf[lane][j] = h2_bits(h);
+      }
+    }
+    // ---- (3) the weight fragments replace the dilated bitfield
+    if (__syncthreads_or(alive ? 1 : 0) != 0) {
+      for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+      __syncthreads();
+    }
   }
   if (!valid_tile) return;  // no barrier after this point
   NRF_STAMP(t_setup_done);

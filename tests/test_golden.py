@@ -69,3 +69,30 @@ def test_hip_matches_golden():
     assert np.abs(depth - G["depth"]).max() <= 2.0 / 255.0
     assert ctx.stats().n_samples >= int(G["n_samples"])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_frame_fingerprints_unchanged():
+    """SHA-1 of the float RGBA / depth planes of 18 frames (three resolutions, six cameras), recorded when the
+    kernel last changed numerically (tests/golden/frame_hashes.txt, written by scripts/frame_hash.py).  Every
+    optimisation that claims to be exact -- culling, lookup skipping, instruction selection -- must leave them
+    bit-identical; a deliberate numerical change regenerates the file and says so in its commit."""
+    import hashlib
+
+    import models
+    import nerfhip as nh
+    import synthetic as syn
+
+    want = [ln.split() for ln in (GOLDEN / "frame_hashes.txt").read_text().splitlines() if ln.strip()]
+    desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
+    c = nh.NerfHip(0)
+    c.load_model(desc)
+    for W, H, az, el, h_rgba, h_depth, n_samples in want:
+        W, H = int(W), int(H)
+        c.set_resolution(W, H)
+        c.render(syn.default_camera(W, H), syn.orbit_pose(float(az), float(el)))
+        rgba, depth = c.read_f32()
+        assert c.stats().n_samples == int(n_samples), (W, H, az, el)
+        assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, (W, H, az, el)
+        assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, (W, H, az, el)
+    c.close()
