@@ -83,7 +83,7 @@ def test_frame_fingerprints_unchanged():
     import nerfhip as nh
     import synthetic as syn
 
-    want = [ln.split() for ln in (GOLDEN / "frame_hashes.txt").read_text().splitlines() if ln.strip()]
+    want = [ln.split() for ln in (Path(__file__).parent / "golden" / "frame_hashes.txt").read_text().splitlines() if ln.strip()]
     desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
     c = nh.NerfHip(0)
     c.load_model(desc)
