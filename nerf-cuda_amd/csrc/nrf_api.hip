@@ -252,6 +252,49 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   return NRF_OK;
 }
 
+// Pixel rectangle outside of which no ray of the view can enter `box` (the inflated box of occupied cells,
+// NGP coordinates): the bounding rectangle of the projections of its 8 corners, 3 pixels wider on every side;
+// the whole image when a corner is not safely in front of the camera; empty when the box is.  Conservative
+// by construction: the box is convex, so a ray that enters it passes through the convex hull of the projected
+// corners; rays inside the rectangle still take the exact per-ray slab test in the kernel.
+void view_roi(const float R[9], const float org[3], const float cam[4], const float box[6], int W, int H, int roi[4]) {
+  roi[0] = 0; roi[1] = 0; roi[2] = W - 1; roi[3] = H - 1;
+  if (!(box[0] <= box[3])) {  // no occupied cell at all
+    roi[2] = -1;
+    roi[3] = -1;
+    return;
+  }
+  // camera coordinates of a world offset p: v = R^-1 p (ray_dir applies R to the camera-space direction; poses
+  // need not be orthonormal, so the inverse is computed, not assumed to be the transpose)
+  const double a = R[0], b = R[1], cc = R[2], d = R[3], e = R[4], f = R[5], g = R[6], h = R[7], i = R[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + cc * (d * h - e * g);
+  if (!(std::fabs(det) > 1e-12)) return;
+  const double inv[9] = {(e * i - f * h) / det, (cc * h - b * i) / det, (b * f - cc * e) / det,
+                         (f * g - d * i) / det, (a * i - cc * g) / det, (cc * d - a * f) / det,
+                         (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int c = 0; c < 8; ++c) {
+    const double p[3] = {(double)box[(c & 1) ? 3 : 0] - org[0], (double)box[(c & 2) ? 4 : 1] - org[1],
+                         (double)box[(c & 4) ? 5 : 2] - org[2]};
+    const double vx = inv[0] * p[0] + inv[1] * p[1] + inv[2] * p[2];
+    const double vy = inv[3] * p[0] + inv[4] * p[1] + inv[5] * p[2];
+    const double vz = inv[6] * p[0] + inv[7] * p[1] + inv[8] * p[2];
+    if (!(vz > 1e-3)) return;  // corner beside / behind the camera (or NaN): keep the whole image
+    const double u = cam[2] + cam[0] * vx / vz, v = cam[3] + cam[1] * vy / vz;
+    if (!(u == u) || !(v == v)) return;
+    lo[0] = u < lo[0] ? u : lo[0]; hi[0] = u > hi[0] ? u : hi[0];
+    lo[1] = v < lo[1] ? v : lo[1]; hi[1] = v > hi[1] ? v : hi[1];
+  }
+  // pixel (i, j) looks through (i + 0.5, j + 0.5)
+  const double m = 3.0;
+  const double x0 = std::floor(lo[0] - 0.5 - m), y0 = std::floor(lo[1] - 0.5 - m);
+  const double x1 = std::ceil(hi[0] - 0.5 + m), y1 = std::ceil(hi[1] - 0.5 + m);
+  roi[0] = x0 < 0 ? 0 : (x0 > W ? W : (int)x0);
+  roi[1] = y0 < 0 ? 0 : (y0 > H ? H : (int)y0);
+  roi[2] = x1 < -1 ? -1 : (x1 > W - 1 ? W - 1 : (int)x1);
+  roi[3] = y1 < -1 ? -1 : (y1 > H - 1 ? H - 1 : (int)y1);
+}
+
 int need_model(nrf_context* c) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->model_loaded) return fail(NRF_E_STATE, "no model loaded (call nrf_load_model first)");
@@ -630,6 +673,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
     for (int v = 0; v < VB.n_views; ++v) {
       nerf_matrix_to_ngp(poses + 16 * (size_t)(first + v), c->desc.scale, VB.v[v].R, VB.v[v].org);
       for (int i = 0; i < 4; ++i) VB.v[v].cam[i] = cams[4 * (size_t)(first + v) + i];
+      view_roi(VB.v[v].R, VB.v[v].org, VB.v[v].cam, c->dm.occ_box, c->W, c->H, VB.v[v].roi);
     }
     HIP_TRY(launch_render(c->dm, P, VB, (char*)rgba + (size_t)first * c->n_out_px * 16, (char*)depth + (size_t)first * c->n_out_px * 4,
                           c->d_counters, st));

@@ -97,6 +97,8 @@ struct ViewParams {
   float R[9];    // rotation of nerf_matrix_to_ngp(pose)
   float org[3];  // translation
   float cam[4];  // fl_x, fl_y, cx, cy
+  int roi[4];    // x0, y0, x1, y1 (pixels, inclusive): no ray outside this rectangle enters the box of occupied
+                 // cells (host: conservative projection of its corners, nrf_api.hip view_roi); x1 < x0: empty
 };
 // Statistics counters: COUNTER_SLOTS copies of 16 x u64 (one 128-byte line each); a workgroup adds to copy
 // blockIdx % COUNTER_SLOTS.  Device-scope atomics on ONE address serialise at ~12 ns each across the 8 XCDs:

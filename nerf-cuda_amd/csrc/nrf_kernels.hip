@@ -190,6 +190,23 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
   const bool in_img = valid_tile && px < P.W && py < P.H;
+  {
+    // (0) the strip's 32x8 pixels against the view's region of interest: outside it every ray misses the box
+    // of occupied cells, so the pixel is the background -- no ray is generated (blockIdx-uniform: all four
+    // waves of the workgroup take this exit together, before any barrier)
+    const int sx0 = (strip % strips_x) * 32, sy0 = ty * 8;
+    if (sx0 > V.roi[2] || sx0 + 31 < V.roi[0] || sy0 > V.roi[3] || sy0 + 7 < V.roi[1]) {
+      const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
+      if (in_img) {
+        rgba[idx] = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
+        depth[idx] = 0.f;
+      } else if (P.tile_major && valid_tile) {
+        rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        depth[idx] = 0.f;
+      }
+      return;
+    }
+  }
 
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;

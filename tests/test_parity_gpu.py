@@ -570,3 +570,22 @@ def test_device_group_equals_single_context(ctx):
             np.testing.assert_array_equal(rgb8, want_u8[i][0])
             np.testing.assert_array_equal(d8, want_u8[i][1])
         g.close()
+
+
+@pytest.mark.parametrize("radius,az,el,fl_scale", [(0.9, 40, 10, 1.0), (0.3, 200, 35, 0.4), (2.2, 310, 80, 3.0), (1.5, 0, -89, 1.0)])
+def test_region_of_interest_cull_is_conservative(ctx, small, radius, az, el, fl_scale):
+    """The per-view pixel rectangle outside of which strips are filled with the background without
+    generating rays (nrf_api.hip view_roi): cameras inside the volume, next to the box of occupied
+    cells (corners behind the image plane -> whole image), far away with a long lens (object spans
+    the frame), looking straight up -- the frame must still match the oracle everywhere."""
+    desc, keep, o = small
+    ctx.load_model(desc)
+    W, H = 136, 72
+    cam = syn.default_camera(W, H)
+    cam[:2] *= np.float32(fl_scale)
+    pose = syn.orbit_pose(az, el, radius=radius / 0.33)
+    rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
+    assert np.abs(rgba - want).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0
+    # pixels the oracle did not touch are exactly the background in both
+    untouched = want[..., 3] == 0
+    assert np.array_equal(rgba[untouched], want[untouched])
