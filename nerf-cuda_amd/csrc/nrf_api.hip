@@ -456,7 +456,22 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       coarse[cc >> 5] |= 1u << (cc & 31);
     }
   }
-  // world-space box around every occupied cell, inflated by 2 cells of its cascade level
+  // A density cell of cascade k >= 1 is only ever looked up for positions of level k, i.e. with
+  // max|p| >= 2^(k-1) (kernel_march_rays picks the level from frexp(max|p|), render_utils.h:603-607): cells
+  // that lie, with one cell of slack, wholly inside the inner cube max|p| < 2^(k-1) cannot produce a sample
+  // whatever their value, so they count neither for the box of occupied cells nor for the visibility sets.
+  auto reachable = [&](uint32_t level, uint32_t nx, uint32_t ny, uint32_t nz) {
+    if (level == 0 || Cs <= 1) return true;
+    const double mb = fmin(ldexp(1.0, (int)level), (double)d->bound), cell = 2.0 * mb / (double)Hs;
+    const uint32_t n3[3] = {nx, ny, nz};
+    double r_max = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double lo = -mb + n3[a] * cell, hi = lo + cell;
+      r_max = fmax(r_max, fmax(fabs(lo), fabs(hi)));
+    }
+    return !(r_max + cell < ldexp(1.0, (int)level - 1));
+  };
+  // world-space box around every occupied (and reachable) cell, inflated by 2 cells of its cascade level
   float occ_box[6] = {1.f, 1.f, 1.f, -1.f, -1.f, -1.f};  // empty
   {
     bool any = false;
@@ -467,6 +482,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
         const uint64_t i = (uint64_t)level * Hh * Hh * Hh + r;
         if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
         const uint32_t n3[3] = {(uint32_t)(r / (Hh * Hh)), (uint32_t)((r / Hh) % Hh), (uint32_t)(r % Hh)};
+        if (!reachable(level, n3[0], n3[1], n3[2])) continue;
         for (int a = 0; a < 3; ++a) { lo[a] = n3[a] < lo[a] ? n3[a] : lo[a]; hi[a] = n3[a] > hi[a] ? n3[a] : hi[a]; }
         lvl_any = true;
       }
@@ -486,23 +502,29 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   // density cell of, an occupied density cell (= the coarse image of the occupancy dilated by one
   // fine cell); used by the per-ray DDA of render_kernel (nrf_device.h coarse_visibility).
   std::vector<uint32_t> dilated;
-  if (coarse_shift && Cs == 1) {
+  uint32_t dilated_level_words = 0;  // words per cascade level (whole words, so a level's bits start at bit 0)
+  if (coarse_shift) {
     const int Hc = (int)(Hs >> 2), Hf = (int)Hs;
-    dilated.assign(((uint64_t)Hc * Hc * Hc + 31) / 32 + 1, 0u);
-    for (int x = 0; x < Hf; ++x)
-      for (int y = 0; y < Hf; ++y)
-        for (int z = 0; z < Hf; ++z) {
-          const uint64_t i = ((uint64_t)x * Hf + y) * Hf + z;
-          if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
-          for (int dx = -1; dx <= 1; ++dx)
-            for (int dy = -1; dy <= 1; ++dy)
-              for (int dz = -1; dz <= 1; ++dz) {
-                const int X = x + dx, Y = y + dy, Z = z + dz;
-                if (X < 0 || Y < 0 || Z < 0 || X >= Hf || Y >= Hf || Z >= Hf) continue;
-                const uint64_t nn = ((uint64_t)(X >> 2) * Hc + (Y >> 2)) * Hc + (Z >> 2);
-                dilated[nn >> 5] |= 1u << (nn & 31);
-              }
-        }
+    dilated_level_words = (uint32_t)(((uint64_t)Hc * Hc * Hc + 31) / 32);
+    dilated.assign((size_t)dilated_level_words * Cs, 0u);
+    for (uint32_t level = 0; level < Cs; ++level) {
+      uint32_t* dl = dilated.data() + (size_t)level * dilated_level_words;
+      for (int x = 0; x < Hf; ++x)
+        for (int y = 0; y < Hf; ++y)
+          for (int z = 0; z < Hf; ++z) {
+            const uint64_t i = (((uint64_t)level * Hf + x) * Hf + y) * Hf + z;
+            if (!((occ[i >> 5] >> (i & 31)) & 1u)) continue;
+            if (!reachable(level, (uint32_t)x, (uint32_t)y, (uint32_t)z)) continue;
+            for (int dx = -1; dx <= 1; ++dx)
+              for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                  const int X = x + dx, Y = y + dy, Z = z + dz;
+                  if (X < 0 || Y < 0 || Z < 0 || X >= Hf || Y >= Hf || Z >= Hf) continue;
+                  const uint64_t nn = ((uint64_t)(X >> 2) * Hc + (Y >> 2)) * Hc + (Z >> 2);
+                  dl[nn >> 5] |= 1u << (nn & 31);
+                }
+          }
+    }
   }
   std::vector<float> ctab((size_t)Cs * (Hs + 1));
   for (uint32_t level = 0; level < Cs; ++level) {
@@ -591,6 +613,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       M.lds_ctab_floats = (uint32_t)fl;
     }
   }
+  M.dilated_level_words = dilated_level_words;
   if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
   M.pos_w = (float)(1.0 / (2 * (double)d->bound));
   M.cascade = d->cascade;

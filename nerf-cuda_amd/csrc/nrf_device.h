@@ -68,7 +68,8 @@ struct DevModel {
   const uint32_t* occ_coarse;  // OR over 4x4x4 cell blocks, [C][(H/4)^3] bits; nullptr if H % 4 != 0
   const float* cell_bound;     // [C][H+1] cell-boundary table (see march_next)
   uint32_t grid_bytes;         // size of the device hash table (< 4 GiB): num_records of its buffer resource
-  const uint32_t* occ_dilated;  // coarse cells within one density cell of an occupied density cell; C == 1 only, else nullptr
+  const uint32_t* occ_dilated;  // [C][dilated_level_words]: coarse cells within one density cell of an occupied density cell
+  uint32_t dilated_level_words;
   const uint4* wfrag;        // N_FRAGS_ALL * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];

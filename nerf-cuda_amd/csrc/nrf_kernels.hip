@@ -260,17 +260,42 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     }
     if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
     __syncthreads();
-    // finer, still exact: walk the dilated coarse occupancy between the box entry and exit
+    // finer, still exact: walk the dilated coarse occupancy between the box entry and exit, one walk per
+    // cascade over the ray's stretch inside that cascade's cube (a trip at a position of level k looks up
+    // cascade k's grid, and such a position lies inside cube k)
     if (M.occ_dilated != nullptr && alive && !nan) {
-      float t_last, t_first;
-      const float t0 = fmaxf(t_in, near);
       const int Hc = (int)(M.H >> 2);
-      const float mb = fminf(1.0f, M.bound);
-      const bool vis = use_dil_lds ? coarse_visibility(dil_lds, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_first, t_last)
-                                   : coarse_visibility(M.occ_dilated, Hc, mb, o, d, rdx, rdy, rdz, t0, far_m, t_first, t_last);
-      alive = vis;
-      if (t_last < far_m) far_m = t_last;
-      if (vis) t_skip = t_first;
+      const float t_box0 = fmaxf(t_in, near);
+      bool any = false;
+      float first = far_m, last = t_box0;
+      const uint32_t n_casc = UNIT ? 1u : M.cascade;  // UNIT instances: one cascade, mip_bound 1
+      for (uint32_t k = 0; k < n_casc; ++k) {
+        const float mb = (n_casc > 1) ? fminf(ldexpf(1.0f, (int)k), M.bound) : fminf(1.0f, M.bound);
+        float c_in = t_box0, c_out = far_m;
+        if (n_casc > 1) {  // the ray inside cube k
+          const float cube[6] = {-mb, -mb, -mb, mb, mb, mb};
+          float a, b;
+          box_interval(cube, o, rdx, rdy, rdz, a, b);
+          if (a == a && b == b) {
+            c_in = fmaxf(c_in, a);
+            c_out = fminf(c_out, b);
+          }
+        }
+        if (!(c_in < c_out)) continue;
+        float t_last, t_first;
+        const uint32_t* dl_g = M.occ_dilated + (size_t)k * M.dilated_level_words;
+        const uint32_t* dl_l = dil_lds + (size_t)k * M.dilated_level_words;
+        const bool vis = use_dil_lds ? coarse_visibility(dl_l, Hc, mb, o, d, rdx, rdy, rdz, c_in, c_out, t_first, t_last)
+                                     : coarse_visibility(dl_g, Hc, mb, o, d, rdx, rdy, rdz, c_in, c_out, t_first, t_last);
+        if (vis) {
+          any = true;
+          first = fminf(first, t_first);
+          last = fmaxf(last, t_last);
+        }
+      }
+      alive = any;
+      if (last < far_m) far_m = last;
+      if (any) t_skip = first;
     }
     if (alive) {  // direction encoding: only rays that will evaluate the network need it
       half_t e[16];

@@ -17,3 +17,17 @@ for (W, H) in ((1920, 1080), (800, 800), (333, 211)):
         rgba, depth = c.read_f32()
         print(W, H, az, el, hashlib.sha1(rgba.tobytes()).hexdigest()[:16], hashlib.sha1(depth.tobytes()).hexdigest()[:16],
               c.stats().n_samples)
+
+# BASELINE config 4 shape: bound 16, 5 cascades (generic march instance, per-cascade visibility walk)
+desc4, keep4, _ = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)
+c.load_model(desc4)
+o4 = nh.default_options(); o4.max_steps = 1024
+c.set_options(o4)
+for (W, H) in ((640, 360), (201, 133)):
+    c.set_resolution(W, H)
+    cam = syn.default_camera(W, H)
+    for az, el, radius in ((0, 30, 4.0311), (120, -15, 1.5 / 0.33), (250, 70, 9.0 / 0.33), (33, 5, 0.4 / 0.33)):
+        c.render(cam, syn.orbit_pose(az, el, radius=radius))
+        rgba, depth = c.read_f32()
+        print("c4", W, H, az, el, radius, hashlib.sha1(rgba.tobytes()).hexdigest()[:16], hashlib.sha1(depth.tobytes()).hexdigest()[:16],
+              c.stats().n_samples)

@@ -4,7 +4,10 @@ sys.path[:0] = ["nerf-cuda_amd", "tests"]
 import numpy as np
 import models, nerfhip as nh, synthetic as syn
 nh.LIB_PATH = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 else "nerf-cuda_amd/libnerfhip_prof.so").resolve()
-desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
+if len(sys.argv) > 2 and sys.argv[2] == "config4":
+    desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)
+else:
+    desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
 ctx = nh.NerfHip(0)
 ctx.load_model(desc)
 W, H = 1920, 1080

@@ -73,7 +73,8 @@ def test_hip_matches_golden():
 
 @pytest.mark.gpu
 def test_frame_fingerprints_unchanged():
-    """SHA-1 of the float RGBA / depth planes of 18 frames (three resolutions, six cameras), recorded when the
+    """SHA-1 of the float RGBA / depth planes of 26 frames (config 2: three resolutions x six cameras; config 4
+    shape: two resolutions x four cameras, outside, inside and far from the volume), recorded when the
     kernel last changed numerically (tests/golden/frame_hashes.txt, written by scripts/frame_hash.py).  Every
     optimisation that claims to be exact -- culling, lookup skipping, instruction selection -- must leave them
     bit-identical; a deliberate numerical change regenerates the file and says so in its commit."""
@@ -85,14 +86,26 @@ def test_frame_fingerprints_unchanged():
 
     want = [ln.split() for ln in (Path(__file__).parent / "golden" / "frame_hashes.txt").read_text().splitlines() if ln.strip()]
     desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
+    desc4, keep4, _ = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)  # BASELINE config 4 shape
     c = nh.NerfHip(0)
-    c.load_model(desc)
-    for W, H, az, el, h_rgba, h_depth, n_samples in want:
+    loaded = None
+    for row in want:
+        config4 = row[0] == "c4"
+        if config4:
+            _, W, H, az, el, radius, h_rgba, h_depth, n_samples = row
+        else:
+            (W, H, az, el, h_rgba, h_depth, n_samples), radius = row, 4.0311
+        if loaded != config4:
+            c.load_model(desc4 if config4 else desc)
+            o = nh.default_options()
+            o.max_steps = 1024 if config4 else o.max_steps
+            c.set_options(o)
+            loaded = config4
         W, H = int(W), int(H)
         c.set_resolution(W, H)
-        c.render(syn.default_camera(W, H), syn.orbit_pose(float(az), float(el)))
+        c.render(syn.default_camera(W, H), syn.orbit_pose(float(az), float(el), radius=float(radius)))
         rgba, depth = c.read_f32()
-        assert c.stats().n_samples == int(n_samples), (W, H, az, el)
-        assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, (W, H, az, el)
-        assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, (W, H, az, el)
+        assert c.stats().n_samples == int(n_samples), row
+        assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
+        assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, row
     c.close()
