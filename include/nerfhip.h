@@ -348,6 +348,11 @@ int nrf_rb_accumulate(nrf_render_buffer* rb, float exposure, void* stream);/* ac
 int nrf_rb_tonemap(nrf_render_buffer* rb, float exposure, const float background_color[4],
                    int output_color_space, void* stream);                  /* tonemap()                      */
 /* host_to_accumulate_buffer(): rgb u8 [n][3] -> accumulate RGBA = rgb/255, a = 1 (render_buffer.h:231-241) */
+/* overlay_depth() (render_buffer.cu:431-477, 690-714): turbo-coloured depth (device float plane of
+ * image_width x image_height, e.g. nrf_frame.depth) blended over the surface with weight alpha.     */
+int nrf_rb_overlay_depth(nrf_render_buffer* rb, float alpha, const void* depth, float depth_scale,
+                         int image_width, int image_height, int fov_axis, float zoom,
+                         const float screen_center[2], void* stream);
 int nrf_rb_host_to_accumulate_buffer(nrf_render_buffer* rb, const uint8_t* rgb, int n);
 int nrf_rb_read(nrf_render_buffer* rb, float* accumulate_rgba, float* surface_rgba);  /* host copies (either may be NULL) */
 

@@ -238,6 +238,65 @@ int nrf_rb_tonemap(nrf_render_buffer* rb, float exposure, const float bg[4], int
   return NRF_OK;
 }
 
+// overlay_depth_kernel, R/src/render_buffer.cu:431-477 with colormap_turbo (:413-429): the polynomial is evaluated
+// as the fixed-size Eigen dot products do, ((a0*b0 + a1*b1) + a2*b2) + a3*b3, every operation rounded on its own.
+__device__ __forceinline__ float dot4(const float a[4], float b0, float b1, float b2, float b3) {
+  return ((a[0] * b0 + a[1] * b1) + a[2] * b2) + a[3] * b3;
+}
+__device__ __forceinline__ void colormap_turbo(float x, float c[3]) {
+  const float kR4[4] = {0.13572138f, 4.61539260f, -42.66032258f, 132.13108234f};
+  const float kG4[4] = {0.09140261f, 2.19418839f, 4.84296658f, -14.18503333f};
+  const float kB4[4] = {0.10667330f, 12.64194608f, -60.58204836f, 110.36276771f};
+  const float kR2[2] = {-152.94239396f, 59.28637943f};
+  const float kG2[2] = {4.27729857f, 2.82956604f};
+  const float kB2[2] = {-89.90310912f, 27.34824973f};
+  x = fminf(fmaxf(x, 0.0f), 1.0f);  // __saturatef (NaN -> 0)
+  if (!(x == x)) x = 0.0f;
+  const float x2 = x * x, x3 = x2 * x;
+  const float v20 = x3 * x, v21 = x3 * x2;
+  c[0] = dot4(kR4, 1.0f, x, x2, x3) + (v20 * kR2[0] + v21 * kR2[1]);
+  c[1] = dot4(kG4, 1.0f, x, x2, x3) + (v20 * kG2[0] + v21 * kG2[1]);
+  c[2] = dot4(kB4, 1.0f, x, x2, x3) + (v20 * kB2[0] + v21 * kB2[1]);
+}
+
+__global__ __launch_bounds__(256) void overlay_depth_kernel(int W, int H, float alpha, const float* __restrict__ depth,
+                                                            float depth_scale, int img_w, int img_h, int fov_axis, float zoom,
+                                                            float center_x, float center_y, float4* __restrict__ surface) {
+  const int n = W * H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int x = i % W, y = i / W;
+    const float scale = (float)(fov_axis == 0 ? img_w : img_h) / (float)(fov_axis == 0 ? W : H);
+    float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+    fx -= (float)W * 0.5f; fx /= zoom; fx += center_x * (float)W;
+    fy -= (float)H * 0.5f; fy /= zoom; fy += center_y * (float)H;
+    const float u = (fx - (float)W * 0.5f) * scale + (float)img_w * 0.5f;
+    const float v = (fy - (float)H * 0.5f) * scale + (float)img_h * 0.5f;
+    const int srcx = (int)floorf(u), srcy = (int)floorf(v);
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(srcx >= img_w || srcy >= img_h || srcx < 0 || srcy < 0)) {
+      float c[3];
+      colormap_turbo(depth[(size_t)srcx + (size_t)img_w * srcy] * depth_scale, c);
+      color = make_float4(c[0], c[1], c[2], 1.0f);
+    }
+    const float4 prev = surface[i];
+    const float ia = 1.f - alpha;
+    surface[i] = make_float4(color.x * alpha + prev.x * ia, color.y * alpha + prev.y * ia, color.z * alpha + prev.z * ia,
+                             color.w * alpha + prev.w * ia);
+  }
+}
+
+int nrf_rb_overlay_depth(nrf_render_buffer* rb, float alpha, const void* depth, float depth_scale, int image_width,
+                         int image_height, int fov_axis, float zoom, const float screen_center[2], void* stream) {
+  if (!depth || !screen_center || image_width <= 0 || image_height <= 0 || (fov_axis != 0 && fov_axis != 1))
+    return rb_fail(NRF_E_INVALID, "bad argument");
+  RB_READY();
+  hipLaunchKernelGGL(overlay_depth_kernel, dim3(rb_grid(n)), dim3(256), 0, st, rb->W, rb->H, alpha, (const float*)depth, depth_scale,
+                     image_width, image_height, fov_axis, zoom, screen_center[0], screen_center[1], (float4*)rb->surface);
+  RB_TRY(hipGetLastError());
+  if (!stream) RB_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
 int nrf_rb_host_to_accumulate_buffer(nrf_render_buffer* rb, const uint8_t* rgb, int count) {
   void* stream = nullptr;
   RB_READY();

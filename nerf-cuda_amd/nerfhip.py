@@ -180,6 +180,8 @@ _SIGS = {
     "nrf_rb_clear_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nrf_rb_accumulate": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "nrf_rb_tonemap": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "nrf_rb_overlay_depth": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.POINTER(C.c_float), C.c_void_p]),
     "nrf_rb_host_to_accumulate_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "nrf_rb_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_encode_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -607,6 +609,12 @@ class RenderBuffer:
     def tonemap(self, exposure, background_color, output_color_space, stream=None):
         bg = np.ascontiguousarray(background_color, np.float32).reshape(4)
         _check(self.lib.nrf_rb_tonemap(self.h, C.c_float(exposure), _fptr(bg), output_color_space, C.c_void_p(stream or 0)))
+
+    def overlay_depth(self, alpha, depth_ptr, depth_scale, image_width, image_height, fov_axis=0, zoom=1.0,
+                      screen_center=(0.5, 0.5), stream=None):
+        ctr = np.ascontiguousarray(screen_center, np.float32).reshape(2)
+        _check(self.lib.nrf_rb_overlay_depth(self.h, C.c_float(alpha), C.c_void_p(depth_ptr), C.c_float(depth_scale), image_width,
+                                             image_height, fov_axis, C.c_float(zoom), _fptr(ctr), C.c_void_p(stream or 0)))
 
     def host_to_accumulate_buffer(self, rgb_u8):
         rgb = np.ascontiguousarray(rgb_u8, np.uint8)

@@ -162,6 +162,40 @@ uint32_t nrfo_fast_hash3(uint32_t x, uint32_t y, uint32_t z) {
   return (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
 }
 
+// R/src/render_buffer.cu:413-429 (colormap_turbo) and :431-477 (overlay_depth_kernel); surface [H][W][4] in place
+static float dot4_(const float a[4], float b0, float b1, float b2, float b3) { return ((a[0] * b0 + a[1] * b1) + a[2] * b2) + a[3] * b3; }
+void nrfo_rb_overlay_depth(float* surface, int W, int H, float alpha, const float* depth, float depth_scale, int img_w, int img_h,
+                           int fov_axis, float zoom, float center_x, float center_y) {
+  const float kR4[4] = {0.13572138f, 4.61539260f, -42.66032258f, 132.13108234f};
+  const float kG4[4] = {0.09140261f, 2.19418839f, 4.84296658f, -14.18503333f};
+  const float kB4[4] = {0.10667330f, 12.64194608f, -60.58204836f, 110.36276771f};
+  const float kR2[2] = {-152.94239396f, 59.28637943f}, kG2[2] = {4.27729857f, 2.82956604f}, kB2[2] = {-89.90310912f, 27.34824973f};
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const float scale = (float)(fov_axis == 0 ? img_w : img_h) / (float)(fov_axis == 0 ? W : H);
+      float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+      fx -= (float)W * 0.5f; fx /= zoom; fx += center_x * (float)W;
+      fy -= (float)H * 0.5f; fy /= zoom; fy += center_y * (float)H;
+      const float u = (fx - (float)W * 0.5f) * scale + (float)img_w * 0.5f;
+      const float v = (fy - (float)H * 0.5f) * scale + (float)img_h * 0.5f;
+      const int srcx = (int)std::floor(u), srcy = (int)std::floor(v);
+      float color[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!(srcx >= img_w || srcy >= img_h || srcx < 0 || srcy < 0)) {
+        float t = depth[(size_t)srcx + (size_t)img_w * srcy] * depth_scale;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        if (!(t == t)) t = 0.0f;
+        const float x2 = t * t, x3 = x2 * t, v20 = x3 * t, v21 = x3 * x2;
+        color[0] = dot4_(kR4, 1.0f, t, x2, x3) + (v20 * kR2[0] + v21 * kR2[1]);
+        color[1] = dot4_(kG4, 1.0f, t, x2, x3) + (v20 * kG2[0] + v21 * kG2[1]);
+        color[2] = dot4_(kB4, 1.0f, t, x2, x3) + (v20 * kB2[0] + v21 * kB2[1]);
+        color[3] = 1.0f;
+      }
+      float* px = surface + 4 * ((size_t)y * W + x);
+      const float ia = 1.f - alpha;
+      for (int k = 0; k < 4; ++k) px[k] = color[k] * alpha + px[k] * ia;
+    }
+}
+
 }  // extern "C"
 
 namespace {

@@ -90,6 +90,10 @@ void nrfo_rb_accumulate(const float* frame_rgba, float* accum_rgba, int n, float
 void nrfo_rb_tonemap(const float* accum_rgba, float* surface_rgba, int n, float exposure, const float bg[4],
                      int color_space, int output_color_space, int curve, int clamp_output);
 
+/* render_buffer.cu:413-477: turbo-coloured depth blended over the surface [H][W][4], in place */
+void nrfo_rb_overlay_depth(float* surface_rgba, int W, int H, float alpha, const float* depth, float depth_scale, int img_w,
+                           int img_h, int fov_axis, float zoom, float center_x, float center_y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,19 @@ def rb_tonemap(accum, exposure, bg, color_space, output_color_space, curve, clam
     return out
 
 
+def rb_overlay_depth(surface, alpha, depth, depth_scale, fov_axis, zoom, center):
+    surface, depth = _f32(surface).copy(), _f32(depth)
+    H, W = surface.shape[:2]
+    ih, iw = depth.shape
+    L = lib()
+    L.nrfo_rb_overlay_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, C.c_float]
+    L.nrfo_rb_overlay_depth.restype = None
+    L.nrfo_rb_overlay_depth(surface.ctypes.data, W, H, float(alpha), depth.ctypes.data, float(depth_scale), iw, ih, int(fov_axis),
+                            float(zoom), float(center[0]), float(center[1]))
+    return surface
+
+
 def quantize_u8(rgba, depth):
     rgba, depth = _f32(rgba), _f32(depth)
     n = depth.size

@@ -103,3 +103,39 @@ def test_render_into_render_buffer_on_device():
     ctx.bind_output(None, None)
     ctx.close()
     rb.close()
+
+
+def test_oracle_turbo_known_answers():
+    """colormap_turbo end points and mid point (render_buffer.cu:413-429): source-derived known answers."""
+    depth = np.array([[0.0, 0.5, 1.0, 7.0, -3.0]], np.float32)
+    out = op.rb_overlay_depth(np.zeros((1, 5, 4), np.float32), 1.0, depth, 1.0, 0, 1.0, (0.5, 0.5))
+    k = dict(r=(0.13572138, 4.61539260, -42.66032258, 132.13108234, -152.94239396, 59.28637943),
+             g=(0.09140261, 2.19418839, 4.84296658, -14.18503333, 4.27729857, 2.82956604),
+             b=(0.10667330, 12.64194608, -60.58204836, 110.36276771, -89.90310912, 27.34824973))
+    for col, x in ((0, 0.0), (1, 0.5), (2, 1.0), (3, 1.0), (4, 0.0)):  # saturation of out-of-range depths
+        want = [sum(c * x ** p for p, c in enumerate(k[ch])) for ch in "rgb"]
+        np.testing.assert_allclose(out[0, col, :3], want, rtol=0, atol=2e-5)
+        assert out[0, col, 3] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha,fov_axis,zoom,center", [(1.0, 0, 1.0, (0.5, 0.5)), (0.35, 1, 1.7, (0.42, 0.61)), (0.5, 0, 0.6, (0.5, 0.5))])
+def test_overlay_depth_matches_oracle(alpha, fov_axis, zoom, center):
+    """nrf_rb_overlay_depth = overlay_depth_kernel (turbo colours, nearest-neighbour resampling, alpha blend)."""
+    import torch
+    rb = nh.RenderBuffer(0)
+    W, H, iw, ih = 96, 54, 80, 60
+    rb.resize(W, H)
+    rng = np.random.default_rng(3)
+    depth = rng.random((ih, iw), dtype=np.float32) * 1.3 - 0.1
+    d_d = torch.from_numpy(depth).cuda()
+    torch.cuda.synchronize()
+    rb.set_color_space(nh.CS_LINEAR)
+    rb.tonemap(0.0, (0.2, 0.4, 0.6, 1.0), nh.CS_LINEAR)  # surface = background colour (the accumulate plane is empty)
+    _, before = rb.read()
+    assert np.all(before == before[0, 0]) and before.max() > 0
+    rb.overlay_depth(alpha, d_d.data_ptr(), 0.9, iw, ih, fov_axis, zoom, center)
+    _, after = rb.read()
+    want = op.rb_overlay_depth(before, alpha, depth, 0.9, fov_axis, zoom, center)
+    np.testing.assert_allclose(after, want, rtol=0, atol=1e-6)
+    rb.close()
