@@ -1,8 +1,8 @@
 // render_buffer.h -- C++ mirror of the reference's ngp::CudaRenderBuffer presentation API
 // (include/nerf-cuda/render_buffer.h:160-315) on the C ABI: same method names for resize,
 // reset_accumulation, spp, frame/depth/accumulate buffers, clear_frame, accumulate, tonemap,
-// host_to_accumulate_buffer, accumulate_buffer_host.  GL textures, CUDA surfaces, DLSS and the
-// overlay kernels of the reference class are out of scope (NVIDIA/GL presentation).
+// host_to_accumulate_buffer, accumulate_buffer_host, overlay_depth.  GL textures, CUDA surfaces, DLSS and the
+// image / false-colour overlays of the reference class are out of scope (NVIDIA/GL presentation, training views).
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -49,6 +49,11 @@ class RenderBuffer {
   void accumulate(float exposure, void* stream = nullptr) { ok(nrf_rb_accumulate(m_rb, exposure, stream)); }
   void tonemap(float exposure, const float background_color[4], EColorSpace output_color_space, void* stream = nullptr) {
     ok(nrf_rb_tonemap(m_rb, exposure, background_color, (int)output_color_space, stream));
+  }
+  // overlay_depth(), render_buffer.h:259-268: `depth` is a device float plane of `resolution` (e.g. depth_buffer())
+  void overlay_depth(float alpha, const float* depth, float depth_scale, const Vector2i& resolution, int fov_axis, float zoom,
+                     const float screen_center[2], void* stream = nullptr) {
+    ok(nrf_rb_overlay_depth(m_rb, alpha, depth, depth_scale, resolution[0], resolution[1], fov_axis, zoom, screen_center, stream));
   }
 
  private:
