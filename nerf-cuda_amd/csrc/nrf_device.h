@@ -139,6 +139,14 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   return h2_bits(v);
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// fp32 -> fp16 of a value that was ROUNDED to fp32 first (what `(half)(float expression)` means in the reference).
+// Without the empty asm the compiler folds a preceding fmul / fadd into v_fma_mixlo_f16, which rounds the exact
+// result once: 1 in ~130 000 SH coefficients then differs from the two-step rounding by one fp16 ulp
+// (scripts/sh_probe.py found 240 of 32 M before this helper existed).
+__device__ __forceinline__ half_t f2h_rne(float v) {
+  asm("" : "+v"(v));
+  return (half_t)v;
+}
 
 // tcnn activations on an fp32 pre-activation (T/include/tiny-cuda-nn/common_device.h:68-114)
 __device__ __forceinline__ float activate(uint32_t act, float v) {
@@ -531,7 +539,7 @@ __device__ __forceinline__ void encode_dir16(const DevModel& M, float d01x, floa
   case DEG: {                                                                   \
     constexpr int n = DEG * DEG, pad = 16 - n;                                  \
     _Pragma("unroll") for (int j = 0; j < pad; ++j) out[j] = (half_t)1.0f;      \
-    _Pragma("unroll") for (int j = 0; j < n; ++j) out[pad + j] = (half_t)c[j];  \
+    _Pragma("unroll") for (int j = 0; j < n; ++j) out[pad + j] = f2h_rne(c[j]);  \
   } break;
     switch (M.sh_degree) {
       NRF_SH_CASE(1)
@@ -556,12 +564,12 @@ __device__ __forceinline__ void encode_dir16(const DevModel& M, float d01x, floa
         const float xs = ldexpf(xin, (int)log2_frequency);
         v = __sinf(xs * PI + phase_shift);
       }
-      out[j] = (half_t)v;
+      out[j] = f2h_rne(v);
     }
   } else {  // Identity: scale 1, offset 0, trailing ones
-    out[0] = (half_t)d01x;
-    out[1] = (half_t)d01y;
-    out[2] = (half_t)d01z;
+    out[0] = f2h_rne(d01x);
+    out[1] = f2h_rne(d01y);
+    out[2] = f2h_rne(d01z);
 #pragma unroll
     for (uint32_t j = 3; j < 16; ++j) out[j] = (half_t)1.0f;
   }
