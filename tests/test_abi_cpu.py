@@ -93,3 +93,27 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(nh.NerfHipError) as e:
         nh.NerfHip(0)
     assert e.value.code == nh.NRF_E_NODEVICE
+
+
+def test_device_code_keeps_the_arithmetic_contract(tmp_path):
+    """Disassembles the gfx950 code object inside libnerfhip.so (no GPU needed) and checks what the parity
+    contract depends on: no packed-fp32 VALU arithmetic (the SLP hazard of DESIGN.md, -fno-slp-vectorize), no
+    v_fma_mix{lo,hi}_f16 (they round (half)(a*b) once instead of fp32-then-fp16: DESIGN.md "Compiler-fused
+    conversions"), no fused fp32 multiply-adds outside the division / sqrt expansions, and the MFMA the MLPs use."""
+    import shutil
+    import subprocess
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "clang-offload-bundler").exists() or shutil.which("objcopy") is None:
+        pytest.skip("ROCm LLVM tools not available")
+    lib = ROOT / "nerf-cuda_amd" / "libnerfhip.so"
+    fat, co = tmp_path / "fat.bin", tmp_path / "dev.co"
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(lib), str(fat)], check=True)
+    subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
+    asm = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], check=True, capture_output=True, text=True).stdout
+    ops = [ln.split()[0] for ln in asm.splitlines() if ln.startswith("\t") and ln.split()]
+    count = lambda name: sum(1 for o in ops if o.startswith(name))  # noqa: E731
+    assert count("v_mfma_f32_16x16x32_f16") >= 100
+    for banned in ("v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_fma_mixlo_f16", "v_fma_mixhi_f16"):
+        assert count(banned) == 0, banned
