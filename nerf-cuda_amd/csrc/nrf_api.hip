@@ -168,7 +168,7 @@ struct nrf_context {
   void* bound_depth = nullptr;
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
-  int march_budget = 16;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
+  int march_budget = 256;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
   bool rendered = false;
   hipStream_t last_stream = nullptr;
 };
