@@ -105,7 +105,8 @@ def test_frame_fingerprints_unchanged():
         c.set_resolution(W, H)
         c.render(syn.default_camera(W, H), syn.orbit_pose(float(az), float(el), radius=float(radius)))
         rgba, depth = c.read_f32()
-        assert c.stats().n_samples == int(n_samples), row
+        # the count of evaluated samples depends on the batching (speculation past a ray's end), the picture does not
+        assert abs(c.stats().n_samples - int(n_samples)) <= 0.02 * int(n_samples) + 64, row
         assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
         assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, row
     c.close()
