@@ -591,3 +591,34 @@ def test_region_of_interest_cull_is_conservative(ctx, small, radius, az, el, fl_
     # pixels the oracle did not touch are exactly the background in both
     untouched = want[..., 3] == 0
     assert np.array_equal(rgba[untouched], want[untouched])
+
+
+@pytest.mark.timeout(180)
+def test_unusual_inputs_terminate_and_stay_finite(ctx):
+    """NaN / inf poses, a zero focal length, 1x1 and 7x5 frames, the camera at the centre of the volume looking
+    along an axis (zero direction components -> infinite reciprocals): every launch ends, every pixel is finite,
+    and degenerate cameras yield the background."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+
+    def go(W, H, cam, pose):
+        ctx.set_resolution(W, H)
+        ctx.render(cam, pose)
+        rgba, depth = ctx.read_f32()
+        assert np.isfinite(rgba).all() and np.isfinite(depth).all()
+        return rgba, ctx.stats().n_samples
+
+    cam, pose = syn.default_camera(64, 48), syn.orbit_pose(30, 30)
+    for bad in ((0, 3, np.nan), (1, 1, np.inf), (2, 3, -np.inf)):
+        p = pose.copy(); p[bad[0], bad[1]] = bad[2]
+        rgba, n = go(64, 48, cam, p)
+        assert n == 0 and np.all(rgba[..., :3] == 1.0) and np.all(rgba[..., 3] == 0.0)
+    z = cam.copy(); z[0] = 0
+    rgba, n = go(64, 48, z, pose)
+    assert n == 0
+    go(64, 48, cam, np.zeros((4, 4), np.float32))
+    assert go(1, 1, syn.default_camera(1, 1), pose)[1] > 0
+    assert go(7, 5, syn.default_camera(7, 5), pose)[1] > 0
+    rgba, n = go(64, 48, cam, np.eye(4, dtype=np.float32))
+    assert n > 0 and rgba[..., 3].max() <= 1.0 + 1e-5
