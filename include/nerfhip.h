@@ -216,6 +216,9 @@ int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
 int nrf_set_max_views(nrf_context* ctx, int max_views);
 int nrf_render_views(nrf_context* ctx, int n_views, const float* cams, const float* poses,
                      void* stream, nrf_frame* out);
+/* SURVEY.md 8(b) lists this entry point as nrf_render_batch: same function.   */
+int nrf_render_batch(nrf_context* ctx, int n_views, const float* cams, const float* poses,
+                     void* stream, nrf_frame* out);
 /* Binds caller-owned device buffers (e.g. a render buffer's RGBA plane or a
  * torch tensor) as the target of subsequent nrf_render calls: rgba float
  * [n_px][4], depth float [n_px], n_px as nrf_frame describes.  NULL, NULL

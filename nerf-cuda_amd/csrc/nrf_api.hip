@@ -721,6 +721,10 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   return NRF_OK;
 }
 
+int nrf_render_batch(nrf_context* c, int n_views, const float* cams, const float* poses, void* stream, nrf_frame* out) {
+  return nrf_render_views(c, n_views, cams, poses, stream, out);
+}
+
 int nrf_render(nrf_context* c, const float cam[4], const float pose[16], void* stream, nrf_frame* out) {
   if (!cam || !pose) return fail(NRF_E_INVALID, "null argument");
   return nrf_render_views(c, 1, cam, pose, stream, out);

@@ -142,6 +142,8 @@ _SIGS = {
     "nrf_set_max_views": (C.c_int, [C.c_void_p, C.c_int]),
     "nrf_render_views": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
                                    C.POINTER(Frame)]),
+    "nrf_render_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
+                                   C.POINTER(Frame)]),
     "nrf_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
