@@ -577,6 +577,13 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   };
+  for (LevelParams& L : lp) {  // byte-offset constants of level_gather
+    const bool hashed_pow2 = L.mode == LV_HASH_POW2;
+    L.off_b = L.offset << 2;
+    L.my_b = hashed_pow2 ? (2654435761u << 2) : (L.res << 2);
+    L.mz_b = hashed_pow2 ? (805459861u << 2) : ((L.res * L.res) << 2);
+    L.mask_b = hashed_pow2 ? ((L.size - 1) << 2) : 0xffffffffu;
+  }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));

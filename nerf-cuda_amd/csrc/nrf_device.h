@@ -44,8 +44,14 @@ struct LevelParams {
   uint32_t size;    // entries in the level ("hashmap_size")
   uint32_t mode;    // LV_*
   uint32_t hashed;  // grid_type == Hash (for LV_GENERIC)
+  // per-level constants of the byte-offset index arithmetic (level_gather), precomputed on the host:
+  uint32_t off_b;   // offset << 2
+  uint32_t my_b;    // y stride in bytes: LV_DENSE res << 2, LV_HASH_POW2 2654435761 << 2
+  uint32_t mz_b;    // z stride in bytes: LV_DENSE (res * res) << 2, LV_HASH_POW2 805459861 << 2
+  uint32_t mask_b;  // LV_HASH_POW2 (size - 1) << 2, else 0xffffffff
   uint32_t pad0, pad1;
 };
+static_assert(sizeof(LevelParams) == 48, "LevelParams layout");
 
 // MFMA weight fragments, packed on the host (nrf_model.cpp: pack_fragments):
 // one fragment = 64 lanes x 8 halves (1 KiB), lane l, element j holds
@@ -445,7 +451,7 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   // into the per-axis terms ((a ^ b ^ d) << 2 == (a<<2) ^ (b<<2) ^ (d<<2), (g * P) << 2 == g * (P << 2)
   // mod 2^32); nrf_load_model rejects tables of 4 GiB or more.
   uint32_t off[8];
-  const uint32_t level_off = L.offset << 2;
+  const uint32_t level_off = L.off_b;
   if (GENERIC && L.mode == LV_GENERIC) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -462,9 +468,9 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   } else {
     // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
     const bool hashed = UNI == 2 || (UNI == 0 && L.mode == LV_HASH_POW2);
-    const uint32_t my = hashed ? (2654435761u << 2) : (L.res << 2);
-    const uint32_t mz = hashed ? (805459861u << 2) : ((L.res * L.res) << 2);
-    const uint32_t mask = hashed ? ((L.size - 1) << 2) : 0xffffffffu;
+    const uint32_t my = UNI == 2 ? (2654435761u << 2) : L.my_b;
+    const uint32_t mz = UNI == 2 ? (805459861u << 2) : L.mz_b;
+    const uint32_t mask = UNI == 1 ? 0xffffffffu : L.mask_b;
     const uint32_t ax0 = (gx << 2) + (hashed ? 0u : level_off);  // dense: the level offset rides on the x term
     const uint32_t ax[2] = {ax0, ax0 + 4u};
     const uint32_t ay0 = gy * my, az0 = gz * mz;
