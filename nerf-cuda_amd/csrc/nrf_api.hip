@@ -556,9 +556,11 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   // res^2 + res + 1 copies of its first entries so that x + y*res + z*res^2 (at most
   // size + res^2 + res when a +1 corner sits on the x = 1 / y = 1 / z = 1 face) needs no modulo.
   std::vector<_Float16> grid16;
-  grid16.reserve(n_grid + 2 * 16 * 4096);
+  grid16.reserve(n_grid + 2 * 16 * 4096 + 2 * ((size_t)1 << d->log2_hashmap_size));
   for (uint32_t l = 0; l < 16; ++l) {
     LevelParams& L = lp[l];
+    if (L.mode == LV_HASH_POW2)  // aligned to its own (power-of-two) size: `hash & mask | offset` (level_gather, UNI == 2)
+      while ((grid16.size() / 2) % L.size != 0) grid16.push_back((_Float16)0.0f);
     L.offset = (uint32_t)(grid16.size() / 2);
     const float* src = gp + (size_t)lv.offset[l] * 2;
     for (size_t i = 0; i < (size_t)L.size * 2; ++i) grid16.push_back((_Float16)src[i]);

@@ -476,6 +476,17 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
     const uint32_t ay0 = gy * my, az0 = gz * mz;
     const uint32_t ay[2] = {ay0, ay0 + my};
     const uint32_t az[2] = {az0, az0 + mz};
+    if (UNI == 2) {
+      // power-of-two hashed levels start at a multiple of their size (nrf_load_model), so the level offset has no
+      // bit in common with the mask: ((a ^ b ^ d) & mask) + off == ((a & mask) | off) ^ ((b ^ d) & mask) -- the
+      // masking moves from the 8 corners to 2 + 4 per-axis terms
+      const uint32_t am[2] = {(ax[0] & mask) | level_off, (ax[1] & mask) | level_off};
+      uint32_t bd[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bd[q] = (ay[q & 1] ^ az[q >> 1]) & mask;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) off[c] = am[c & 1] ^ bd[c >> 1];
+    } else
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
