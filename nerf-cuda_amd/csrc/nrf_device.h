@@ -486,16 +486,19 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
       for (int q = 0; q < 4; ++q) bd[q] = (ay[q & 1] ^ az[q >> 1]) & mask;
 #pragma unroll
       for (int c = 0; c < 8; ++c) off[c] = am[c & 1] ^ bd[c >> 1];
-    } else
+    } else if (UNI == 1) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint32_t a = ax[c & 1], b = ay[(c >> 1) & 1], d = az[(c >> 2) & 1];
-      if (UNI == 1) off[c] = a + b + d;
-      else if (UNI == 2) off[c] = ((a ^ b ^ d) & mask) + level_off;
-      else {  // per-lane choice as a bit select (v_bfi_b32): a ?: here compiles to divergent branches
-        const uint32_t pick = hashed ? 0xffffffffu : 0u;
-        const uint32_t hsh = ((a ^ b ^ d) & mask) + level_off, lin = a + b + d;
-        off[c] = (hsh & pick) | (lin & ~pick);
+      for (int c = 0; c < 8; ++c) off[c] = ax[c & 1] + ay[(c >> 1) & 1] + az[(c >> 2) & 1];
+    } else {
+      // lanes of one instruction mix dense and hashed levels: both 2-term forms, one v_cndmask per corner
+      // (ax already carries the level offset for dense lanes; hashed levels are aligned, see above)
+      const uint32_t am[2] = {(ax[0] & mask) | level_off, (ax[1] & mask) | level_off};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t b = ay[q & 1], d = az[q >> 1];
+        const uint32_t bd_x = (b ^ d) & mask, bd_s = b + d;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) off[2 * q + e] = hashed ? (am[e] ^ bd_x) : (ax[e] + bd_s);
       }
     }
   }
