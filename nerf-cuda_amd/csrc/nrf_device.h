@@ -339,10 +339,12 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     int level = 0;
     int nx, ny, nz;
     if (UNIT) {
-      // mip_bound == 1: (x * 1 + 1) == (x + 1); H = 2^k: (0.5f * v) * H == v * (0.5f * H), no rounding
-      nx = (int)clamp3((x + 1) * c.halfH, 0.0f, c.Hm1);
-      ny = (int)clamp3((y + 1) * c.halfH, 0.0f, c.Hm1);
-      nz = (int)clamp3((z + 1) * c.halfH, 0.0f, c.Hm1);
+      // mip_bound == 1: (x * 1 + 1) == (x + 1); H = 2^k: (0.5f * v) * H == v * (0.5f * H), no rounding; and
+      // round(x + 1) * 2^j == round(x * 2^j + 2^j) (scaling by a power of two commutes with rounding), so the
+      // add and the multiply are ONE fused multiply-add with the same value as the reference's three operations
+      nx = (int)clamp3(__builtin_fmaf(x, c.halfH, c.halfH), 0.0f, c.Hm1);
+      ny = (int)clamp3(__builtin_fmaf(y, c.halfH, c.halfH), 0.0f, c.Hm1);
+      nz = (int)clamp3(__builtin_fmaf(z, c.halfH, c.halfH), 0.0f, c.Hm1);
     } else {
       float mip_bound = fminf(1.0f, c.bound), mip_rbound;
       if (c.C > 1) {
