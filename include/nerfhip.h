@@ -247,7 +247,7 @@ int nrf_read_view_u8(nrf_context* ctx, int view, uint8_t* rgb, uint8_t* depth);
  * [n_tiles*64] (tile-major when shard_count > 1, else the row-major frame).  */
 int nrf_read_shard_f32(nrf_context* ctx, float* rgba, float* depth);
 /* Rearranges gathered tile-major shards ([shard][n_tiles_max][64][C] floats,
- * as produced by an all-gather of every rank's nrf_frame buffer) into a
+ * as produced by a gather of every rank's nrf_frame buffer) into a
  * row-major [H][W][C] image on the device.  Replaces the de-interleave loop
  * nerf_render.cu:352-359.                                                    */
 int nrf_untile(nrf_context* ctx, const void* gathered, int shard_count,

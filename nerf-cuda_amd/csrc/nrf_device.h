@@ -131,7 +131,7 @@ struct FrameParams {
   int tile_major;
   float bg_color, min_near, dt_gamma, density_scale;
   int max_steps;
-  int march_budget;  // cell trips a lane may spend per round (tuning knob, default 16)
+  int march_budget;  // cell trips a lane may spend per round (tuning knob, default 256)
 };
 
 // ------------------------------------------------------------------ misc ----
