@@ -20,15 +20,19 @@
 namespace nrf {
 
 // ---------------------------------------------------------------- LDS map ----
+#ifndef NRF_SLOTS
+#define NRF_SLOTS 64
+#endif
+constexpr int SLOTS = NRF_SLOTS;  // sample slots a wave fills per round
 struct WaveLds {
   union {
-    float4 pos[64];      // sample slot before the network phase: x, y, z (world, clamped), ray lane (bit pattern)
-    float4 out[64];      // sample slot after it: r, g, b, sigma (each lane overwrites only slots it has consumed)
+    float4 pos[SLOTS];   // sample slot before the network phase: x, y, z (world, clamped), ray lane (bit pattern)
+    float4 out[SLOTS];   // sample slot after it: r, g, b, sigma (each lane overwrites only slots it has consumed)
   };
-  float2 aux[64];        // sample slot: dt, composited t
+  float2 aux[SLOTS];     // sample slot: dt, composited t
   uint32_t dirf[64][8];  // ray lane: 16 fp16 direction-encoding values
 };
-static_assert(sizeof(WaveLds) == 3584, "WaveLds layout");
+static_assert(sizeof(WaveLds) == 2048 + 24 * SLOTS, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     bool ended = false;  // t >= far or sample cap: the ray dies after compositing this round's samples
     for (int k = 0; k < 8; ++k) {
       const unsigned long long mm = __ballot(marching);
-      if (mm == 0ull || S + __popcll(mm) > 64) break;
+      if (mm == 0ull || S + __popcll(mm) > SLOTS) break;
       float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
       bool found = false;
 #ifdef NRF_PHASE_TIMING
