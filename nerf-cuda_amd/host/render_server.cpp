@@ -9,6 +9,9 @@
 // render_frames call (one launch of the fused kernel).  Requests that arrive while a batch renders
 // form the next batch, so batching needs no timer and a lone client sees no added latency
 // (BASELINE config 5: many concurrent camera requests).
+// Extended request (optional, same connection): the 4 bytes "NRF1", u32 n, then n x {f32 cam[4] = fl_x, fl_y,
+// cx, cy; f32 pose[16]}; the answer is n images of 3*W*H bytes in request order.  A raw 64-byte pose keeps
+// meaning what it means to the reference's clients.
 //   usage: render_server [port=12345] [snapshot=./freality.msgpack] [width height]
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -57,6 +60,7 @@ static bool write_n(int fd, const void* buf, size_t n) {
 namespace {
 
 struct Request {
+  Camera cam;
   Matrix4f pose;
   std::vector<unsigned char> rgb;  // filled by the render thread
   bool done = false, failed = false;
@@ -73,7 +77,7 @@ struct Batcher {
 };
 
 // the one thread that owns the renderer
-void render_loop(NerfRender& render, const Camera cam, const size_t frame_bytes, Batcher& b) {
+void render_loop(NerfRender& render, const size_t frame_bytes, Batcher& b) {
   while (true) {
     std::vector<std::shared_ptr<Request>> batch;
     {
@@ -87,9 +91,12 @@ void render_loop(NerfRender& render, const Camera cam, const size_t frame_bytes,
     }
     bool ok = true;
     try {
-      std::vector<Camera> cams(batch.size(), cam);
+      std::vector<Camera> cams;
       std::vector<Matrix4f> poses;
-      for (const auto& r : batch) poses.push_back(r->pose);
+      for (const auto& r : batch) {
+        cams.push_back(r->cam);
+        poses.push_back(r->pose);
+      }
       const std::vector<Image> imgs = render.render_frames(cams, poses);
       for (size_t i = 0; i < batch.size(); ++i) batch[i]->rgb.assign(imgs[i].rgb, imgs[i].rgb + frame_bytes);
     } catch (const std::exception& e) {
@@ -107,7 +114,27 @@ void render_loop(NerfRender& render, const Camera cam, const size_t frame_bytes,
   }
 }
 
-void serve_client(int sock, const std::string peer, const size_t frame_bytes, Batcher& b, int srv) {
+std::shared_ptr<Request> submit(Batcher& b, const Camera& cam, const float pose[16]) {
+  auto req = std::make_shared<Request>();
+  req->cam = cam;
+  for (int i = 0; i < 16; ++i) req->pose.m[i] = pose[i];
+  {
+    std::lock_guard<std::mutex> lk(b.m);
+    b.queue.push_back(req);
+  }
+  b.cv.notify_one();
+  return req;
+}
+
+bool wait_and_send(int sock, const std::shared_ptr<Request>& req, size_t frame_bytes) {
+  {
+    std::unique_lock<std::mutex> lk(req->m);
+    req->cv.wait(lk, [&] { return req->done; });
+  }
+  return !req->failed && write_n(sock, req->rgb.data(), frame_bytes);
+}
+
+void serve_client(int sock, const std::string peer, const Camera default_cam, const size_t frame_bytes, Batcher& b, int srv) {
   std::cout << "Received a connection request from " << peer << std::endl;
   float nerf_pos[16] = {0};
   while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
@@ -119,18 +146,25 @@ void serve_client(int sock, const std::string peer, const size_t frame_bytes, Ba
       ::shutdown(srv, SHUT_RDWR);  // wakes the acceptor
       break;
     }
-    auto req = std::make_shared<Request>();
-    for (int i = 0; i < 16; ++i) req->pose.m[i] = nerf_pos[i];
-    {
-      std::lock_guard<std::mutex> lk(b.m);
-      b.queue.push_back(req);
+    if (std::memcmp(nerf_pos, "NRF1", 4) == 0) {  // extended request: the 64 bytes read so far are its first 64
+      uint32_t n = 0;
+      std::memcpy(&n, (const char*)nerf_pos + 4, 4);
+      if (n == 0 || n > 4096) break;
+      std::vector<float> body((size_t)n * 20);
+      const size_t have = sizeof(nerf_pos) - 8, need = body.size() * sizeof(float);
+      std::memcpy(body.data(), (const char*)nerf_pos + 8, have < need ? have : need);
+      if (need > have && !read_n(sock, (char*)body.data() + have, need - have)) break;
+      std::vector<std::shared_ptr<Request>> reqs;
+      for (uint32_t v = 0; v < n; ++v) {
+        const float* r = body.data() + (size_t)v * 20;
+        reqs.push_back(submit(b, Camera{r[0], r[1], r[2], r[3]}, r + 4));  // all queued before the first wait: one batch
+      }
+      bool ok = true;
+      for (const auto& r : reqs) ok = ok && wait_and_send(sock, r, frame_bytes);
+      if (!ok) break;
+      continue;
     }
-    b.cv.notify_one();
-    {
-      std::unique_lock<std::mutex> lk(req->m);
-      req->cv.wait(lk, [&] { return req->done; });
-    }
-    if (req->failed || !write_n(sock, req->rgb.data(), frame_bytes)) break;
+    if (!wait_and_send(sock, submit(b, default_cam, nerf_pos), frame_bytes)) break;
   }
   std::cout << "Connection closed" << std::endl;
   ::close(sock);
@@ -163,7 +197,7 @@ int main(int argc, char** argv) {
       return 1;
     }
     Batcher batcher;
-    std::thread renderer(render_loop, std::ref(render), cam, frame_bytes, std::ref(batcher));
+    std::thread renderer(render_loop, std::ref(render), frame_bytes, std::ref(batcher));
     std::vector<std::thread> clients;
     std::cout << "Awaiting connections on port " << port << "..." << std::endl;
     while (!batcher.stop.load()) {
@@ -176,7 +210,7 @@ int main(int argc, char** argv) {
         continue;
       }
       ::setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      clients.emplace_back(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), frame_bytes, std::ref(batcher), srv);
+      clients.emplace_back(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, frame_bytes, std::ref(batcher), srv);
     }
     batcher.stop = true;
     batcher.cv.notify_all();

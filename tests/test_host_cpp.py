@@ -136,6 +136,20 @@ def test_render_server_wire_protocol(snapshot):
             ctx.render(cam, pose)
             rgb8, _ = ctx.read_u8()
             np.testing.assert_array_equal(np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3), rgb8)
+        # extended request on the same connection: "NRF1", u32 n, n x {cam[4], pose[16]}: one launch, per-view intrinsics
+        views = [(cam * np.float32(1.0 + 0.1 * i), syn.orbit_pose(70.0 * i, 15.0 + 5 * i)) for i in range(3)]
+        msg = b"NRF1" + np.uint32(len(views)).tobytes()
+        for c, p in views:
+            msg += np.ascontiguousarray(c, np.float32).tobytes() + np.ascontiguousarray(p, np.float32).tobytes()
+        sock.sendall(msg)
+        for c, p in views:
+            buf = bytearray()
+            while len(buf) < 3 * W * H:
+                chunk = sock.recv(3 * W * H - len(buf))
+                assert chunk, "connection closed early"
+                buf += chunk
+            ctx.render(c, p)
+            np.testing.assert_array_equal(np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3), ctx.read_u8()[0])
         quit_msg = np.zeros(16, np.float32)
         quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
         sock.sendall(quit_msg.tobytes())
