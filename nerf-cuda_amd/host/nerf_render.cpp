@@ -122,16 +122,56 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
   d.cascade = (uint32_t)snapshot.value("cascade", 1);
   d.density_grid_size = (uint32_t)snapshot.value("density_grid_size", 128);
   d.mean_density = snapshot.value("mean_density", 1.e-4f);
-  const mpk::Value& grid = snapshot.at("density_grid");
-  if (grid.type != mpk::Value::NumArray) throw std::runtime_error{"snapshot.density_grid must be an array of numbers"};
-  m_density_grid = grid.nums;
+  // The reference reads `params` / `density_grid` as msgpack arrays of numbers (nerf_render.cu:447-466).  Accepted in
+  // addition (instant-ngp's snapshot convention): `params_binary` / `density_grid_binary` = the same values, same
+  // order, as one raw little-endian blob of `params_type` / `density_grid_type` "__half" (default) or "float".
+  auto numbers = [&](const char* key, const char* what) -> std::vector<float> {
+    if (snapshot.contains(key)) {
+      const mpk::Value& v = snapshot.at(key);
+      if (v.type != mpk::Value::NumArray) throw std::runtime_error{std::string("snapshot.") + what + " must be an array of numbers"};
+      return v.nums;
+    }
+    const std::string bkey = std::string(key) + "_binary", tkey = std::string(key) + "_type";
+    if (!snapshot.contains(bkey.c_str())) throw std::runtime_error{std::string("snapshot.") + what + " is missing"};
+    const mpk::Value& b = snapshot.at(bkey.c_str());
+    if (b.type != mpk::Value::Bin) throw std::runtime_error{"snapshot." + bkey + " must be a binary blob"};
+    const std::string type = snapshot.value(tkey.c_str(), "__half");
+    std::vector<float> out;
+    if (type == "float") {
+      if (b.str.size() % 4) throw std::runtime_error{"snapshot." + bkey + ": size is not a multiple of 4"};
+      out.resize(b.str.size() / 4);
+      std::memcpy(out.data(), b.str.data(), b.str.size());
+    } else if (type == "__half" || type == "half") {
+      if (b.str.size() % 2) throw std::runtime_error{"snapshot." + bkey + ": size is not a multiple of 2"};
+      out.resize(b.str.size() / 2);
+      for (size_t i = 0; i < out.size(); ++i) {
+        uint16_t h;
+        std::memcpy(&h, b.str.data() + 2 * i, 2);
+        const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+        uint32_t bits;
+        if (e == 0) {
+          if (m == 0) bits = sign;
+          else {  // subnormal half: normalise
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 1024u)) { mm <<= 1; ++sh; }
+            bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13);
+          }
+        } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+        else bits = sign | ((e + 112u) << 23) | (m << 13);
+        std::memcpy(&out[i], &bits, 4);
+      }
+    } else {
+      throw std::runtime_error{"snapshot." + tkey + ": unknown element type '" + type + "'"};
+    }
+    return out;
+  };
+  m_density_grid = numbers("density_grid", "density_grid");
   const uint64_t H = d.density_grid_size;
   if (m_density_grid.size() != H * H * H * d.cascade) {
     throw std::runtime_error{"Incompatible number of grid cascades."};
   }
-  const mpk::Value& params = snapshot.at("params");
-  if (params.type != mpk::Value::NumArray) throw std::runtime_error{"snapshot.params must be an array of numbers"};
-  m_params = params.nums;
+  m_params = numbers("params", "params");
   m_network_config_path = filepath_string;
   m_network_config = std::move(config);
   m_have_snapshot = true;

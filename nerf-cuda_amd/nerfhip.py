@@ -337,11 +337,18 @@ def desc_from_config(config: dict, params: np.ndarray | None = None, density_gri
     else:
         raise NotImplementedError(f"dir encoding '{ot}' is outside the hot path")
 
-    p = np.ascontiguousarray(params if params is not None else np.asarray(snap["params"], dtype=np.float32),
-                             dtype=np.float32)
-    g = np.ascontiguousarray(
-        density_grid if density_grid is not None else np.asarray(snap["density_grid"], dtype=np.float32),
-        dtype=np.float32)
+    def numbers(key):
+        """`key` as an array of numbers (the reference's format) or `key_binary` + `key_type` (instant-ngp's)."""
+        if key in snap:
+            return np.asarray(snap[key], dtype=np.float32)
+        blob = snap[key + "_binary"]
+        kind = snap.get(key + "_type", "__half")
+        if kind not in ("__half", "half", "float"):
+            raise RuntimeError(f"snapshot.{key}_type: unknown element type '{kind}'")
+        return np.frombuffer(blob, np.float32 if kind == "float" else np.float16).astype(np.float32)
+
+    p = np.ascontiguousarray(params if params is not None else numbers("params"), dtype=np.float32)
+    g = np.ascontiguousarray(density_grid if density_grid is not None else numbers("density_grid"), dtype=np.float32)
     d.params = p.ctypes.data_as(C.POINTER(C.c_float))
     d.n_params = p.size
     d.density_grid = g.ctypes.data_as(C.POINTER(C.c_float))

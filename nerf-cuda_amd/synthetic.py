@@ -175,14 +175,25 @@ REFERENCE_MAIN_POSE = np.array([  # the hard-coded pose of reference src/main.cu
     [0.0, 0.0, 0.0, 1.0]], np.float32)
 
 
-def write_snapshot(path, config, params, density_grid):
+def write_snapshot(path, config, params, density_grid, binary=None):
     """Writes a snapshot in the format the reference consumes: msgpack of a
     JSON object whose `snapshot.params` / `snapshot.density_grid` are plain arrays of numbers
-    (float32 on the wire)."""
+    (float32 on the wire).  binary="__half" | "float": instant-ngp's convention instead -- the same values
+    as raw blobs `params_binary` / `density_grid_binary` with `params_type` / `density_grid_type`."""
     import msgpack
 
     cfg = {k: v for k, v in config.items() if k != "snapshot"}
     snap = dict(config["snapshot"])
+    if binary:
+        dt = np.float16 if binary == "__half" else np.float32
+        snap["params_binary"] = np.asarray(params, np.float32).astype(dt).tobytes()
+        snap["params_type"] = binary
+        snap["density_grid_binary"] = np.asarray(density_grid, np.float32).astype(dt).tobytes()
+        snap["density_grid_type"] = binary
+        cfg["snapshot"] = snap
+        with open(path, "wb") as f:
+            f.write(msgpack.packb(cfg, use_single_float=True, use_bin_type=True))
+        return
     snap["params"] = np.asarray(params, np.float32).tolist()
     snap["density_grid"] = np.asarray(density_grid, np.float32).tolist()
     cfg["snapshot"] = snap

@@ -232,3 +232,40 @@ def test_render_server_batches_concurrent_clients(snapshot):
     finally:
         if srv.poll() is None:
             srv.kill()
+
+
+def test_binary_snapshot_blobs_cpp_and_python(tmp_path, snapshot):
+    """`params_binary` / `density_grid_binary` (+ `*_type` "__half" | "float": instant-ngp's convention) carry the
+    same values in the same order as the reference's arrays of numbers; the C++ loader and the Python one agree
+    on every element (order-dependent checksums), and fp32 blobs reproduce the array form exactly."""
+    path, desc, keep, cfg = snapshot
+    params, grid = keep
+
+    def checksums(p, g):
+        w = (np.arange(p.size, dtype=np.float64) % 97) + 1
+        v = (np.arange(g.size, dtype=np.float64) % 89) + 1
+        return float((p.astype(np.float64) * w).sum()), float((g.astype(np.float64) * v).sum())
+
+    base = json.loads(_info(path).stdout.strip().splitlines()[-1])
+    for kind, cast in (("float", np.float32), ("__half", np.float16)):
+        f = tmp_path / f"bin_{kind}.msgpack"
+        syn.write_snapshot(f, cfg, params, grid, binary=kind)
+        assert f.stat().st_size < path.stat().st_size
+        r = _info(f)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        want_p, want_g = checksums(params.astype(cast).astype(np.float32), grid.astype(cast).astype(np.float32))
+        assert d["n_params"] == params.size and d["n_grid"] == grid.size and d["rc"] == 0
+        assert abs(d["psum"] - want_p) <= 1e-9 * abs(want_p) and abs(d["gsum"] - want_g) <= 1e-9 * max(abs(want_g), 1.0)
+        if kind == "float":
+            assert d["psum"] == base["psum"] and d["gsum"] == base["gsum"]
+        d2, keep2 = nh.desc_from_config(syn.read_snapshot(f))
+        np.testing.assert_array_equal(keep2[0], params.astype(cast).astype(np.float32))
+        np.testing.assert_array_equal(keep2[1], grid.astype(cast).astype(np.float32))
+    # unknown element type / odd blob sizes are errors, not guesses
+    import msgpack
+    bad = syn.read_snapshot(tmp_path / "bin_float.msgpack")
+    bad["snapshot"]["params_type"] = "double"
+    (tmp_path / "bad.msgpack").write_bytes(msgpack.packb(bad, use_single_float=True, use_bin_type=True))
+    r = _info(tmp_path / "bad.msgpack")
+    assert r.returncode == 1 and "unknown element type" in r.stderr
