@@ -9,7 +9,7 @@ compositing -> RGBA/depth in HBM, all inside ONE launch of the fused gfx950
 kernel per rank (nrf_render_views; --views-per-step 1 gives one frame per step).
 The views of a batch are independent frames: batching only lets the workgroups
 of view v+1 take the wave slots that the few long-lived tiles of view v leave
-idle (one frame alone: 1.35 ms; in a batch: 0.90 ms per frame).  With N ranks
+idle (one frame alone: 1.0 ms; in a batch: 0.83 ms per frame).  With N ranks
 every frame's tile strips are dealt round-robin to the ranks (strong scaling of
 the same frames), two steps are in flight, every rank quantises its shard to
 the reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only exchange
@@ -266,8 +266,9 @@ def main():
     # PMC passes cannot run inside this process: the counters of the same command are read from the committed summary
     if world == 1 and (W, H) == (WIDTH, HEIGHT) and V == DEFAULT_VIEWS and tfile.exists():
         pmc = json.loads(tfile.read_text())
-        traffic = pmc["hbm_bytes_per_launch"]
-        valu = pmc.get("valu_insts_per_launch")
+        if pmc.get("views_per_launch") == V:  # counters of exactly this launch shape
+            traffic = pmc["hbm_bytes_per_launch"]
+            valu = pmc.get("valu_insts_per_launch")
     out = {
         "metric": "megasamples/s (network-evaluated march samples), Lego-like NeRF render @1920x1080",
         "value": round(msamples_s, 2),

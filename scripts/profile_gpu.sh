@@ -10,7 +10,7 @@ BENCH="python3 $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
 OLDPWD=$PWD
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
-python3 "$OLDPWD/scripts/trace_summary.py" "$OUT"/stats/*/*_kernel_trace.csv 2 8 > "$OUT/trace_summary.txt" 2>&1 || true
+python3 "$OLDPWD/scripts/trace_summary.py" "$OUT"/stats/*/*_kernel_trace.csv 2 8 16 > "$OUT/trace_summary.txt" 2>&1 || true
 # PMC passes: counters in their own runs (no trace flags), a few per pass
 pass() { n=$1; shift; timeout -k 10 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$n" -- $BENCH > "$OUT/pmc_$n.log" 2>&1; }
 pass fetch FETCH_SIZE
