@@ -299,6 +299,11 @@ int nrf_encode_dir(nrf_context* ctx, const void* dir01, uint32_t n, void* out_f1
  * out fp16 [n][4] = (r,g,b,sigma)                                            */
 int nrf_mlp_forward(nrf_context* ctx, const void* feat_f16, const void* dirfeat_f16,
                     uint32_t n, void* out_f16, void* stream);
+/* Measurement aid: the same call, every chunk of samples evaluated `repeat`
+ * times from registers (identical output): repeat >> 1 gives the rate of the
+ * MFMA chain with its fp32 -> fp16 re-packing, without the HBM stream.       */
+int nrf_mlp_forward_repeat(nrf_context* ctx, const void* feat_f16, const void* dirfeat_f16,
+                           uint32_t n, void* out_f16, uint32_t repeat, void* stream);
 /* Whole network on raw march output (world-space xyz in [-bound,bound], unit
  * dirs), including the two affine maps nerf_render.cu:311-314 and
  * decompose (render_utils.h:308-334): -> sigma f32 [n], rgb f32 [n][3]       */

@@ -902,11 +902,17 @@ int nrf_encode_dir(nrf_context* c, const void* dir01, uint32_t n, void* out, voi
   STAGE_EPILOGUE();
 }
 
-int nrf_mlp_forward(nrf_context* c, const void* feat, const void* dirfeat, uint32_t n, void* out, void* stream) {
+int nrf_mlp_forward_repeat(nrf_context* c, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,
+                           void* stream) {
   STAGE_PROLOGUE();
   if (n && (!feat || !dirfeat || !out)) return fail(NRF_E_INVALID, "null argument");
-  HIP_TRY(launch_mlp_forward(c->dm, feat, dirfeat, n, out, st));
+  if (repeat < 1) return fail(NRF_E_INVALID, "repeat must be >= 1");
+  HIP_TRY(launch_mlp_forward(c->dm, feat, dirfeat, n, out, repeat, st));
   STAGE_EPILOGUE();
+}
+
+int nrf_mlp_forward(nrf_context* c, const void* feat, const void* dirfeat, uint32_t n, void* out, void* stream) {
+  return nrf_mlp_forward_repeat(c, feat, dirfeat, n, out, 1, stream);
 }
 
 int nrf_network(nrf_context* c, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, void* stream) {

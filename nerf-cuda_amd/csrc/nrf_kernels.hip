@@ -508,10 +508,10 @@ __global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const
 // while the current one goes through the 80 MFMAs.
 constexpr int LDS_WFRAG_ALL_BYTES = N_FRAGS_ALL * 64 * 16;  // 24576
 constexpr int MLP_TILES = 2;  // 16-sample tiles per trip
-template <bool GEN>
+template <bool GEN, bool REPEAT>
 __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
-                                                          uint2* __restrict__ out) {
+                                                          uint2* __restrict__ out, uint32_t repeat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = reinterpret_cast<uint4*>(smem);
   for (int i = threadIdx.x; i < N_FRAGS_ALL * 64; i += blockDim.x) wl[i] = M.wfrag[i];
@@ -547,6 +547,17 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
     }
     float4_t o[T];
     mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
+    // repeat > 1 (nrf_mlp_forward_repeat): the same rows again from registers -- the rate of the MFMA chain
+    // with its re-packing, without the HBM stream; the empty asm keeps the evaluations from being merged
+    for (uint32_t r = 1; REPEAT && r < repeat; ++r) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        asm volatile("" : "+v"(fv[t].x), "+v"(fv[t].y), "+v"(fv[t].z), "+v"(fv[t].w), "+v"(dv[t].x), "+v"(dv[t].y));
+        f[t] = __builtin_bit_cast(half8_t, fv[t]);
+        df[t] = __builtin_bit_cast(half4_t, dv[t]);
+      }
+      mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
+    }
     if (g == 0) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -783,15 +794,19 @@ hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, v
   return hipGetLastError();
 }
 
-hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, hipStream_t st) {
+hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,
+                              hipStream_t st) {
   if (!n) return hipSuccess;
   const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
-  if (M.generic_act)
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M,
-                       (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
-  else
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M,
-                       (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out);
+#define NRF_LAUNCH_MLP(G, R)                                                                                                \
+  hipLaunchKernelGGL((mlp_forward_kernel<G, R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M, \
+                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out, repeat)
+  if (M.generic_act) {
+    if (repeat > 1) NRF_LAUNCH_MLP(true, true); else NRF_LAUNCH_MLP(true, false);
+  } else {
+    if (repeat > 1) NRF_LAUNCH_MLP(false, true); else NRF_LAUNCH_MLP(false, false);
+  }
+#undef NRF_LAUNCH_MLP
   return hipGetLastError();
 }
 

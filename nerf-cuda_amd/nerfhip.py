@@ -189,6 +189,7 @@ _SIGS = {
     "nrf_encode_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "nrf_encode_dir": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nrf_mlp_forward_repeat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "nrf_network": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_generate_rays": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -483,6 +484,10 @@ class NerfHip:
     def mlp_forward(self, feat, dirfeat, n, out, stream=None):
         _check(self.lib.nrf_mlp_forward(self.h, C.c_void_p(feat), C.c_void_p(dirfeat), n, C.c_void_p(out),
                                         C.c_void_p(stream or 0)))
+
+    def mlp_forward_repeat(self, feat, dirfeat, n, out, repeat, stream=None):
+        _check(self.lib.nrf_mlp_forward_repeat(self.h, C.c_void_p(feat), C.c_void_p(dirfeat), n, C.c_void_p(out), int(repeat),
+                                               C.c_void_p(stream or 0)))
 
     def network(self, xyz, dirs, n, sigma, rgb, stream=None):
         _check(self.lib.nrf_network(self.h, C.c_void_p(xyz), C.c_void_p(dirs), n, C.c_void_p(sigma), C.c_void_p(rgb),
