@@ -546,15 +546,16 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
       df[t] = __builtin_bit_cast(half4_t, dv[t]);
     }
     float4_t o[T];
-    mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
-    // repeat > 1 (nrf_mlp_forward_repeat): the same rows again from registers -- the rate of the MFMA chain
+    // REPEAT (nrf_mlp_forward_repeat): the same rows `repeat` times from registers -- the rate of the MFMA chain
     // with its re-packing, without the HBM stream; the empty asm keeps the evaluations from being merged
-    for (uint32_t r = 1; REPEAT && r < repeat; ++r) {
+    for (uint32_t r = 0; r < (REPEAT ? repeat : 1u); ++r) {
+      if (REPEAT) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        asm volatile("" : "+v"(fv[t].x), "+v"(fv[t].y), "+v"(fv[t].z), "+v"(fv[t].w), "+v"(dv[t].x), "+v"(dv[t].y));
-        f[t] = __builtin_bit_cast(half8_t, fv[t]);
-        df[t] = __builtin_bit_cast(half4_t, dv[t]);
+        for (int t = 0; t < T; ++t) {
+          asm volatile("" : "+v"(fv[t].x), "+v"(fv[t].y), "+v"(fv[t].z), "+v"(fv[t].w), "+v"(dv[t].x), "+v"(dv[t].y));
+          f[t] = __builtin_bit_cast(half8_t, fv[t]);
+          df[t] = __builtin_bit_cast(half4_t, dv[t]);
+        }
       }
       mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
     }
