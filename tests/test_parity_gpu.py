@@ -622,3 +622,33 @@ def test_unusual_inputs_terminate_and_stay_finite(ctx):
     assert go(7, 5, syn.default_camera(7, 5), pose)[1] > 0
     rgba, n = go(64, 48, cam, np.eye(4, dtype=np.float32))
     assert n > 0 and rgba[..., 3].max() <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("H,bound,cascade,dt_gamma", [(30, 1.0, 1, 1.0 / 128), (96, 1.0, 1, 1.0 / 128), (64, 1.5, 2, 0.0),
+                                                      (48, 3.0, 3, 1.0 / 64), (128, 0.75, 1, 1.0 / 128)])
+def test_every_march_instance_matches_oracle(ctx, H, bound, cascade, dt_gamma):
+    """The render kernel picks its march instance from the model: tables in LDS or not (H % 4), the specialised
+    single-cascade / power-of-two instance or the generic one, one visibility walk per cascade, bounds that are
+    not powers of two (mip_bound = min(2^k, bound)), bound < 1, dt_gamma = 0 (constant step).  Frames must match
+    the oracle and the stage march must be bit-exact for each."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=14, H=H, bound=bound, cascade=cascade)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    W, Hh = 88, 56
+    cam, pose = syn.default_camera(W, Hh), syn.orbit_pose(140, 20)
+    opts = nh.default_options()
+    opts.dt_gamma = dt_gamma
+    ro, rd, nr, fr = _rays(ctx, o, W, Hh, cam, pose)
+    n = W * Hh
+    xyzs = torch.empty((n, 4, 3), device="cuda"); dirs = torch.empty((n, 4, 3), device="cuda")
+    deltas = torch.empty((n, 4, 2), device="cuda")
+    ctx.set_options(opts)
+    sync()
+    ctx.march(ro.data_ptr(), rd.data_ptr(), nr.data_ptr(), fr.data_ptr(), n, 4, xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr())
+    wx, wd, wdl = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), 4, opts)
+    np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
+    np.testing.assert_array_equal(deltas.cpu().numpy(), wdl)
+    rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, Hh, cam, pose, opts)
+    assert st.n_samples > 0
+    assert np.abs(rgba - want).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0
+    ctx.set_options(nh.default_options())
