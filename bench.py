@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default (3)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="steps in flight; 0 = default (1 at N = 1, else 2)")
     ap.add_argument("--views-per-step", type=int, default=0,
                     help="camera views rendered by ONE launch per step (nrf_render_views); 0 = default")
     ap.add_argument("--gather-format", choices=("rgbd8", "f32"), default="rgbd8",
