@@ -1,8 +1,8 @@
 // nrf_kernels.hip -- gfx950 kernels of the render hot path and their launchers.
 //
-// render_kernel is the product: ONE launch per frame replaces the reference's
-// host-driven loop of ~15 launches + a blocking D2H copy per march iteration
-// (R/src/nerf_render.cu:269-338).  One wavefront owns one 8x8 pixel tile (64
+// render_kernel is the product: ONE launch per frame -- or per batch of up to
+// 32 camera views -- replaces the reference's host-driven loop of ~15 launches
+// + a blocking D2H copy per march iteration (R/src/nerf_render.cu:269-338).  One wavefront owns one 8x8 pixel tile (64
 // rays) for the tile's whole life:
 //     raygen -> near/far -> { march (ballot/mbcnt sample compaction into LDS)
 //                             -> hash-grid gather + SH -> both MLPs on MFMA
