@@ -570,6 +570,69 @@ class NerfGroup:
         return s
 
 
+class NerfRender:
+    """Python mirror of ngp::NerfRender (reference include/nerf-cuda/nerf_render.h:29-50): the same method names
+    and call order as the reference's testbed (src/main.cu:140-170), on an nrf_group of `n_gpus` devices.
+
+        render = NerfRender()
+        render.reload_network_from_file("snapshot.msgpack")
+        render.set_resolution((1920, 1080))
+        rgb, depth = render.render_frame(cam, pose)          # u8 [H][W][3], u8 [H][W]  (ngp::Image)
+    """
+
+    def __init__(self, n_gpus: int = 1, devices=None):
+        self.group = NerfGroup(list(devices) if devices is not None else list(range(n_gpus)))
+        self.network_config = None
+        self.desc = None
+        self._keep = None
+        self.resolution = None
+
+    def load_network_config(self, path):  # nerf_render.cu:66-91: .json or .msgpack
+        path = str(path)
+        if not os.path.exists(path):
+            raise RuntimeError(f"Network config path {path} does not exist.")
+        if path.lower().endswith(".json"):
+            import json
+
+            with open(path) as f:
+                return json.load(f)
+        import msgpack
+
+        with open(path, "rb") as f:
+            return msgpack.unpackb(f.read(), raw=False)
+
+    def load_snapshot(self, path):  # nerf_render.cu:431-473
+        config = self.load_network_config(path)
+        if "snapshot" not in config:
+            raise RuntimeError(f"File {path} does not contain a snapshot.")
+        self.network_config = config
+
+    def reset_network(self):  # nerf_render.cu:111-184
+        self.desc, self._keep = desc_from_config(self.network_config)
+
+    def reload_network_from_file(self, path):  # nerf_render.cu:93-109
+        self.load_snapshot(path)
+        self.reset_network()
+        self.group.load_model(self.desc)
+
+    def set_resolution(self, resolution):  # nerf_render.cu:186-236
+        self.resolution = (int(resolution[0]), int(resolution[1]))
+        self.group.set_resolution(*self.resolution)
+
+    def render_frame(self, cam, pos):  # nerf_render.cu:238-367
+        return self.render_frames([cam], [pos])[0]
+
+    def render_frames(self, cams, poses):
+        """Batched form: one launch per NRF_MAX_VIEWS cameras and device; [(rgb u8, depth u8), ...]."""
+        if self.desc is None or self.resolution is None:
+            raise RuntimeError("reload_network_from_file and set_resolution must be called first")
+        f = self.group.render_views(cams, poses)
+        return [self.group.read_view_u8(v) for v in range(f.n_views)]
+
+    def close(self):
+        self.group.close()
+
+
 class RenderBuffer:
     """nrf_render_buffer: the presentation chain of the reference's CudaRenderBuffer (same method names)."""
 

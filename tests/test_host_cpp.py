@@ -269,3 +269,27 @@ def test_binary_snapshot_blobs_cpp_and_python(tmp_path, snapshot):
     (tmp_path / "bad.msgpack").write_bytes(msgpack.packb(bad, use_single_float=True, use_bin_type=True))
     r = _info(tmp_path / "bad.msgpack")
     assert r.returncode == 1 and "unknown element type" in r.stderr
+
+
+@pytest.mark.gpu
+def test_python_nerf_render_mirror_matches_cpp_testbed(tmp_path, snapshot):
+    """nerfhip.NerfRender (the reference class's method names on top of nrf_group) produces the testbed's image."""
+    path, desc, keep, cfg = snapshot
+    W, H = 120, 88
+    r = subprocess.run([str(HOST / "testbed"), str(path), str(W), str(H), str(tmp_path) + "/"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    want = np.fromfile(tmp_path / "image.rgb", np.uint8).reshape(H, W, 3)
+    render = nh.NerfRender(devices=[0, 0])  # two members on the one device of this box
+    with pytest.raises(RuntimeError):
+        render.load_snapshot(tmp_path / "missing.msgpack")
+    render.reload_network_from_file(path)
+    render.set_resolution((W, H))
+    s = np.float32(W) / np.float32(500.0)
+    cam = np.array([3550.115 / 8, 3554.515 / 8, 3010.45 / 8, 1996.027 / 8], np.float32) * s
+    rgb, depth = render.render_frame(cam, syn.REFERENCE_MAIN_POSE)
+    np.testing.assert_array_equal(rgb, want)
+    both = render.render_frames([cam, cam], [syn.REFERENCE_MAIN_POSE, syn.orbit_pose(10, 20)])
+    np.testing.assert_array_equal(both[0][0], want)
+    assert both[1][0].shape == (H, W, 3) and not np.array_equal(both[1][0], want)
+    render.close()
