@@ -168,6 +168,8 @@ typedef struct nrf_stats {
   uint64_t n_rays;      /* rays generated by this shard                       */
   uint64_t n_samples;   /* march-emitted samples evaluated by the network     */
   uint64_t n_rounds;    /* sum over wave tiles of march/eval/composite rounds */
+  uint64_t n_network_evals; /* network evaluations including the padding of the
+                           16-sample MFMA tiles (>= n_samples)                 */
   float render_ms;      /* device time of the last nrf_render (hipEvents)     */
 } nrf_stats;
 

@@ -791,7 +791,8 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   s->n_rays = (uint64_t)c->n_local_tiles * 64;
   s->n_samples = cnt[0];
-  s->n_rounds = cnt[1];
+  s->n_rounds = cnt[1] & 0xffffffffull;      // render_kernel packs two sums into one atomic
+  s->n_network_evals = cnt[1] >> 32;
   s->render_ms = ms;
   return NRF_OK;
 }

@@ -249,6 +249,7 @@ int nrf_group_get_stats(nrf_group* g, nrf_stats* s) {
     s->n_rays += m.n_rays;
     s->n_samples += m.n_samples;
     s->n_rounds += m.n_rounds;
+    s->n_network_evals += m.n_network_evals;
     if (m.render_ms > s->render_ms) s->render_ms = m.render_ms;  // members run concurrently
   }
   return NRF_OK;

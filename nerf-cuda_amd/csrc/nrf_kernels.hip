@@ -214,7 +214,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
-  unsigned n_tile_slots = 0, n_lane_trips = 0, n_wave_iters = 0;
+  unsigned n_lane_trips = 0, n_wave_iters = 0;
 #endif
   NRF_STAMP(t_begin);
   // ---- ray generation + aabb
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   NRF_STAMP(t_setup_done);
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
   int n_ray_samples = 0;
-  unsigned n_samples = 0, n_rounds = 0;
+  unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;  // slots: 16-sample MFMA tiles evaluated x 16 (padding included)
 
   while (true) {
     if (__ballot(alive) == 0ull) break;
@@ -415,9 +415,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     NRF_ACC(c_comp, t2, t3);
     n_samples += (unsigned)S;
     n_rounds++;
-#ifdef NRF_PHASE_TIMING
     n_tile_slots += (unsigned)((S + 15) & ~15);
-#endif
   }
 
   // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
@@ -436,7 +434,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   counters += (blockIdx.x % COUNTER_SLOTS) * 16;  // see COUNTER_SLOTS
   if (lane == 0 && n_rounds != 0) {           // waves that never sampled (background) add nothing
     atomicAdd(&counters[0], (unsigned long long)n_samples);
-    atomicAdd(&counters[1], (unsigned long long)n_rounds);
+    atomicAdd(&counters[1], (unsigned long long)n_rounds | ((unsigned long long)n_tile_slots << 32));  // one atomic, two sums
   }
 #ifdef NRF_PHASE_TIMING
   if (lane == 0) {
@@ -446,7 +444,6 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
     atomicAdd(&counters[4], c_comp);
     atomicAdd(&counters[5], t_end - t_begin);
     atomicAdd(&counters[6], 1ull);
-    atomicAdd(&counters[7], (unsigned long long)n_tile_slots);
     atomicAdd(&counters[9], (unsigned long long)n_wave_iters);
     atomicAdd(&counters[10], t_setup_done - t_begin);
   }

@@ -106,6 +106,7 @@ class Stats(C.Structure):
         ("n_rays", C.c_uint64),
         ("n_samples", C.c_uint64),
         ("n_rounds", C.c_uint64),
+        ("n_network_evals", C.c_uint64),
         ("render_ms", C.c_float),
     ]
 

@@ -826,6 +826,7 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
     stats->n_rays = (uint64_t)W * H;
     stats->n_samples = n_samples;
     stats->n_rounds = n_rounds;
+    stats->n_network_evals = n_samples;  // D-5: the oracle evaluates live samples only, no tile padding
     stats->render_ms = 0.0f;
   }
 #ifdef _OPENMP

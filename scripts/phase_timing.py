@@ -22,7 +22,8 @@ for az in (0, 45, 90):
     out = (C.c_ulonglong * 16)()
     ctx.lib.nrf_debug_counters(ctx.h, out)
     s, r, m, n, c, tot, waves = [int(x) for x in out[:7]]
-    slots = int(out[7])
+    r &= 0xffffffff  # render_kernel packs rounds (low) and evaluated tile slots (high) into one counter
+    slots = int(st.n_network_evals)
     other = tot - m - n - c
     print(f"az {az}: {st.render_ms:.3f} ms samples {s} rounds {r} waves {waves}  samples/round {s/max(r,1):.1f}")
     print(f"   cycles/wave {tot/waves:.0f}  march {100*m/tot:.1f}%  network {100*n/tot:.1f}%  composite {100*c/tot:.1f}%  setup+final {100*other/tot:.1f}%")
