@@ -288,8 +288,9 @@ struct MarchConst {
   uint32_t H, C, HH, HHH;
   uint32_t coarse_shift;  // 2 when the coarse grid is present, else 0
   uint32_t Hc;            // H >> coarse_shift
-  uint32_t log2H;         // UNIT instances only (H is a power of two there)
+  uint32_t log2H;         // MARCH_UNIT / MARCH_POW2 instances only (H is a power of two there)
   float halfH;            // 0.5f * H
+  int log2_bound;         // MARCH_POW2 instances only: bound == 2^log2_bound
 };
 
 __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_gamma) {
@@ -309,6 +310,11 @@ __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_ga
   c.Hc = M.H >> M.coarse_shift;
   c.log2H = 31u - (uint32_t)__builtin_clz(M.H | 1u);
   c.halfH = 0.5f * (float)M.H;
+  {
+    int e;
+    (void)frexpf(M.bound, &e);
+    c.log2_bound = e - 1;  // exact when bound is a power of two (the only case it is used in)
+  }
   return c;
 }
 
@@ -325,7 +331,12 @@ enum : int { MARCH_FOUND = 0, MARCH_EXHAUSTED = 1, MARCH_OUT_OF_BUDGET = 2 };
 // shifts and ors.  clamp() is v_med3_f32 (same value as fminf(hi, fmaxf(lo, x)) for non-NaN x).
 __device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
-template <bool COARSE, bool UNIT>
+// MODE: MARCH_GENERIC = the literal arithmetic; MARCH_UNIT = one cascade, mip_bound 1, H = 2^k (see above);
+// MARCH_POW2 = several cascades with H = 2^k and bound = 2^b: every mip_bound is a power of two, so
+// (0.5f * (x * mip_rbound + 1)) * H == fma(x, 2^(k-1-lb), 2^(k-1)) (power-of-two scalings do not round and
+// commute with the one rounding of the addition), the level clamp is an integer med3, indices are shifts.
+enum : int { MARCH_GENERIC = 0, MARCH_UNIT = 1, MARCH_POW2 = 2 };
+template <bool COARSE, int MODE>
 __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* __restrict__ occ, const uint32_t* coarse,
                                           const float* ctab, float ox, float oy, float oz, float dx, float dy, float dz,
                                           float rdx, float rdy, float rdz, int sx, int sy, int sz, float far, float t_skip,
@@ -336,6 +347,7 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     x = clamp3(ox + t * dx, -c.bound, c.bound);
     y = clamp3(oy + t * dy, -c.bound, c.bound);
     z = clamp3(oz + t * dz, -c.bound, c.bound);
+    constexpr bool UNIT = MODE == MARCH_UNIT, POW2 = MODE == MARCH_POW2;
     int level = 0;
     int nx, ny, nz;
     if (UNIT) {
@@ -345,6 +357,15 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
       nx = (int)clamp3(__builtin_fmaf(x, c.halfH, c.halfH), 0.0f, c.Hm1);
       ny = (int)clamp3(__builtin_fmaf(y, c.halfH, c.halfH), 0.0f, c.Hm1);
       nz = (int)clamp3(__builtin_fmaf(z, c.halfH, c.halfH), 0.0f, c.Hm1);
+    } else if (POW2) {
+      const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+      int exponent;
+      (void)frexpf(mx, &exponent);
+      level = min(max(exponent, 0), (int)c.C - 1);
+      const float scale = ldexpf(c.halfH, -min(level, c.log2_bound));  // halfH / mip_bound
+      nx = (int)clamp3(__builtin_fmaf(x, scale, c.halfH), 0.0f, c.Hm1);
+      ny = (int)clamp3(__builtin_fmaf(y, scale, c.halfH), 0.0f, c.Hm1);
+      nz = (int)clamp3(__builtin_fmaf(z, scale, c.halfH), 0.0f, c.Hm1);
     } else {
       float mip_bound = fminf(1.0f, c.bound), mip_rbound;
       if (c.C > 1) {
@@ -363,16 +384,16 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     }
     // all loads of the trip are issued together (addresses depend only on the cell), so the
     // trip pays one memory latency instead of three dependent ones
-    const uint32_t cell = UNIT ? ((((uint32_t)nx << c.log2H) | (uint32_t)ny) << c.log2H) | (uint32_t)nz
-                               : (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
+    const uint32_t cell = (UNIT || POW2) ? ((((((uint32_t)level << c.log2H) | (uint32_t)nx) << c.log2H) | (uint32_t)ny) << c.log2H) | (uint32_t)nz
+                                         : (uint32_t)level * c.HHH + (uint32_t)nx * c.HH + (uint32_t)ny * c.H + (uint32_t)nz;
     const float* tab = UNIT ? ctab : ctab + (uint32_t)level * (c.H + 1);
     const float bx = tab[nx + sx], by = tab[ny + sy], bz = tab[nz + sz];
     bool occupied = false;
     if (!(t < t_skip)) {  // before t_skip the cell is known to be empty (coarse_visibility)
       if (COARSE) {
         const uint32_t lc = c.log2H - 2u;
-        const uint32_t cc = UNIT ? (((((uint32_t)nx >> 2) << lc) | ((uint32_t)ny >> 2)) << lc) | ((uint32_t)nz >> 2)
-                                 : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
+        const uint32_t cc = (UNIT || POW2) ? (((((((uint32_t)level << lc) | ((uint32_t)nx >> 2)) << lc) | ((uint32_t)ny >> 2)) << lc) | ((uint32_t)nz >> 2))
+                                           : ((uint32_t)level * c.Hc + ((uint32_t)nx >> 2)) * c.Hc * c.Hc + ((uint32_t)ny >> 2) * c.Hc + ((uint32_t)nz >> 2);
         const bool coarse_occ = (coarse[cc >> 5] >> (cc & 31u)) & 1u;
         if (coarse_occ) occupied = (occ[cell >> 5] >> (cell & 31u)) & 1u;
       } else {

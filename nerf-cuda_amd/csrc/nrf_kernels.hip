@@ -147,7 +147,7 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 // 256 threads, >= 4 waves per SIMD (four workgroups per CU, 39.9 KB of LDS each): caps the kernel at
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
-template <bool GEN, bool COARSE_LDS, bool UNIT>
+template <bool GEN, bool COARSE_LDS, int MARCH>
 __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
                                                      float4* __restrict__ rgba, float* __restrict__ depth,
                                                      unsigned long long* __restrict__ counters) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       const float t_box0 = fmaxf(t_in, near);
       bool any = false;
       float first = far_m, last = t_box0;
-      const uint32_t n_casc = UNIT ? 1u : M.cascade;  // UNIT instances: one cascade, mip_bound 1
+      const uint32_t n_casc = MARCH == MARCH_UNIT ? 1u : M.cascade;  // MARCH_UNIT: one cascade, mip_bound 1
       for (uint32_t k = 0; k < n_casc; ++k) {
         const float mb = (n_casc > 1) ? fminf(ldexpf(1.0f, (int)k), M.bound) : fminf(1.0f, M.bound);
         float c_in = t_box0, c_out = far_m;
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       const int budget_before = budget;
 #endif
       if (marching) {
-        const int r = COARSE_LDS ? march_next<true, UNIT>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+        const int r = COARSE_LDS ? march_next<true, MARCH>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                     rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt)
-                                 : march_next<false, false>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                 : march_next<false, MARCH_GENERIC>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                      rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt);
         found = r == MARCH_FOUND;
         marching = found;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
       bool found = false;
       if (marching) {
         int budget = 0x7fffffff;
-        found = march_next<COARSE, false>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
+        found = march_next<COARSE, MARCH_GENERIC>(mc, M.occ_bits, M.occ_coarse, M.cell_bound, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz,
                                    far, -3.402823466e+38f, budget, t, x, y, z, dt) == MARCH_FOUND;
       }
       marching = found;
@@ -762,14 +762,20 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 #define NRF_LAUNCH_RENDER(G, C, U)                                                                                       \
   hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, VB, (float4*)rgba,     \
                      (float*)depth, (unsigned long long*)counters)
-  // hot instance: compile-time activations, march tables in LDS, single cascade with mip_bound == 1
-  const bool unit = lds_tab && M.cascade == 1 && M.bound >= 1.0f && (M.H & (M.H - 1)) == 0;
+  // hot instances: compile-time activations, march tables in LDS; a power-of-two grid with either one cascade and
+  // mip_bound == 1 (MARCH_UNIT) or several cascades and a power-of-two bound (MARCH_POW2)
+  const bool pow2_h = (M.H & (M.H - 1)) == 0;
+  const bool unit = lds_tab && pow2_h && M.cascade == 1 && M.bound >= 1.0f;
+  int eb = 0;
+  const bool pow2_bound = M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+  const bool pow2 = lds_tab && pow2_h && M.cascade > 1 && pow2_bound;
   if (M.generic_act) {
-    if (lds_tab) NRF_LAUNCH_RENDER(true, true, false); else NRF_LAUNCH_RENDER(true, false, false);
+    if (lds_tab) NRF_LAUNCH_RENDER(true, true, MARCH_GENERIC); else NRF_LAUNCH_RENDER(true, false, MARCH_GENERIC);
   } else {
-    if (unit) NRF_LAUNCH_RENDER(false, true, true);
-    else if (lds_tab) NRF_LAUNCH_RENDER(false, true, false);
-    else NRF_LAUNCH_RENDER(false, false, false);
+    if (unit) NRF_LAUNCH_RENDER(false, true, MARCH_UNIT);
+    else if (pow2) NRF_LAUNCH_RENDER(false, true, MARCH_POW2);
+    else if (lds_tab) NRF_LAUNCH_RENDER(false, true, MARCH_GENERIC);
+    else NRF_LAUNCH_RENDER(false, false, MARCH_GENERIC);
   }
 #undef NRF_LAUNCH_RENDER
   return hipGetLastError();
