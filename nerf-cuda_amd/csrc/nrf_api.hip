@@ -625,6 +625,10 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.dilated_level_words = dilated_level_words;
   if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
   M.pos_w = (float)(1.0 / (2 * (double)d->bound));
+  {
+    int e;
+    M.pos_w_pow2 = std::frexp(M.pos_w, &e) == 0.5f ? 1u : 0u;
+  }
   M.cascade = d->cascade;
   M.H = d->density_grid_size;
   M.n_levels = d->n_levels;

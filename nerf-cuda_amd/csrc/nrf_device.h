@@ -76,6 +76,7 @@ struct DevModel {
   uint32_t grid_bytes;         // size of the device hash table (< 4 GiB): num_records of its buffer resource
   const uint32_t* occ_dilated;  // [C][dilated_level_words]: coarse cells within one density cell of an occupied density cell
   uint32_t dilated_level_words;
+  uint32_t pos_w_pow2;         // pos_w = 1 / (2 bound) is a power of two: pos_w * x + 0.5 is then ONE fma (the product is exact)
   const uint4* wfrag;        // N_FRAGS_ALL * 64 uint4
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];

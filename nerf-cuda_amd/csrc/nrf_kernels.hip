@@ -91,9 +91,16 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     if (slot < S) {
       const float4 p = W->pos[slot];
       // xyz -> [0,1]: linear_transformer(1/(2 bound), 0.5), R/src/nerf_render.cu:311-312
-      float px = M.pos_w * p.x; px = px + 0.5f;
-      float py = M.pos_w * p.y; py = py + 0.5f;
-      float pz = M.pos_w * p.z; pz = pz + 0.5f;
+      float px, py, pz;
+      if (M.pos_w_pow2) {  // wave-uniform: the product cannot round, so the fma equals multiply-then-add
+        px = __builtin_fmaf(M.pos_w, p.x, 0.5f);
+        py = __builtin_fmaf(M.pos_w, p.y, 0.5f);
+        pz = __builtin_fmaf(M.pos_w, p.z, 0.5f);
+      } else {
+        px = M.pos_w * p.x; px = px + 0.5f;
+        py = M.pos_w * p.y; py = py + 0.5f;
+        pz = M.pos_w * p.z; pz = pz + 0.5f;
+      }
       // lane group g encodes levels {g, 4+g, 8+g, 12+g}: for each unrolled step jl the four groups work
       // on four ADJACENT levels, which for the usual tables are all dense (jl = 0) or all hashed
       // (jl >= 2), so the index arithmetic is specialised per step by a wave-uniform branch.
