@@ -652,3 +652,18 @@ def test_every_march_instance_matches_oracle(ctx, H, bound, cascade, dt_gamma):
     assert st.n_samples > 0
     assert np.abs(rgba - want).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0
     ctx.set_options(nh.default_options())
+
+
+@pytest.mark.parametrize("kw", [dict(dir_otype="Frequency", n_frequencies=2), dict(dir_otype="Identity"), dict(sh_degree=2)])
+def test_render_with_other_direction_encodings(ctx, kw):
+    """The fused kernel with the other direction encodings of the Composite block (frequency.h:46-93, Identity,
+    lower SH degrees with their leading-ones padding): frames against the oracle."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=14, H=64, **kw)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    W, H = 96, 64
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(215, 25)
+    rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
+    assert st.n_samples > 0
+    assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
+    assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
