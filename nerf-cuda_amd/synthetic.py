@@ -29,7 +29,7 @@ N_MLP = N_D0 + N_D1 + N_R0 + N_R1 + N_R2  # 10240
 
 
 def base_config(log2_hashmap_size=19, n_levels=16, base_resolution=16, sh_degree=4, rgb_output_activation="None",
-                dir_otype="SphericalHarmonics", n_frequencies=2):
+                dir_otype="SphericalHarmonics", n_frequencies=2, grid_type=None, per_level_scale=None):
     """The four network blocks of reference configs/nerf/base.json."""
     if dir_otype == "SphericalHarmonics":
         dir_nested = {"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": sh_degree}
@@ -37,9 +37,14 @@ def base_config(log2_hashmap_size=19, n_levels=16, base_resolution=16, sh_degree
         dir_nested = {"n_dims_to_encode": 3, "otype": "Frequency", "n_frequencies": n_frequencies}
     else:
         dir_nested = {"n_dims_to_encode": 3, "otype": "Identity"}
+    encoding = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+                "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution}
+    if grid_type:  # "Hash" (default) | "Dense" | "Tiled": tcnn GridEncoding `type` (grid.h:1365-1386)
+        encoding["type"] = grid_type
+    if per_level_scale:
+        encoding["per_level_scale"] = float(per_level_scale)
     return {
-        "encoding": {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
-                     "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution},
+        "encoding": encoding,
         "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
                     "n_hidden_layers": 1},
         "dir_encoding": {"otype": "Composite", "nested": [dir_nested, {"otype": "Identity", "n_bins": 4, "degree": 4}]},

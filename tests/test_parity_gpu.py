@@ -667,3 +667,28 @@ def test_render_with_other_direction_encodings(ctx, kw):
     assert st.n_samples > 0
     assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+
+
+@pytest.mark.parametrize("kw", [dict(grid_type="Tiled", base_resolution=16), dict(grid_type="Dense", per_level_scale=1.13),
+                                dict(grid_type="Hash", log2_hashmap_size=10, base_resolution=4)])
+def test_other_grid_types_encode_and_render(ctx, kw):
+    """GridEncoding `type` Tiled (every level folded into base^3 entries by `index % size`) and Dense (all levels
+    dense), and a hash table so small that even the coarse levels are hashed: the generic level path of the kernels
+    (stride loop + modulo, grid.h:100-117) -- bit-exact encoding and frames against the oracle."""
+    desc, keep, cfg = models.build_model(H=32, **kw)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    rng = np.random.default_rng(11)
+    pos = np.concatenate([rng.random((4000, 3), dtype=np.float32),
+                          np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.999999, 1e-7, 0.5]], np.float32)])
+    want = o.encode_grid(pos)
+    out = torch.empty((len(pos), 32), dtype=torch.int16, device="cuda")
+    p_d = dev(pos)
+    sync()
+    ctx.encode_grid(p_d.data_ptr(), len(pos), out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), want)
+    W, H = 80, 56
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(20, 35)
+    rgba, depth, st, wantf, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
+    assert st.n_samples > 0
+    assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0
