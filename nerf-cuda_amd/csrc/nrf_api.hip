@@ -785,18 +785,19 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipEventSynchronize(c->ev1));
-  unsigned long long raw[COUNTER_SLOTS * 16], cnt[2] = {0, 0};
+  unsigned long long raw[COUNTER_SLOTS * 16], cnt[3] = {0, 0, 0};
   HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int sl = 0; sl < COUNTER_SLOTS; ++sl) {
     cnt[0] += raw[sl * 16];
     cnt[1] += raw[sl * 16 + 1];
+    cnt[2] += raw[sl * 16 + 11];
   }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   s->n_rays = (uint64_t)c->n_local_tiles * 64;
   s->n_samples = cnt[0];
-  s->n_rounds = cnt[1] & 0xffffffffull;      // render_kernel packs two sums into one atomic
-  s->n_network_evals = cnt[1] >> 32;
+  s->n_rounds = cnt[1];
+  s->n_network_evals = cnt[2];
   s->render_ms = ms;
   return NRF_OK;
 }

@@ -441,7 +441,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   counters += (blockIdx.x % COUNTER_SLOTS) * 16;  // see COUNTER_SLOTS
   if (lane == 0 && n_rounds != 0) {           // waves that never sampled (background) add nothing
     atomicAdd(&counters[0], (unsigned long long)n_samples);
-    atomicAdd(&counters[1], (unsigned long long)n_rounds | ((unsigned long long)n_tile_slots << 32));  // one atomic, two sums
+    atomicAdd(&counters[1], (unsigned long long)n_rounds);
+    atomicAdd(&counters[11], (unsigned long long)n_tile_slots);
   }
 #ifdef NRF_PHASE_TIMING
   if (lane == 0) {

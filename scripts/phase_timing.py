@@ -22,7 +22,6 @@ for az in (0, 45, 90):
     out = (C.c_ulonglong * 16)()
     ctx.lib.nrf_debug_counters(ctx.h, out)
     s, r, m, n, c, tot, waves = [int(x) for x in out[:7]]
-    r &= 0xffffffff  # render_kernel packs rounds (low) and evaluated tile slots (high) into one counter
     slots = int(st.n_network_evals)
     other = tot - m - n - c
     print(f"az {az}: {st.render_ms:.3f} ms samples {s} rounds {r} waves {waves}  samples/round {s/max(r,1):.1f}")
