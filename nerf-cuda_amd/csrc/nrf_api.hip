@@ -473,6 +473,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   };
   // world-space box around every occupied (and reachable) cell, inflated by 2 cells of its cascade level
   float occ_box[6] = {1.f, 1.f, 1.f, -1.f, -1.f, -1.f};  // empty
+  bool boundary_occupied = false;  // an occupied (reachable) cell with index 0 or H-1 on some axis
   {
     bool any = false;
     for (uint32_t level = 0; level < Cs; ++level) {
@@ -490,20 +491,38 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
       const double mip_bound = fmin(Cs > 1 ? ldexp(1.0, (int)level) : 1.0, (double)d->bound);
       const double cell = 2.0 * mip_bound / (double)Hs;
       for (int a = 0; a < 3; ++a) {
-        const float wlo = (float)(-mip_bound + ((double)lo[a] - 2.0) * cell);
-        const float whi = (float)(-mip_bound + ((double)hi[a] + 3.0) * cell);
+        float wlo = (float)(-mip_bound + ((double)lo[a] - 2.0) * cell);
+        float whi = (float)(-mip_bound + ((double)hi[a] + 3.0) * cell);
+        // The march clamps the position to +-bound and then the cell index to [0, H-1] (render_utils.h:595-611):
+        // a position OUTSIDE this cascade's cube -- bound > 2^(C-1), or an aabb wider than +-bound -- lands in the
+        // boundary layer of cells.  An occupied boundary cell therefore stands for everything beyond that face: the
+        // box is extended to wherever a ray can be (its aabb range) on that side.
+        if (lo[a] == 0) wlo = fminf(wlo, fminf(d->aabb[a], -d->bound) - (float)(2.0 * cell));
+        if (hi[a] == Hs - 1) whi = fmaxf(whi, fmaxf(d->aabb[a + 3], d->bound) + (float)(2.0 * cell));
         if (!any || wlo < occ_box[a]) occ_box[a] = wlo;
         if (!any || whi > occ_box[a + 3]) occ_box[a + 3] = whi;
+        boundary_occupied = boundary_occupied || lo[a] == 0 || hi[a] == Hs - 1;
       }
       any = true;
     }
   }
+  // Positions outside the outermost cube exist when bound > its mip_bound or the aabb is wider than +-bound.  The
+  // per-cascade visibility walk (coarse_visibility) only covers a ray's stretch INSIDE each cube, so with an
+  // occupied boundary layer in such a model it would miss those samples: the walk is switched off then (the box
+  // test above stays exact).
+  bool exterior_positions = false;
+  {
+    const float outer = fminf(Cs > 1 ? ldexpf(1.0f, (int)Cs - 1) : 1.0f, d->bound);
+    exterior_positions = d->bound > outer;
+    for (int a = 0; a < 3; ++a) exterior_positions = exterior_positions || d->aabb[a] < -d->bound || d->aabb[a + 3] > d->bound;
+  }
+  const bool visibility_walk = !(exterior_positions && boundary_occupied);
   // Conservative coarse visibility set (single cascade): coarse cells that contain, or lie within one
   // density cell of, an occupied density cell (= the coarse image of the occupancy dilated by one
   // fine cell); used by the per-ray DDA of render_kernel (nrf_device.h coarse_visibility).
   std::vector<uint32_t> dilated;
   uint32_t dilated_level_words = 0;  // words per cascade level (whole words, so a level's bits start at bit 0)
-  if (coarse_shift) {
+  if (coarse_shift && visibility_walk) {
     const int Hc = (int)(Hs >> 2), Hf = (int)Hs;
     dilated_level_words = (uint32_t)(((uint64_t)Hc * Hc * Hc + 31) / 32);
     dilated.assign((size_t)dilated_level_words * Cs, 0u);

@@ -56,6 +56,15 @@ class Reader {
  private:
   const uint8_t* p_;
   const uint8_t* end_;
+  int depth_ = 0;  // nesting of containers: hostile input must not recurse the stack away
+  static constexpr int kMaxDepth = 64;
+  struct Nest {
+    int& d;
+    explicit Nest(int& depth) : d(depth) {
+      if (++d > kMaxDepth) throw std::runtime_error("msgpack: nesting deeper than 64 levels");
+    }
+    ~Nest() { --d; }
+  };
   void need(size_t n) const {
     if ((size_t)(end_ - p_) < n) throw std::runtime_error("msgpack: truncated input");
   }
@@ -80,8 +89,11 @@ class Reader {
     return v;
   }
   Value array(size_t n) {
+    Nest guard(depth_);
     Value v;
     v.type = Value::NumArray;
+    // every element takes at least one byte: a length field larger than what is left is a lie, not a reservation
+    if (n > (size_t)(end_ - p_)) throw std::runtime_error("msgpack: array length exceeds the input");
     v.nums.reserve(n);
     bool numeric = true;
     for (size_t i = 0; i < n; ++i) {
@@ -110,8 +122,10 @@ class Reader {
     return v;
   }
   Value map(size_t n) {
+    Nest guard(depth_);
     Value v;
     v.type = Value::Map;
+    if (n > (size_t)(end_ - p_) / 2) throw std::runtime_error("msgpack: map length exceeds the input");
     for (size_t i = 0; i < n; ++i) {
       Value k = item();
       if (k.type != Value::String) throw std::runtime_error("msgpack: non-string map key");

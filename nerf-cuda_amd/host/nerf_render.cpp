@@ -195,6 +195,7 @@ void NerfRender::reset_network() {
   const std::string gtype = to_lower(enc.value("type", default_type.c_str()));
   d.grid_type = gtype == "hash" ? NRF_GRID_HASH : (gtype == "dense" ? NRF_GRID_DENSE : NRF_GRID_TILED);
   d.n_features_per_level = enc.value("n_features_per_level", 2u);
+  if (d.n_features_per_level == 0) throw std::runtime_error{"GridEncoding: n_features_per_level must be 1, 2, 4 or 8"};  // grid.h:1403-1411
   if (enc.contains("n_features") && enc.value("n_features", 0u) > 0) {
     if (enc.contains("n_levels")) throw std::runtime_error{"GridEncoding: may not specify n_features and n_levels simultaneously (one determines the other)"};
     d.n_levels = enc.value("n_features", 0u) / d.n_features_per_level;

@@ -12,8 +12,18 @@
 // Extended request (optional, same connection): the 4 bytes "NRF1", u32 n, then n x {f32 cam[4] = fl_x, fl_y,
 // cx, cy; f32 pose[16]}; the answer is n images of 3*W*H bytes in request order.  A raw 64-byte pose keeps
 // meaning what it means to the reference's clients.
+// Robustness (the reference relies on sockpp::socket_initializer for the first point and has none of the others):
+//   * a client that disconnects mid-reply must not take the server down: SIGPIPE is ignored and every send uses
+//     MSG_NOSIGNAL;
+//   * an extended request of n views is served in chunks of NRF_MAX_VIEWS (one launch each): at most that many
+//     frames are held per connection, whatever n (<= NRF1_MAX_VIEWS_PER_REQUEST) says;
+//   * client threads are detached and counted, nothing grows with the number of connections served;
+//   * NRF_SERVER_BIND=<ipv4> restricts the listening address (default: any, like the reference's acceptor);
+//   * the "QUIT" message (prints the batch statistics and stops the server) is a test hook: it is honoured only
+//     when NRF_SERVER_TEST_HOOKS=1 is set in the server's environment.
 //   usage: render_server [port=12345] [snapshot=./freality.msgpack] [width height]
 #include <arpa/inet.h>
+#include <csignal>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
@@ -49,7 +59,7 @@ static bool read_n(int fd, void* buf, size_t n) {  // the reference does not han
 static bool write_n(int fd, const void* buf, size_t n) {
   const char* p = (const char*)buf;
   while (n) {
-    const ssize_t r = ::write(fd, p, n);
+    const ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL);  // a vanished peer is an error code, not a SIGPIPE
     if (r <= 0) return false;
     p += r;
     n -= (size_t)r;
@@ -74,7 +84,10 @@ struct Batcher {
   std::deque<std::shared_ptr<Request>> queue;
   std::atomic<bool> stop{false};
   std::atomic<unsigned long> batches{0}, frames{0};
+  std::atomic<int> live_clients{0};
+  bool test_hooks = false;  // NRF_SERVER_TEST_HOOKS=1
 };
+constexpr uint32_t NRF1_MAX_VIEWS_PER_REQUEST = 4096;
 
 // the one thread that owns the renderer
 void render_loop(NerfRender& render, const size_t frame_bytes, Batcher& b) {
@@ -138,7 +151,7 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, co
   std::cout << "Received a connection request from " << peer << std::endl;
   float nerf_pos[16] = {0};
   while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
-    if (std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {  // test hook
+    if (b.test_hooks && std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {
       std::printf("\nbatches %lu frames %lu\n", b.batches.load(), b.frames.load());  // one write: other threads print too
       std::fflush(stdout);
       b.stop = true;
@@ -149,18 +162,22 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, co
     if (std::memcmp(nerf_pos, "NRF1", 4) == 0) {  // extended request: the 64 bytes read so far are its first 64
       uint32_t n = 0;
       std::memcpy(&n, (const char*)nerf_pos + 4, 4);
-      if (n == 0 || n > 4096) break;
-      std::vector<float> body((size_t)n * 20);
+      if (n == 0 || n > NRF1_MAX_VIEWS_PER_REQUEST) break;
+      std::vector<float> body((size_t)n * 20);  // 80 bytes per view: <= 320 KB
       const size_t have = sizeof(nerf_pos) - 8, need = body.size() * sizeof(float);
       std::memcpy(body.data(), (const char*)nerf_pos + 8, have < need ? have : need);
       if (need > have && !read_n(sock, (char*)body.data() + have, need - have)) break;
-      std::vector<std::shared_ptr<Request>> reqs;
-      for (uint32_t v = 0; v < n; ++v) {
-        const float* r = body.data() + (size_t)v * 20;
-        reqs.push_back(submit(b, Camera{r[0], r[1], r[2], r[3]}, r + 4));  // all queued before the first wait: one batch
-      }
       bool ok = true;
-      for (const auto& r : reqs) ok = ok && wait_and_send(sock, r, frame_bytes);
+      // chunks of NRF_MAX_VIEWS: every chunk is queued before its first wait (one launch), sent, and freed before
+      // the next one is queued -- a connection never holds more than NRF_MAX_VIEWS rendered frames
+      for (uint32_t first = 0; ok && first < n; first += NRF_MAX_VIEWS) {
+        std::vector<std::shared_ptr<Request>> reqs;
+        for (uint32_t v = first; v < n && v < first + NRF_MAX_VIEWS; ++v) {
+          const float* r = body.data() + (size_t)v * 20;
+          reqs.push_back(submit(b, Camera{r[0], r[1], r[2], r[3]}, r + 4));
+        }
+        for (const auto& r : reqs) ok = ok && wait_and_send(sock, r, frame_bytes);
+      }
       if (!ok) break;
       continue;
     }
@@ -168,6 +185,7 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, co
   }
   std::cout << "Connection closed" << std::endl;
   ::close(sock);
+  b.live_clients--;
 }
 
 }  // namespace
@@ -177,6 +195,7 @@ int main(int argc, char** argv) {
   const int port = argc > 1 ? std::atoi(argv[1]) : 12345;
   const std::string config_path = argc > 2 ? argv[2] : "./freality.msgpack";
   const int W = argc > 4 ? std::atoi(argv[3]) : 1080, H = argc > 4 ? std::atoi(argv[4]) : 1080;
+  std::signal(SIGPIPE, SIG_IGN);
   try {
     NerfRender render;
     render.reload_network_from_file(config_path);  // Init Model
@@ -191,14 +210,23 @@ int main(int argc, char** argv) {
     sockaddr_in addr{};
     addr.sin_family = AF_INET;
     addr.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (const char* bind_to = std::getenv("NRF_SERVER_BIND")) {
+      if (::inet_pton(AF_INET, bind_to, &addr.sin_addr) != 1) {
+        std::cerr << "NRF_SERVER_BIND: not an IPv4 address: " << bind_to << std::endl;
+        return 1;
+      }
+    }
     addr.sin_port = htons((uint16_t)port);
     if (srv < 0 || ::bind(srv, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(srv, 64) != 0) {
       std::cerr << "Error creating the acceptor: " << std::strerror(errno) << std::endl;
       return 1;
     }
     Batcher batcher;
+    {
+      const char* hooks = std::getenv("NRF_SERVER_TEST_HOOKS");
+      batcher.test_hooks = hooks && std::strcmp(hooks, "1") == 0;
+    }
     std::thread renderer(render_loop, std::ref(render), frame_bytes, std::ref(batcher));
-    std::vector<std::thread> clients;
     std::cout << "Awaiting connections on port " << port << "..." << std::endl;
     while (!batcher.stop.load()) {
       sockaddr_in peer{};
@@ -210,13 +238,13 @@ int main(int argc, char** argv) {
         continue;
       }
       ::setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      clients.emplace_back(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, frame_bytes, std::ref(batcher), srv);
+      // detached: a finished connection leaves nothing behind (readers of still-open connections end with the process)
+      batcher.live_clients++;
+      std::thread(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, frame_bytes, std::ref(batcher), srv).detach();
     }
     batcher.stop = true;
     batcher.cv.notify_all();
     renderer.join();
-    for (auto& t : clients)
-      if (t.joinable()) t.detach();  // readers of still-open connections end with the process
     ::close(srv);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -1,0 +1,86 @@
+"""bench.py's launch contract: `--gpus N` without a launcher starts N ranks itself (the parent never touches a
+GPU), a WORLD_SIZE that differs from --gpus fails loudly, and -- on the GPU box -- the self-launched two-rank
+rehearsal (gloo, both ranks on the one device) produces a line with n_gpus == 2 whose gathered frames equal
+unsharded renders, for the tile-sharded configuration (BASELINE config 3) and the replica one (config 5)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BENCH = ROOT / "bench.py"
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_world_size_mismatch_fails_before_any_gpu_work():
+    r = subprocess.run([sys.executable, str(BENCH), "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    # a launcher that started more ranks than --gpus (default 1) is just as wrong
+    r = subprocess.run([sys.executable, str(BENCH)], env=_env(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 1" in r.stderr
+
+
+def test_self_launch_builds_a_torchrun_command_and_parent_stays_gpu_free():
+    code = r"""
+import sys, types, subprocess
+sys.argv = ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"]
+sys.path.insert(0, %r)
+import bench
+seen = {}
+def fake_run(cmd, env=None, **kw):
+    seen["cmd"], seen["env"] = cmd, env
+    return types.SimpleNamespace(returncode=7)
+subprocess.run = fake_run
+try:
+    bench.main()
+except SystemExit as e:
+    code = e.code
+cmd = seen["cmd"]
+assert code == 7, code                       # the children's exit code is relayed
+assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+i = cmd.index(str(bench.Path(bench.__file__).resolve()))
+assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]   # the ranks get the same arguments
+assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+assert "torch" not in sys.modules, "the launching parent must not import torch (nor initialise a GPU)"
+print("ok")
+""" % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def _bench_line(args, timeout=900):
+    r = subprocess.run([sys.executable, str(BENCH), *args], env=_env(), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_self_launched_two_rank_rehearsal_tile_sharded():
+    out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "2", "--warmup", "1",
+                       "--views-per-step", "2"])
+    assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert out["distributed"]["launcher"] == "bench.py self-launch" and len(out["distributed"]["devices"]) == 2
+    assert out["sharded_frame_equals_unsharded"] is True
+    assert out["config"]["parallelism"] == "tile2" and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_self_launched_two_rank_rehearsal_config5_replicas():
+    out = _bench_line(["--gpus", "2", "--config", "5", "--backend", "gloo", "--single-device", "--check", "--steps", "1",
+                       "--warmup", "1", "--views-per-step", "8"])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "replica2"
+    assert out["config"]["views_per_step"] == 8 and out["config"]["views_per_rank_and_step"] == 4
+    assert out["sharded_frame_equals_unsharded"] is True and "800x800" in out["config"]["workload"]

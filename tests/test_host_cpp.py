@@ -1,6 +1,7 @@
 """The C++ host mirror (nerf-cuda_amd/host): snapshot parsing and config derivation on the CPU,
 the testbed and the render_server wire protocol on the GPU."""
 import json
+import os
 import socket
 import subprocess
 import time
@@ -15,6 +16,8 @@ import synthetic as syn
 
 ROOT = Path(__file__).resolve().parent.parent
 HOST = ROOT / "nerf-cuda_amd" / "host"
+# the QUIT message (statistics + shutdown) is a test hook the server only honours with this variable set
+SERVER_TEST_ENV = dict(os.environ, NRF_SERVER_TEST_HOOKS="1", NRF_SERVER_BIND="127.0.0.1")
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +27,20 @@ def snapshot(tmp_path_factory):
     path = d / "tiny.msgpack"
     syn.write_snapshot(path, cfg, keep[0], keep[1])
     return path, desc, keep, cfg
+
+
+def _oracle_rgb8(desc, cam, pose, W, H):
+    """The reference's answer to one pose request (render_server.cu:93-101: render_frame -> Image.rgb): the CPU
+    oracle's frame (per-ray schedule), quantised like nerf_render.cu:352-359."""
+    import oracle_py as op
+    rgba, depth, _ = op.Oracle(desc).render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
+    return op.quantize_u8(rgba, depth)[0]
+
+
+def _assert_within_one_lsb(got_u8, want_u8, what):
+    d = np.abs(got_u8.astype(np.int16) - want_u8.astype(np.int16))
+    assert d.max() <= 1, f"{what}: server bytes differ from the oracle's quantised frame by {d.max()} LSB"
+    assert (d > 0).mean() < 0.02, f"{what}: {100 * (d > 0).mean():.2f} % of the bytes differ"  # rounding-edge cases only
 
 
 def _info(path):
@@ -111,7 +128,7 @@ def test_render_server_wire_protocol(snapshot):
     path, desc, keep, cfg = snapshot
     W, H, port = 64, 64, 23457
     srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True)
+                           stderr=subprocess.STDOUT, text=True, env=SERVER_TEST_ENV)
     try:
         sock = None
         for _ in range(200):
@@ -135,7 +152,10 @@ def test_render_server_wire_protocol(snapshot):
                 buf += chunk
             ctx.render(cam, pose)
             rgb8, _ = ctx.read_u8()
-            np.testing.assert_array_equal(np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3), rgb8)
+            got = np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3)
+            np.testing.assert_array_equal(got, rgb8)
+            _assert_within_one_lsb(got, _oracle_rgb8(desc, cam, pose, W, H), "raw 64-byte pose")  # HIP vs the oracle
+            assert got.min() < 250  # the object is in view: the comparison is not background against background
         # extended request on the same connection: "NRF1", u32 n, n x {cam[4], pose[16]}: one launch, per-view intrinsics
         views = [(cam * np.float32(1.0 + 0.1 * i), syn.orbit_pose(70.0 * i, 15.0 + 5 * i)) for i in range(3)]
         msg = b"NRF1" + np.uint32(len(views)).tobytes()
@@ -149,7 +169,9 @@ def test_render_server_wire_protocol(snapshot):
                 assert chunk, "connection closed early"
                 buf += chunk
             ctx.render(c, p)
-            np.testing.assert_array_equal(np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3), ctx.read_u8()[0])
+            got = np.frombuffer(bytes(buf), np.uint8).reshape(H, W, 3)
+            np.testing.assert_array_equal(got, ctx.read_u8()[0])
+            _assert_within_one_lsb(got, _oracle_rgb8(desc, c, p, W, H), "NRF1 request")
         quit_msg = np.zeros(16, np.float32)
         quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
         sock.sendall(quit_msg.tobytes())
@@ -171,7 +193,7 @@ def test_render_server_batches_concurrent_clients(snapshot):
     path, desc, keep, cfg = snapshot
     W, H, port = 96, 64, 23459
     srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True)
+                           stderr=subprocess.STDOUT, text=True, env=SERVER_TEST_ENV)
     n_clients, per_client = 6, 5
     try:
         socks = []
@@ -219,6 +241,7 @@ def test_render_server_batches_concurrent_clients(snapshot):
             for i in range(per_client):
                 ctx.render(cam, poses[c][i])
                 np.testing.assert_array_equal(got[c][i], ctx.read_u8()[0])
+                _assert_within_one_lsb(got[c][i], _oracle_rgb8(desc, cam, poses[c][i], W, H), f"client {c} request {i}")
         ctx.close()
         quit_msg = np.zeros(16, np.float32)
         quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
@@ -293,3 +316,93 @@ def test_python_nerf_render_mirror_matches_cpp_testbed(tmp_path, snapshot):
     np.testing.assert_array_equal(both[0][0], want)
     assert both[1][0].shape == (H, W, 3) and not np.array_equal(both[1][0], want)
     render.close()
+
+
+def _connect(port, tries=200):
+    for _ in range(tries):
+        try:
+            return socket.create_connection(("127.0.0.1", port), timeout=1.0)
+        except OSError:
+            time.sleep(0.1)
+    return None
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        assert chunk, "connection closed early"
+        buf += chunk
+    return bytes(buf)
+
+
+@pytest.mark.gpu
+def test_render_server_survives_rude_clients(snapshot):
+    """A client that disconnects in the middle of a reply must not end the server (the reference ignores SIGPIPE
+    through sockpp::socket_initializer), a remote "QUIT" is an ordinary (degenerate) pose unless the test hook is
+    enabled, and an extended request larger than one launch is served in bounded chunks."""
+    path, desc, keep, cfg = snapshot
+    W, H, port = 256, 192, 23461
+    env = dict(os.environ, NRF_SERVER_BIND="127.0.0.1")
+    env.pop("NRF_SERVER_TEST_HOOKS", None)
+    srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, env=env)
+    try:
+        pose = np.ascontiguousarray(syn.REFERENCE_MAIN_POSE, np.float32).tobytes()
+        for _ in range(3):  # pipelined requests, then gone without reading a byte: the replies hit a closed socket
+            rude = _connect(port)
+            assert rude is not None, "server did not come up"
+            rude.sendall(pose * 4)
+            rude.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, b"\x01\x00\x00\x00\x00\x00\x00\x00")  # RST on close
+            rude.close()
+        time.sleep(0.5)
+        assert srv.poll() is None, "the server died of a disconnected client"
+        s = _connect(port)
+        assert s is not None
+        s.settimeout(60)
+        quit_msg = np.zeros(16, np.float32)
+        quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
+        s.sendall(quit_msg.tobytes())              # without the hook: a pose like any other -> one frame comes back
+        _recv_exact(s, 3 * W * H)
+        assert srv.poll() is None
+        # 40 views in one extended request = two launches (NRF_MAX_VIEWS = 32), answers in request order
+        cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
+        views = [syn.orbit_pose(9.0 * i, 25.0) for i in range(40)]
+        msg = b"NRF1" + np.uint32(len(views)).tobytes()
+        for p in views:
+            msg += cam.tobytes() + np.ascontiguousarray(p, np.float32).tobytes()
+        s.sendall(msg)
+        frames = [np.frombuffer(_recv_exact(s, 3 * W * H), np.uint8).reshape(H, W, 3) for _ in views]
+        ctx = nh.NerfHip(0)
+        ctx.load_model(desc)
+        ctx.set_resolution(W, H)
+        for i in (0, 31, 32, 39):
+            ctx.render(cam, views[i])
+            np.testing.assert_array_equal(frames[i], ctx.read_u8()[0])
+        ctx.close()
+        s.close()
+        assert srv.poll() is None
+    finally:
+        srv.kill()
+        srv.wait(timeout=20)
+
+
+def test_snapshot_parser_rejects_hostile_input(tmp_path):
+    """The msgpack reader trusts nothing: an array/map length larger than the bytes that follow, or nesting deep
+    enough to exhaust the stack, is an error message -- not a 16 GiB reservation or a crash."""
+    cases = {
+        "huge_array": b"\x81\xa8snapshot\xdd\xff\xff\xff\xff\x01\x02",            # array32 of 2^32-1 elements, 2 present
+        "huge_map": b"\x81\xa8snapshot\xdf\xff\xff\xff\xff",                        # map32 of 2^32-1 pairs
+        "deep": b"\x81\xa8snapshot" + b"\x91" * 100000 + b"\x00",                      # 100 000 nested one-element arrays
+        "zero_F": None,
+    }
+    import msgpack
+    cases["zero_F"] = msgpack.packb({"encoding": {"otype": "HashGrid", "n_features_per_level": 0, "n_features": 32},
+                                     "snapshot": {"aabb": [-1, -1, -1, 1, 1, 1], "density_grid_size": 1, "density_grid": [0.0],
+                                                  "params": [0.0]}}, use_single_float=True)
+    for name, blob in cases.items():
+        f = tmp_path / f"{name}.msgpack"
+        f.write_bytes(blob)
+        r = _info(f)
+        assert r.returncode == 1, (name, r.returncode, r.stderr[-300:])   # 1 = caught exception; a signal would be negative
+        assert "error" in r.stderr.lower() or "msgpack" in r.stderr or "must be" in r.stderr, (name, r.stderr[-300:])

@@ -574,6 +574,39 @@ def test_device_group_equals_single_context(ctx):
         g.close()
 
 
+def test_device_group_on_distinct_devices(ctx):
+    """nrf_group_* with members on DIFFERENT devices: hipDeviceEnablePeerAccess + hipMemcpyPeerAsync over xGMI
+    (csrc/nrf_group.hip), which the single-device rehearsal above cannot exercise.  Runs wherever at least two GPUs
+    are visible (the driver's 8-GPU node); skipped on a one-GPU box."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two visible GPUs")
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    W, H = 328, 200
+    n = 3
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    poses = np.stack([syn.orbit_pose(70.0 * i, 25.0) for i in range(n)])
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    ctx.set_max_views(n)
+    ctx.render_views(cams, poses)
+    want = [ctx.read_view_f32(i) for i in range(n)]
+    want_samples = ctx.stats().n_samples
+    ctx.set_max_views(1)
+    for members in sorted({2, min(n_dev, 4), min(n_dev, 8)}):
+        g = nh.NerfGroup(list(range(members)))
+        g.load_model(desc)
+        g.set_resolution(W, H)
+        g.render_views(cams, poses)
+        assert g.stats().n_samples == want_samples
+        for i in range(n):
+            rgba, depth = g.read_view_f32(i)
+            np.testing.assert_array_equal(rgba, want[i][0])
+            np.testing.assert_array_equal(depth, want[i][1])
+        g.close()
+
+
 @pytest.mark.parametrize("radius,az,el,fl_scale", [(0.9, 40, 10, 1.0), (0.3, 200, 35, 0.4), (2.2, 310, 80, 3.0), (1.5, 0, -89, 1.0)])
 def test_region_of_interest_cull_is_conservative(ctx, small, radius, az, el, fl_scale):
     """The per-view pixel rectangle outside of which strips are filled with the background without
@@ -692,3 +725,48 @@ def test_other_grid_types_encode_and_render(ctx, kw):
     rgba, depth, st, wantf, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
     assert st.n_samples > 0
     assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0
+
+
+@pytest.mark.parametrize("bound,cascade,aabb_half", [(2.0, 1, 2.0), (1.0, 1, 1.5), (4.0, 2, 4.0)])
+def test_occupied_boundary_layer_outside_the_outermost_cube(ctx, bound, cascade, aabb_half):
+    """The march clamps positions to +-bound and then the cell index to [0, H-1] (render_utils.h:595-611), so with
+    bound > 2^(cascade-1) -- or an aabb wider than +-bound -- positions OUTSIDE the outermost cube are looked up in
+    its boundary cells.  With that layer occupied the reference emits samples out there; the kernel's box of
+    occupied cells, region of interest and visibility walk must not cut them."""
+    Hg = 32
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=Hg, bound=bound, cascade=cascade)
+    grid = keep[1].reshape(cascade, Hg, Hg, Hg).copy()
+    top = grid[cascade - 1]
+    top[Hg - 1, 8:24, 8:24] = 1.0   # +x face of the outermost cascade
+    top[10:20, 0, 10:20] = 1.0      # -y face
+    top[12:18, 12:18, Hg - 1] = 1.0  # +z face
+    cfg = dict(cfg)
+    cfg["snapshot"] = dict(cfg["snapshot"], aabb=[-aabb_half] * 3 + [aabb_half] * 3, mean_density=float(grid.mean()))
+    d2, k2 = nh.desc_from_config(cfg, keep[0], grid.reshape(-1))
+    ctx.load_model(d2)
+    o = op.Oracle(d2)
+    W, H = 96, 64
+    cam = syn.default_camera(W, H) * np.float32(0.5)  # wide field of view: the faces are in the picture
+    cam[2:] = (W * 0.5, H * 0.5)
+    for az, el, radius in ((20, 25, 4.0311), (200, -30, 9.0), (95, 60, 2.0)):
+        pose = syn.orbit_pose(az, el, radius=radius)
+        ro, rd, nr, fr = _rays(ctx, o, W, H, cam, pose)
+        n = W * H
+        xyzs = torch.empty((n, 4, 3), device="cuda"); dirs = torch.empty((n, 4, 3), device="cuda")
+        deltas = torch.empty((n, 4, 2), device="cuda")
+        sync()
+        ctx.march(ro.data_ptr(), rd.data_ptr(), nr.data_ptr(), fr.data_ptr(), n, 4, xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr())
+        wx, wd, wdl = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), 4)
+        np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
+        # the scene of this test: samples exist beyond the outermost cube's faces
+        outer = min(2.0 ** (cascade - 1), bound)
+        emitted = wdl[..., 0] > 0
+        far_out = np.abs(wx[emitted]).max(axis=-1)
+        if bound > outer:
+            assert (far_out > outer * (1 + 2.0 / Hg)).any()
+        elif aabb_half > bound:
+            assert (far_out == bound).any()  # positions beyond +-bound, clamped onto the face
+        rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
+        assert st.n_samples >= wst.n_samples * 0.995 - 8, (st.n_samples, wst.n_samples)  # nothing was culled away
+        assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
+        assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
