@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 2
+#define NRF_ABI_VERSION 3
 #define NRF_MAX_VIEWS 32 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -58,12 +58,15 @@ enum {
 };
 /* direction encodings, T/src/encoding.cu:97-117 */
 enum {
-  NRF_DIR_SH = 0,        /* SphericalHarmonics, degree 1..8 (4 on the hot path) */
-  NRF_DIR_FREQUENCY = 1, /* Frequency, n_frequencies                            */
+  NRF_DIR_SH = 0,        /* SphericalHarmonics, degree 1..8                     */
+  NRF_DIR_FREQUENCY = 1, /* Frequency, n_frequencies 1..18 (tcnn's default: 12)  */
   NRF_DIR_IDENTITY = 2
 };
 /* hash-grid flavours, T/include/tiny-cuda-nn/encodings/grid.h:1366-1367 */
 enum { NRF_GRID_HASH = 0, NRF_GRID_DENSE = 1, NRF_GRID_TILED = 2 };
+/* grid interpolation, T/include/tiny-cuda-nn/encodings/grid.h:1383 ("interpolation": Nearest | Linear | Smoothstep),
+ * kernel_grid :196-232 */
+enum { NRF_INTERP_LINEAR = 0, NRF_INTERP_NEAREST = 1, NRF_INTERP_SMOOTHSTEP = 2 };
 
 /* ---- model description ---------------------------------------------------
  * Replaces: NerfRender::load_snapshot + reset_network + NerfNetwork ctor +
@@ -76,17 +79,21 @@ typedef struct nrf_model_desc {
   /* "encoding" block (position hash grid, 3-D input) */
   uint32_t grid_type;             /* NRF_GRID_*                               */
   uint32_t n_levels;              /* L, <= 16                                 */
-  uint32_t n_features_per_level;  /* F, only 2 on the HIP path                */
+  uint32_t n_features_per_level;  /* F in {1, 2, 4, 8} (grid.h:1403-1411)     */
   uint32_t log2_hashmap_size;     /* log2 T                                   */
   uint32_t base_resolution;       /* Nmin                                     */
   float per_level_scale;          /* b (already derived, nerf_render.cu:158)  */
+  uint32_t interpolation;         /* NRF_INTERP_*                             */
 
-  /* "network" (density MLP) and "rgb_network" blocks */
-  uint32_t n_neurons;              /* 64 on the HIP path                      */
+  /* "network" (density MLP) and "rgb_network" blocks: FullyFusedMLP widths 16/32/64/128, any number of hidden
+   * layers >= 1 (T/src/fully_fused_mlp.cu:636-687, 700-725).  L = 16, F = 2, 64 neurons, 1 + 2 hidden layers, a
+   * 16-wide direction encoding, ReLU / None / Exponential activations (the reference's base.json) run in the
+   * register-resident instance of the fused kernel; every other combination in its generic instance.           */
+  uint32_t n_neurons;
   uint32_t density_hidden_layers;  /* n_hidden_layers of "network"            */
   uint32_t density_activation;     /* hidden activation                       */
   uint32_t density_output_activation;
-  uint32_t density_n_output;       /* 16 (nerf_network.h:120-122)             */
+  uint32_t density_n_output;       /* 1..16, padded to 16 rows (nerf_network.h:120-122) */
   uint32_t sigma_activation;       /* nerf_network.h:125, default Exponential */
   uint32_t rgb_hidden_layers;
   uint32_t rgb_activation;
@@ -111,7 +118,8 @@ typedef struct nrf_model_desc {
    * last [16 x n_neurons], row-major [out][in], no biases.                   */
   const float* params;
   uint64_t n_params;
-  /* float density grid [C*H*H*H], index level*H^3 + x*H^2 + y*H + z          */
+  /* float density grid [C*H*H*H], index level*H^3 + x*H^2 + y*H + z; NULL (n = 0): the snapshot carries
+   * none -- nrf_generate_density_grid evaluates one from the network before the first render              */
   const float* density_grid;
   uint64_t n_density_grid;
 } nrf_model_desc;
@@ -194,6 +202,15 @@ int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t 
 
 /* load_snapshot + reset_network + deserialize                                */
 int nrf_load_model(nrf_context* ctx, const nrf_model_desc* d);
+/* NerfRender::generate_density_grid, nerf_render.cu:388-429 (dead and incomplete in the reference: its density
+ * query is commented out at :415).  Completed as its origin (torch-ngp's update_extra_state) defines it: for every
+ * cascade, the density network at every cell position (init_xyzs / dd_scale, render_utils.h:79-108; no random
+ * perturbation), scaled by 0.001691, folded into a grid that starts at 1/64 by g = max(g * decay, value)
+ * (dg_update, render_utils.h:120-128) n_iterations times; mean_density = mean(max(g, 0)).  Replaces the model's
+ * density grid and rebuilds the occupancy structures of the march.  nrf_read_density_grid returns the float grid
+ * [cascade * H^3] the march currently uses (snapshot's or generated) and its mean_density.                        */
+int nrf_generate_density_grid(nrf_context* ctx, int n_iterations, float decay, float* mean_density);
+int nrf_read_density_grid(nrf_context* ctx, float* grid, uint64_t n, float* mean_density);
 /* NerfRender::set_resolution, nerf_render.cu:186-236 (idempotent here)       */
 int nrf_set_resolution(nrf_context* ctx, int width, int height);
 int nrf_set_options(nrf_context* ctx, const nrf_options* o);
@@ -289,16 +306,19 @@ int nrf_group_get_stats(nrf_group* grp, nrf_stats* s); /* sums; render_ms = slow
 
 /* ---- stage entry points (unit parity against the oracle) -----------------
  * All pointers are DEVICE pointers, n = number of samples / rays.            */
-/* kernel_grid<half,3,2>, grid.h:139-268.  pos01 [n][3] in [0,1];
- * out fp16 [n][2L]                                                           */
+/* kernel_grid<half,3,F>, grid.h:139-268.  pos01 [n][3] in [0,1];
+ * out fp16 [n][next_multiple(L*F, 16)] (padding columns are 0, grid.h:959-969) */
 int nrf_encode_grid(nrf_context* ctx, const void* pos01, uint32_t n, void* out_f16,
                     void* stream);
-/* kernel_sh / frequency_encoding.  dir01 [n][3] in [0,1]; out fp16 [n][16]   */
+/* kernel_sh / frequency_encoding / identity.  dir01 [n][3] in [0,1];
+ * out fp16 [n][next_multiple(raw width, 16)]: 16 for SH <= 4, 64 for SH 8,
+ * 80 for Frequency with 12 frequencies                                       */
 int nrf_encode_dir(nrf_context* ctx, const void* dir01, uint32_t n, void* out_f16,
                    void* stream);
 /* kernel_mlp_fused x2 + extract_density (nerf_network.h:148-196) on
- * pre-encoded inputs: feat fp16 [n][32], dirfeat fp16 [n][16] ->
- * out fp16 [n][4] = (r,g,b,sigma)                                            */
+ * pre-encoded inputs: feat fp16 [n][feature width], dirfeat fp16 [n][dir
+ * width] (the widths of nrf_encode_grid / nrf_encode_dir: 32 and 16 for the
+ * base configuration) -> out fp16 [n][4] = (r,g,b,sigma)                     */
 int nrf_mlp_forward(nrf_context* ctx, const void* feat_f16, const void* dirfeat_f16,
                     uint32_t n, void* out_f16, void* stream);
 /* Measurement aid: the same call, every chunk of samples evaluated `repeat`

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "nrf_device.h"
+#include "nrf_generic.h"
 #include "nrf_launch.h"
 
 using namespace nrf;
@@ -90,7 +91,7 @@ int expected_params(const nrf_model_desc& d, const nrf_level_table& t, uint64_t&
   const uint64_t feat = next_multiple(d.n_levels * d.n_features_per_level, 16u);
   const uint64_t rgb_in = next_multiple(next_multiple(raw, 16u) + 16u, 16u);
   if (d.density_hidden_layers < 1 || d.rgb_hidden_layers < 1)
-    return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer");  // fully_fused_mlp.cu:654
+    return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");  // fully_fused_mlp.cu:653-655
   auto mlp = [&](uint64_t in, uint64_t hidden) { return in * Wn + (hidden - 1) * Wn * Wn + Wn * 16; };
   n = mlp(feat, d.density_hidden_layers) + mlp(rgb_in, d.rgb_hidden_layers) +
       (uint64_t)t.offset[d.n_levels] * d.n_features_per_level;
@@ -123,6 +124,19 @@ void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& fra
   for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
 }
 
+// Generic instance (nrf_generic.h gen_layer): fragment (m, s) of a layer W[N][K], lane l, element j =
+// W[16 m + (l & 15)][32 s + 8 (l >> 4) + j]  (natural K order), zero beyond K.
+void pack_generic_layer(const _Float16* Wm, uint32_t N, uint32_t K, std::vector<_Float16>& frags) {
+  const uint32_t n_tiles = N / 16, k_steps = (K + 31) / 32;
+  for (uint32_t m = 0; m < n_tiles; ++m)
+    for (uint32_t s = 0; s < k_steps; ++s)
+      for (uint32_t l = 0; l < 64; ++l)
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t k = 32 * s + 8 * (l >> 4) + j;
+          frags.push_back(k < K ? Wm[(size_t)(16 * m + (l & 15)) * K + k] : (_Float16)0.0f);
+        }
+}
+
 // R/include/nerf-cuda/render_utils.h:68-77
 void nerf_matrix_to_ngp(const float p[16], float s, float R[9], float org[3]) {
   const int rows[3] = {1, 2, 0};
@@ -152,6 +166,10 @@ struct nrf_context {
   void* d_coarse = nullptr;
   void* d_dilated = nullptr;
   void* d_ctab = nullptr;
+  void* d_gen = nullptr;
+  GenModel gen{};  // host copy of the generic instance's description (valid when dm.generic)
+  std::vector<float> host_grid;  // the float density grid the march tables were built from
+  bool grid_missing = false;     // loaded without a density grid and none generated yet
   nrf_options opt{};
   int W = 0, H = 0;
   int n_local_tiles = 0;
@@ -188,7 +206,8 @@ void free_model(nrf_context* c) {
   if (c->d_coarse) (void)hipFree(c->d_coarse);
   if (c->d_ctab) (void)hipFree(c->d_ctab);
   if (c->d_dilated) (void)hipFree(c->d_dilated);
-  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = nullptr;
+  if (c->d_gen) (void)hipFree(c->d_gen);
+  c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = c->d_gen = nullptr;
   c->model_loaded = false;
 }
 
@@ -295,149 +314,25 @@ void view_roi(const float R[9], const float org[3], const float cam[4], const fl
   roi[3] = y1 < -1 ? -1 : (y1 > H - 1 ? H - 1 : (int)y1);
 }
 
-int need_model(nrf_context* c) {
-  if (!c) return fail(NRF_E_INVALID, "null context");
-  if (!c->model_loaded) return fail(NRF_E_STATE, "no model loaded (call nrf_load_model first)");
-  return set_device(c);
-}
-
-}  // namespace
-
-extern "C" {
-
-const char* nrf_last_error(void) { return g_err.c_str(); }
-void nrf_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by nrf_renderbuffer.hip
-int nrf_abi_version(void) { return NRF_ABI_VERSION; }
-
-void nrf_default_options(nrf_options* o) {
-  if (!o) return;
-  o->bg_color = 1.0f;
-  o->min_near = 0.2f;
-  o->dt_gamma = 1.0f / 128.0f;
-  o->max_steps = 1024;
-  o->density_scale = 1.0f;
-  o->perturb = 0;
-  o->shard_index = 0;
-  o->shard_count = 1;
-}
-
-int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t) {
-  if (!d || !t) return fail(NRF_E_INVALID, "null argument");
-  return compute_level_table(*d, *t);
-}
-
-int nrf_expected_n_params(const nrf_model_desc* d, uint64_t* n) {
-  if (!d || !n) return fail(NRF_E_INVALID, "null argument");
-  nrf_level_table t;
-  int rc = compute_level_table(*d, t);
-  if (rc) return rc;
-  return expected_params(*d, t, *n);
-}
-
-int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t n_levels, float* out) {
-  if (!out || n_levels < 2 || base_resolution == 0) return fail(NRF_E_INVALID, "bad argument");
-  const float desired_resolution = 2048.0f;  // R/src/nerf_render.cu:154-165
-  *out = std::exp(std::log(desired_resolution * bound / (float)base_resolution) / (float)(n_levels - 1));
-  return NRF_OK;
-}
-
-int nrf_tiles_per_shard(int width, int height, int shard_count, int* n) {
-  if (!n || width <= 0 || height <= 0 || shard_count <= 0) return fail(NRF_E_INVALID, "bad argument");
-  *n = 4 * ((total_strips(width, height) + shard_count - 1) / shard_count);
-  return NRF_OK;
-}
-
-int nrf_create(int device, nrf_context** out) {
-  if (!out) return fail(NRF_E_INVALID, "null argument");
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0)
-    return fail(NRF_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (device < 0 || device >= count) return fail(NRF_E_NODEVICE, "device index out of range");
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NRF_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  nrf_context* c = new nrf_context;
-  c->device = device;
-  nrf_default_options(&c->opt);
-  if (const char* e = std::getenv("NRF_MARCH_BUDGET")) {
-    const int b = std::atoi(e);
-    if (b >= 1 && b <= 4096) c->march_budget = b;
-  }
-  HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&c->ev0));
-  HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES));
-  HIP_TRY(hipMemset(c->d_counters, 0, COUNTER_BYTES));
-  *out = c;
-  return NRF_OK;
-}
-
-int nrf_destroy(nrf_context* c) {
-  if (!c) return NRF_OK;
-  (void)hipSetDevice(c->device);
-  (void)hipDeviceSynchronize();
-  free_model(c);
-  free_frame(c);
-  if (c->d_counters) (void)hipFree(c->d_counters);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
-  delete c;
-  return NRF_OK;
-}
-
-int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
-  if (!c || !d || !d->params || !d->density_grid) return fail(NRF_E_INVALID, "null argument");
-  if (d->abi_version != NRF_ABI_VERSION) return fail(NRF_E_INVALID, "abi_version mismatch");
-  int rc = set_device(c);
-  if (rc) return rc;
-  // what the HIP path implements (everything else is refused loudly, never emulated on the CPU)
-  if (d->n_features_per_level != 2) return fail(NRF_E_UNSUPPORTED, "HIP path: n_features_per_level must be 2");
-  if (d->n_levels != 16) return fail(NRF_E_UNSUPPORTED, "HIP path: n_levels must be 16");
-  if (d->n_neurons != 64) return fail(NRF_E_UNSUPPORTED, "HIP path: n_neurons must be 64");
-  if (d->density_hidden_layers != 1 || d->rgb_hidden_layers != 2)
-    return fail(NRF_E_UNSUPPORTED, "HIP path: density MLP must have 1 and rgb MLP 2 hidden layers");
-  if (d->density_n_output != 16) return fail(NRF_E_UNSUPPORTED, "HIP path: density n_output_dims must be 16");
-  const uint32_t raw = dir_raw_width(*d);
-  if (raw == 0 || raw > 16) return fail(NRF_E_UNSUPPORTED, "HIP path: direction encoding must fit 16 outputs");
-  if (d->dir_encoding == NRF_DIR_SH && (d->sh_degree < 1 || d->sh_degree > 4))
-    return fail(NRF_E_UNSUPPORTED, "HIP path: SH degree must be 1..4");
-  if (d->density_grid_size < 2 || d->density_grid_size >= (1u << 24) || d->cascade < 1)
-    return fail(NRF_E_INVALID, "bad density grid geometry");
-  if (!(d->bound > 0.0f)) return fail(NRF_E_INVALID, "bound must be positive");
-
-  nrf_level_table lv;
-  rc = compute_level_table(*d, lv);
-  if (rc) return rc;
-  uint64_t expect = 0;
-  rc = expected_params(*d, lv, expect);
-  if (rc) return rc;
-  if (d->n_params != expect)  // R/include/nerf-cuda/nerf_network.h:425-427
-    return fail(NRF_E_PARAMS, "Can't set params because number of parameters and model size do not match with each other.");
+// Everything the march needs from the density grid (reference: the float grid [C*H^3] of load_snapshot,
+// nerf_render.cu:441-466, read by kernel_march_rays): occupancy bits, coarse occupancy, the box of occupied cells,
+// the dilated coarse sets of the visibility walk and the cell-boundary table.  Called by nrf_load_model with the
+// snapshot's grid and by nrf_generate_density_grid with the one evaluated from the network.  Needs c->desc, and
+// c->dm.generic / gen_wave_bytes (LDS budget of the tables).
+int set_density_grid(nrf_context* c, const float* density_grid, float mean_density) {
+  const nrf_model_desc* d = &c->desc;
   const uint64_t Hh = d->density_grid_size;
   const uint64_t cells = Hh * Hh * Hh * d->cascade;
-  if (d->n_density_grid != cells)  // R/src/nerf_render.cu:467-469
-    return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
-  if (cells >= (1ull << 32)) return fail(NRF_E_UNSUPPORTED, "density grid too large");
-
-  HIP_TRY(hipDeviceSynchronize());  // nothing may still be reading the old model
-  free_model(c);
-  // fp32 -> fp16 cast of every parameter (nerf_network.h:434-436), order: density MLP | rgb MLP | grid
-  const size_t n_mlp = 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64;
-  std::vector<_Float16> w16(n_mlp);
-  for (size_t i = 0; i < n_mlp; ++i) w16[i] = (_Float16)d->params[i];
-  std::vector<_Float16> frags;
-  pack_fragments(w16, frags);
-  const size_t n_grid = (size_t)lv.offset[16] * 2;
-  const float* gp = d->params + n_mlp;
+  HIP_TRY(hipDeviceSynchronize());  // nothing may still be marching on the old tables
+  for (void** q : {&c->d_occ, &c->d_coarse, &c->d_ctab, &c->d_dilated}) {
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+  }
   // occupancy bitfield: grid[cell] > min(0.01, mean_density) (render_utils.h:560,619), decided once
-  const float thresh = fminf(0.01f, d->mean_density);
+  const float thresh = fminf(0.01f, mean_density);
   std::vector<uint32_t> occ((cells + 31) / 32 + 1, 0u);
   for (uint64_t i = 0; i < cells; ++i)
-    if (d->density_grid[i] > thresh) occ[i >> 5] |= 1u << (i & 31);
+    if (density_grid[i] > thresh) occ[i >> 5] |= 1u << (i & 31);
 
   // march tables (nrf_device.h march_next): coarse occupancy = OR over 4x4x4 cell blocks, and the
   // cell-boundary table ((v/(H-1))*2-1)*mip_bound in the reference's fp32 operation order
@@ -552,40 +447,266 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     for (uint32_t v = 0; v <= Hs; ++v) ctab[(size_t)level * (Hs + 1) + v] = ((float)v / Hm1 * 2 - 1) * mip_bound;
   }
 
+  auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
+  if (coarse_shift) HIP_TRY(upload(&c->d_coarse, coarse.data(), coarse.size() * 4));
+  HIP_TRY(upload(&c->d_ctab, ctab.data(), ctab.size() * 4));
+  if (!dilated.empty()) HIP_TRY(upload(&c->d_dilated, dilated.data(), dilated.size() * 4));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());
+  DevModel& M = c->dm;
+  M.occ_bits = (const uint32_t*)c->d_occ;
+  for (int i = 0; i < 6; ++i) M.occ_box[i] = occ_box[i];
+  M.occ_coarse = (const uint32_t*)c->d_coarse;
+  M.cell_bound = (const float*)c->d_ctab;
+  M.occ_dilated = (const uint32_t*)c->d_dilated;
+  M.coarse_shift = coarse_shift;
+  M.lds_coarse_words = M.lds_ctab_floats = M.lds_dilated_words = 0;
+  {
+    const uint64_t words = coarse_shift ? (uint64_t)coarse.size() : 0, fl = ctab.size();
+    uint64_t budget = (uint64_t)render_lds_table_max_bytes();
+    if (M.generic) {  // whatever the generic instance's rows leave of the CU's 160 KiB
+      const uint64_t used = (uint64_t)render_gen_lds_fixed_bytes(M.gen_wave_bytes);
+      budget = used + budget <= 160u * 1024u ? budget : 160u * 1024u - used;
+    }
+    if (coarse_shift && 4 * (words + fl) <= budget) {
+      M.lds_coarse_words = (uint32_t)words;
+      M.lds_ctab_floats = (uint32_t)fl;
+    }
+  }
+  M.dilated_level_words = dilated_level_words;
+  if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
+  c->desc.mean_density = mean_density;
+  c->host_grid.assign(density_grid, density_grid + cells);
+  return NRF_OK;
+}
+
+int need_model(nrf_context* c) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if (!c->model_loaded) return fail(NRF_E_STATE, "no model loaded (call nrf_load_model first)");
+  return set_device(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nrf_last_error(void) { return g_err.c_str(); }
+void nrf_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by nrf_renderbuffer.hip
+int nrf_abi_version(void) { return NRF_ABI_VERSION; }
+
+void nrf_default_options(nrf_options* o) {
+  if (!o) return;
+  o->bg_color = 1.0f;
+  o->min_near = 0.2f;
+  o->dt_gamma = 1.0f / 128.0f;
+  o->max_steps = 1024;
+  o->density_scale = 1.0f;
+  o->perturb = 0;
+  o->shard_index = 0;
+  o->shard_count = 1;
+}
+
+int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t) {
+  if (!d || !t) return fail(NRF_E_INVALID, "null argument");
+  return compute_level_table(*d, *t);
+}
+
+int nrf_expected_n_params(const nrf_model_desc* d, uint64_t* n) {
+  if (!d || !n) return fail(NRF_E_INVALID, "null argument");
+  nrf_level_table t;
+  int rc = compute_level_table(*d, t);
+  if (rc) return rc;
+  return expected_params(*d, t, *n);
+}
+
+int nrf_default_per_level_scale(float bound, uint32_t base_resolution, uint32_t n_levels, float* out) {
+  if (!out || n_levels < 2 || base_resolution == 0) return fail(NRF_E_INVALID, "bad argument");
+  const float desired_resolution = 2048.0f;  // R/src/nerf_render.cu:154-165
+  *out = std::exp(std::log(desired_resolution * bound / (float)base_resolution) / (float)(n_levels - 1));
+  return NRF_OK;
+}
+
+int nrf_tiles_per_shard(int width, int height, int shard_count, int* n) {
+  if (!n || width <= 0 || height <= 0 || shard_count <= 0) return fail(NRF_E_INVALID, "bad argument");
+  *n = 4 * ((total_strips(width, height) + shard_count - 1) / shard_count);
+  return NRF_OK;
+}
+
+int nrf_create(int device, nrf_context** out) {
+  if (!out) return fail(NRF_E_INVALID, "null argument");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(NRF_E_NODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(NRF_E_NODEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NRF_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  nrf_context* c = new nrf_context;
+  c->device = device;
+  nrf_default_options(&c->opt);
+  if (const char* e = std::getenv("NRF_MARCH_BUDGET")) {
+    const int b = std::atoi(e);
+    if (b >= 1 && b <= 4096) c->march_budget = b;
+  }
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES));
+  HIP_TRY(hipMemset(c->d_counters, 0, COUNTER_BYTES));
+  *out = c;
+  return NRF_OK;
+}
+
+int nrf_destroy(nrf_context* c) {
+  if (!c) return NRF_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  free_model(c);
+  free_frame(c);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return NRF_OK;
+}
+
+int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
+  if (!c || !d || !d->params) return fail(NRF_E_INVALID, "null argument");
+  if (d->abi_version != NRF_ABI_VERSION) return fail(NRF_E_INVALID, "abi_version mismatch");
+  int rc = set_device(c);
+  if (rc) return rc;
+  // what the reference's vocabulary allows (T/.../grid.h:1403-1411, T/src/fully_fused_mlp.cu:700-725, 653-655;
+  // spherical_harmonics.h:394-412); anything outside is refused loudly, never emulated on the CPU
+  const uint32_t F = d->n_features_per_level;
+  if (F != 1 && F != 2 && F != 4 && F != 8) return fail(NRF_E_INVALID, "GridEncoding: n_features_per_level must be 1, 2, 4, or 8.");
+  if (d->interpolation > NRF_INTERP_SMOOTHSTEP) return fail(NRF_E_INVALID, "Invalid interpolation type");
+  if (d->n_neurons != 16 && d->n_neurons != 32 && d->n_neurons != 64 && d->n_neurons != 128)
+    return fail(NRF_E_INVALID, "FullyFusedMLP: n_neurons must be 16, 32, 64 or 128");
+  if (d->density_hidden_layers < 1 || d->rgb_hidden_layers < 1)
+    return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");
+  if (d->density_hidden_layers + d->rgb_hidden_layers + 2 > (uint32_t)GEN_MAX_LAYERS)
+    return fail(NRF_E_UNSUPPORTED, "HIP path: more than 24 layers in the two MLPs together");
+  if (d->density_n_output < 1 || d->density_n_output > 16)  // wider outputs take tcnn's CUTLASS last layer (out of scope)
+    return fail(NRF_E_UNSUPPORTED, "HIP path: density n_output_dims must be 1..16");
+  const uint32_t raw = dir_raw_width(*d);
+  if (d->dir_encoding == NRF_DIR_SH && (d->sh_degree < 1 || d->sh_degree > 8))
+    return fail(NRF_E_INVALID, "SphericalHarmonics: degree must be 1..8");
+  if (raw == 0 || next_multiple(raw, 16u) > (uint32_t)GEN_MAX_DIR_W)
+    return fail(NRF_E_UNSUPPORTED, "HIP path: direction encoding must have 1..112 outputs (after padding to 16)");
+  if (d->density_grid_size < 2 || d->density_grid_size >= (1u << 24) || d->cascade < 1)
+    return fail(NRF_E_INVALID, "bad density grid geometry");
+  if (!(d->bound > 0.0f)) return fail(NRF_E_INVALID, "bound must be positive");
+
+  nrf_level_table lv;
+  rc = compute_level_table(*d, lv);
+  if (rc) return rc;
+  uint64_t expect = 0;
+  rc = expected_params(*d, lv, expect);
+  if (rc) return rc;
+  if (d->n_params != expect)  // R/include/nerf-cuda/nerf_network.h:425-427
+    return fail(NRF_E_PARAMS, "Can't set params because number of parameters and model size do not match with each other.");
+  const uint64_t Hh = d->density_grid_size;
+  const uint64_t cells = Hh * Hh * Hh * d->cascade;
+  if (d->density_grid && d->n_density_grid != cells)  // R/src/nerf_render.cu:467-469
+    return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
+  if (cells >= (1ull << 32)) return fail(NRF_E_UNSUPPORTED, "density grid too large");
+
+  HIP_TRY(hipDeviceSynchronize());  // nothing may still be reading the old model
+  free_model(c);
+  // fp32 -> fp16 cast of every parameter (nerf_network.h:434-436), order: density MLP | rgb MLP | grid;
+  // each MLP: first [W x in] | hidden [W x W] ... | last [16 x W] (fully_fused_mlp.cu:636-687)
+  const uint32_t L = d->n_levels, Wn = d->n_neurons;
+  const uint32_t feat_raw = L * F, feat_w = next_multiple(feat_raw, 16u);
+  const uint32_t dir_w = next_multiple(raw, 16u), rgb_in = 16u + dir_w;
+  struct LayerDim { uint32_t N, K, act; };
+  std::vector<LayerDim> layers;
+  auto add_mlp = [&](uint32_t in, uint32_t hidden, uint32_t act, uint32_t out_act) {
+    layers.push_back({Wn, in, act});
+    for (uint32_t i = 1; i < hidden; ++i) layers.push_back({Wn, Wn, act});
+    layers.push_back({16u, Wn, out_act});
+  };
+  add_mlp(feat_w, d->density_hidden_layers, d->density_activation, d->density_output_activation);
+  add_mlp(rgb_in, d->rgb_hidden_layers, d->rgb_activation, d->rgb_output_activation);
+  size_t n_mlp = 0;
+  for (const LayerDim& ly : layers) n_mlp += (size_t)ly.N * ly.K;
+  std::vector<_Float16> w16(n_mlp);
+  for (size_t i = 0; i < n_mlp; ++i) w16[i] = (_Float16)d->params[i];
+  const size_t n_grid = (size_t)lv.offset[L] * F;
+  const float* gp = d->params + n_mlp;
   std::vector<LevelParams> lp(16);
   bool generic_grid = false;
-  for (uint32_t l = 0; l < 16; ++l) {
-    LevelParams& L = lp[l];
-    std::memset(&L, 0, sizeof(L));
-    L.scale = lv.scale[l];
-    L.res = lv.resolution[l];
-    L.size = lv.offset[l + 1] - lv.offset[l];
-    L.hashed = d->grid_type == NRF_GRID_HASH;
+  for (uint32_t l = 0; l < 16; ++l) std::memset(&lp[l], 0, sizeof(LevelParams));
+  for (uint32_t l = 0; l < L; ++l) {
+    LevelParams& Lv = lp[l];
+    Lv.scale = lv.scale[l];
+    Lv.res = lv.resolution[l];
+    Lv.size = lv.offset[l + 1] - lv.offset[l];
+    Lv.hashed = d->grid_type == NRF_GRID_HASH;
     // replay grid_index's stride loop (grid.h:106-114) in uint32 to classify the level
     uint32_t stride = 1;
     int dims = 0;
-    for (; dims < 3 && stride <= L.size; ++dims) stride *= L.res;
-    const bool uses_hash = L.hashed && L.size < stride;
-    if (uses_hash && (L.size & (L.size - 1)) == 0) L.mode = LV_HASH_POW2;
-    else if (!uses_hash && dims == 3 && L.res >= 2 && (uint64_t)L.res * L.res * L.res <= L.size) L.mode = LV_DENSE;
-    else L.mode = LV_GENERIC;
-    generic_grid = generic_grid || L.mode == LV_GENERIC;
+    for (; dims < 3 && stride <= Lv.size; ++dims) stride *= Lv.res;
+    const bool uses_hash = Lv.hashed && Lv.size < stride;
+    if (uses_hash && (Lv.size & (Lv.size - 1)) == 0) Lv.mode = LV_HASH_POW2;
+    else if (!uses_hash && dims == 3 && Lv.res >= 2 && (uint64_t)Lv.res * Lv.res * Lv.res <= Lv.size) Lv.mode = LV_DENSE;
+    else Lv.mode = LV_GENERIC;
+    generic_grid = generic_grid || Lv.mode == LV_GENERIC;
   }
+  // The register-resident instance is the shape of the reference's base.json; everything else is the generic one.
+  const bool generic = generic_grid || F != 2 || L != 16 || Wn != 64 || d->density_hidden_layers != 1 || d->rgb_hidden_layers != 2 ||
+                       dir_w != 16 || d->interpolation != NRF_INTERP_LINEAR ||
+                       !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+                         d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
+                         d->sigma_activation == NRF_ACT_EXPONENTIAL);
+  std::vector<_Float16> frags;
+  GenModel G;
+  std::memset(&G, 0, sizeof(G));
+  if (!generic) {
+    pack_fragments(w16, frags);
+  } else {
+    G.F = F; G.interp = d->interpolation; G.n_levels = L; G.feat_raw = feat_raw; G.feat_w = feat_w;
+    G.feat_k = next_multiple(feat_w, 32u); G.width = Wn; G.dir_raw = raw; G.dir_w = dir_w; G.rgb_in = rgb_in;
+    G.n_dens = d->density_hidden_layers + 1; G.n_rgb = d->rgb_hidden_layers + 1;
+    const uint32_t max_k = G.feat_k > next_multiple(Wn, 32u) ? G.feat_k : next_multiple(Wn, 32u);
+    G.act_stride = max_k + 8;   // +16 bytes: consecutive rows start 4 banks apart (ds_read_b128 of 16 rows: conflict-free)
+    G.dir_stride = dir_w + 8;
+    const _Float16* wp = w16.data();
+    for (size_t i = 0; i < layers.size(); ++i) {
+      G.layer[i].frag_off = (uint32_t)(frags.size() / (64 * 8));
+      G.layer[i].k_steps = (layers[i].K + 31) / 32;
+      G.layer[i].n_tiles = layers[i].N / 16;
+      G.layer[i].act = layers[i].act;
+      pack_generic_layer(wp, layers[i].N, layers[i].K, frags);
+      wp += (size_t)layers[i].N * layers[i].K;
+    }
+  }
+  const uint32_t gen_wave_bytes = generic ? gen_dir_bytes(G) + gen_act_bytes(G) : 0u;
+  if (generic && render_gen_lds_fixed_bytes(gen_wave_bytes) > 160 * 1024)
+    return fail(NRF_E_UNSUPPORTED, "HIP path: this network shape needs more LDS than a CU has");
   // Device copy of the table: the reference's entries level by level; a dense level is followed by
   // res^2 + res + 1 copies of its first entries so that x + y*res + z*res^2 (at most
   // size + res^2 + res when a +1 corner sits on the x = 1 / y = 1 / z = 1 face) needs no modulo.
-  std::vector<_Float16> grid16;
-  grid16.reserve(n_grid + 2 * 16 * 4096 + 2 * ((size_t)1 << d->log2_hashmap_size));
-  for (uint32_t l = 0; l < 16; ++l) {
-    LevelParams& L = lp[l];
-    if (L.mode == LV_HASH_POW2)  // aligned to its own (power-of-two) size: `hash & mask | offset` (level_gather, UNI == 2)
-      while ((grid16.size() / 2) % L.size != 0) grid16.push_back((_Float16)0.0f);
-    L.offset = (uint32_t)(grid16.size() / 2);
-    const float* src = gp + (size_t)lv.offset[l] * 2;
-    for (size_t i = 0; i < (size_t)L.size * 2; ++i) grid16.push_back((_Float16)src[i]);
-    if (L.mode == LV_DENSE) {
-      const size_t extra = (size_t)L.res * L.res + L.res + 1;
-      for (size_t i = 0; i < extra * 2; ++i) grid16.push_back((_Float16)src[i % ((size_t)L.size * 2)]);
+  std::vector<_Float16> grid16;  // F halves per entry
+  grid16.reserve(n_grid + (size_t)F * (16 * 4096 + ((size_t)1 << d->log2_hashmap_size)));
+  for (uint32_t l = 0; l < L; ++l) {
+    LevelParams& Lv = lp[l];
+    if (Lv.mode == LV_HASH_POW2)  // aligned to its own (power-of-two) size: `hash & mask | offset` (level_gather, UNI == 2)
+      while ((grid16.size() / F) % Lv.size != 0) grid16.push_back((_Float16)0.0f);
+    Lv.offset = (uint32_t)(grid16.size() / F);
+    const float* src = gp + (size_t)lv.offset[l] * F;
+    for (size_t i = 0; i < (size_t)Lv.size * F; ++i) grid16.push_back((_Float16)src[i]);
+    if (Lv.mode == LV_DENSE) {
+      const size_t extra = (size_t)Lv.res * Lv.res + Lv.res + 1;
+      for (size_t i = 0; i < extra * F; ++i) grid16.push_back((_Float16)src[i % ((size_t)Lv.size * F)]);
     }
   }
   if ((uint64_t)grid16.size() * 2 >= (1ull << 32))  // level_gather addresses the table by 32-bit byte offsets
@@ -606,12 +727,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     L.mask_b = hashed_pow2 ? ((L.size - 1) << 2) : 0xffffffffu;
   }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
-  HIP_TRY(upload(&c->d_occ, occ.data(), occ.size() * 4));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
+  if (generic) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
-  if (coarse_shift) HIP_TRY(upload(&c->d_coarse, coarse.data(), coarse.size() * 4));
-  HIP_TRY(upload(&c->d_ctab, ctab.data(), ctab.size() * 4));
-  if (!dilated.empty()) HIP_TRY(upload(&c->d_dilated, dilated.data(), dilated.size() * 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
 
@@ -623,26 +741,11 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   std::memset(&M, 0, sizeof(M));
   M.grid = (const uint32_t*)c->d_grid;
   M.grid_bytes = (uint32_t)(grid16.size() * 2);
-  M.occ_bits = (const uint32_t*)c->d_occ;
   M.wfrag = (const uint4*)c->d_wfrag;
   M.lv = (const LevelParams*)c->d_lv;
   for (int i = 0; i < 6; ++i) M.aabb[i] = d->aabb[i];
   M.bound = d->bound;
-  for (int i = 0; i < 6; ++i) M.occ_box[i] = occ_box[i];
   M.rbound = 1.0f / d->bound;
-  M.occ_coarse = (const uint32_t*)c->d_coarse;
-  M.cell_bound = (const float*)c->d_ctab;
-  M.occ_dilated = (const uint32_t*)c->d_dilated;
-  M.coarse_shift = coarse_shift;
-  {
-    const uint64_t words = coarse_shift ? (uint64_t)coarse.size() : 0, fl = ctab.size();
-    if (coarse_shift && 4 * (words + fl) <= (uint64_t)render_lds_table_max_bytes()) {
-      M.lds_coarse_words = (uint32_t)words;
-      M.lds_ctab_floats = (uint32_t)fl;
-    }
-  }
-  M.dilated_level_words = dilated_level_words;
-  if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
   M.pos_w = (float)(1.0 / (2 * (double)d->bound));
   {
     int e;
@@ -668,10 +771,76 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     }
     M.uni_modes |= (all_dense ? 1u : (all_hash ? 2u : 0u)) << (2 * jl);
   }
-  M.generic_act = generic_grid || !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
-                    d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
-                    d->sigma_activation == NRF_ACT_EXPONENTIAL);
+  M.generic = generic ? 1u : 0u;
+  M.gen = (const GenModel*)c->d_gen;
+  M.gen_wave_bytes = gen_wave_bytes;
+  c->gen = G;
+  // the density grid of the snapshot (nerf_render.cu:447-466) -- or none yet: nrf_generate_density_grid evaluates it
+  // from the network (NerfRender::generate_density_grid); until then the model cannot be rendered
+  if (d->density_grid) {
+    rc = set_density_grid(c, d->density_grid, d->mean_density);
+    if (rc) { free_model(c); return rc; }
+    c->grid_missing = false;
+  } else {
+    std::vector<float> empty((size_t)cells, 0.0f);
+    rc = set_density_grid(c, empty.data(), d->mean_density);
+    if (rc) { free_model(c); return rc; }
+    c->grid_missing = true;
+  }
   c->model_loaded = true;
+  return NRF_OK;
+}
+
+// NerfRender::generate_density_grid (R/src/nerf_render.cu:388-429; dead and incomplete in the reference: the density
+// query is commented out at :415).  What it sets out to do (torch-ngp's update_extra_state, which it restates), made
+// whole: for every cascade the density at every cell's position (init_xyzs + dd_scale, perturbation off), scaled by
+// 0.001691, folded into a grid that starts at 1/64 with g = max(g * decay, value), n_iterations times; mean_density =
+// mean of max(g, 0).  The march tables are rebuilt from the result.
+int nrf_generate_density_grid(nrf_context* c, int n_iterations, float decay, float* mean_density_out) {
+  int rc = need_model(c);
+  if (rc) return rc;
+  if (n_iterations < 1 || !(decay > 0.0f) || !(decay <= 1.0f)) return fail(NRF_E_INVALID, "n_iterations >= 1 and 0 < decay <= 1 required");
+  const uint32_t H = c->desc.density_grid_size, C = c->desc.cascade;
+  const uint64_t n = (uint64_t)H * H * H;
+  if (n >= (1ull << 31)) return fail(NRF_E_UNSUPPORTED, "density grid too large");
+  void* buf = nullptr;  // xyz [n][3] | dir [n][3] | rgb [n][3] | sigma [n] | grid [n]
+  HIP_TRY(hipMalloc(&buf, n * 11 * sizeof(float)));
+  float* d_xyz = (float*)buf;
+  float* d_dir = d_xyz + 3 * n;
+  float* d_rgb = d_dir + 3 * n;
+  float* d_sigma = d_rgb + 3 * n;
+  float* d_cell = d_sigma + n;
+  std::vector<float> grid((size_t)n * C);
+  hipError_t e = hipSuccess;
+  for (uint32_t cas = 0; cas < C && e == hipSuccess; ++cas) {
+    const float bound = (float)(1u << cas) < c->desc.bound ? (float)(1u << cas) : c->desc.bound;  // nerf_render.cu:409
+    const float half_grid_size = bound / (float)H;
+    e = launch_density_positions(H, bound - half_grid_size, d_xyz, d_dir, c->stream);
+    if (e == hipSuccess) e = launch_network(c->dm, d_xyz, d_dir, (uint32_t)n, d_sigma, d_rgb, c->stream);
+    if (e == hipSuccess) e = launch_density_update(d_sigma, (uint32_t)n, decay, n_iterations, d_cell, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(grid.data() + (size_t)cas * n, d_cell, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(buf);
+  if (e != hipSuccess) return hip_fail(e, "nrf_generate_density_grid");
+  double sum = 0.0;  // sequential, in cell order: the same number on every run (and in the oracle)
+  for (float g : grid) sum += g > 0.0f ? (double)g : 0.0;
+  const float mean = (float)(sum / (double)grid.size());
+  rc = set_density_grid(c, grid.data(), mean);
+  if (rc) return rc;
+  c->grid_missing = false;
+  if (mean_density_out) *mean_density_out = mean;
+  return NRF_OK;
+}
+
+int nrf_read_density_grid(nrf_context* c, float* grid, uint64_t n, float* mean_density) {
+  int rc = need_model(c);
+  if (rc) return rc;
+  if (grid) {
+    if (n != c->host_grid.size()) return fail(NRF_E_INVALID, "n must be cascade * H^3");
+    std::memcpy(grid, c->host_grid.data(), c->host_grid.size() * sizeof(float));
+  }
+  if (mean_density) *mean_density = c->desc.mean_density;
   return NRF_OK;
 }
 
@@ -711,6 +880,8 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   if (!cams || !poses) return fail(NRF_E_INVALID, "null argument");
   if (n_views < 1) return fail(NRF_E_INVALID, "n_views must be >= 1");
   if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
+  if (c->grid_missing)
+    return fail(NRF_E_STATE, "the model was loaded without a density grid: call nrf_generate_density_grid first");
   if (!c->bound_rgba && n_views > c->max_views)
     return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
   FrameParams P;

@@ -77,7 +77,7 @@ struct DevModel {
   const uint32_t* occ_dilated;  // [C][dilated_level_words]: coarse cells within one density cell of an occupied density cell
   uint32_t dilated_level_words;
   uint32_t pos_w_pow2;         // pos_w = 1 / (2 bound) is a power of two: pos_w * x + 0.5 is then ONE fma (the product is exact)
-  const uint4* wfrag;        // N_FRAGS_ALL * 64 uint4
+  const uint4* wfrag;        // hot instance: N_FRAGS_ALL * 64 uint4; generic instance: the fragments GenModel::layer names
   const LevelParams* lv;     // 16 entries (device memory)
   float aabb[6];
   float occ_box[6];  // world-space box around every occupied cell, inflated by 2 cells; min > max when nothing is occupied
@@ -92,8 +92,12 @@ struct DevModel {
   uint32_t rgb_activation, rgb_output_activation;
   uint32_t uni_modes;    // 2 bits per unrolled step jl = 0..3 of the fused kernel (levels 4*jl + g): 0 mixed, 1 all dense,
                          // 2 all power-of-two hashed (host: nrf_load_model)
-  uint32_t generic_act;  // 0: hidden ReLU / outputs None / sigma Exponential AND every grid level dense or
-                         // power-of-two hashed (compile-time fast path); 1: the generic kernel instances
+  uint32_t generic;      // 0: the shape of the reference's base.json (L = 16, F = 2, 64 neurons, 1 + 2 hidden layers, a
+                         // 16-wide direction encoding, hidden ReLU / outputs None / sigma Exponential, linear interpolation,
+                         // every level dense or power-of-two hashed): the register-resident instance (this file);
+                         // 1: everything else: the generic instance (nrf_generic.h), described by `gen`
+  const struct GenModel* gen;  // device memory; nullptr unless generic
+  uint32_t gen_wave_bytes;     // generic instance: LDS bytes per wave of the direction rows + activation rows
   uint32_t coarse_shift;    // 2 or 0
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
@@ -437,8 +441,8 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 // One (sample, level) of kernel_grid<half,3,2>: 8 corner gathers of a half2,
 // fp16 accumulation in corner order (grid.h:236-262).  Returns the packed
 // half2 (feature 0 in the low half).
-//   GENERIC == false: every level is LV_DENSE or LV_HASH_POW2 (the hot path); dense levels are
-//   stored with res^2 + res + 1 wrapped entries appended (nrf_api.hip), so `index % size` of
+//   Every level is LV_DENSE or LV_HASH_POW2 (anything else runs in the generic instance, nrf_generic.h); dense
+//   levels are stored with res^2 + res + 1 wrapped entries appended (nrf_api.hip), so `index % size` of
 //   grid.h:116 needs no instruction: a dense index never exceeds size + res^2 + res.
 //   UNI: 0 = the lanes of the wave may mix dense and hashed levels (per-lane select);
 //        1 = every lane's level is dense, 2 = every lane's level is power-of-two hashed.
@@ -447,28 +451,19 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 // lane): the network phase is bound by gather latency, not by instruction issue.
 //   level_gather: corner indices + the 8 loads (results not touched) + the fractional position
 //   level_interp: trilinear weights and the fp16 accumulation in corner order
-template <bool GENERIC, int UNI = 0>
+template <int UNI = 0>
 __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
                                              float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
   float fx = px * L.scale; fx = fx + 0.5f;
   float fy = py * L.scale; fy = fy + 0.5f;
   float fz = pz * L.scale; fz = fz + 0.5f;
-  uint32_t gx, gy, gz;
-  if (GENERIC) {
-    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-    gx = (uint32_t)(int)flx; gy = (uint32_t)(int)fly; gz = (uint32_t)(int)flz;
-    frac[0] = fx - flx;
-    frac[1] = fy - fly;
-    frac[2] = fz - flz;
-  } else {
-    // hot path: positions are in [0,1] (march clamps to the aabb), so f >= 0.5: the truncating
-    // conversion is floor, and v_fract_f32 returns f - floor(f) exactly (the subtraction is exact
-    // for f >= 0; the instruction's clamp to 1-ulp only concerns tiny negative inputs)
-    gx = (uint32_t)(int)fx; gy = (uint32_t)(int)fy; gz = (uint32_t)(int)fz;
-    frac[0] = __builtin_amdgcn_fractf(fx);
-    frac[1] = __builtin_amdgcn_fractf(fy);
-    frac[2] = __builtin_amdgcn_fractf(fz);
-  }
+  // positions are in [0,1] (march clamps to the aabb), so f >= 0.5: the truncating
+  // conversion is floor, and v_fract_f32 returns f - floor(f) exactly (the subtraction is exact
+  // for f >= 0; the instruction's clamp to 1-ulp only concerns tiny negative inputs)
+  const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+  frac[0] = __builtin_amdgcn_fractf(fx);
+  frac[1] = __builtin_amdgcn_fractf(fy);
+  frac[2] = __builtin_amdgcn_fractf(fz);
 
   // The gathers are MUBUF loads: address = table base (buffer resource, SGPRs) + a 32-bit BYTE
   // offset per lane, so no 64-bit address arithmetic is spent per corner.  The shift by 2 is folded
@@ -476,20 +471,7 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   // mod 2^32); nrf_load_model rejects tables of 4 GiB or more.
   uint32_t off[8];
   const uint32_t level_off = L.off_b;
-  if (GENERIC && L.mode == LV_GENERIC) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint32_t p0 = gx + (c & 1), p1 = gy + ((c >> 1) & 1), p2 = gz + ((c >> 2) & 1);
-      // the loop `for dim < 3 && stride <= size` stops at the first failing dim; stride then
-      // stays put, so three sequential tests are equivalent
-      uint32_t stride = 1, index = 0;
-      if (stride <= L.size) { index += p0 * stride; stride *= L.res; }
-      if (stride <= L.size) { index += p1 * stride; stride *= L.res; }
-      if (stride <= L.size) { index += p2 * stride; stride *= L.res; }
-      if (L.hashed && L.size < stride) index = p0 ^ (p1 * 2654435761u) ^ (p2 * 805459861u);
-      off[c] = ((index % L.size) << 2) + level_off;
-    }
-  } else {
+  {
     // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
     const bool hashed = UNI == 2 || (UNI == 0 && L.mode == LV_HASH_POW2);
     const uint32_t my = UNI == 2 ? (2654435761u << 2) : L.my_b;
@@ -545,12 +527,12 @@ __device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const f
   return h2_bits(acc);
 }
 
-template <bool GENERIC, int UNI = 0>
+template <int UNI = 0>
 __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L,
                                                  float px, float py, float pz) {
   uint32_t v[8];
   float frac[3];
-  level_gather<GENERIC, UNI>(grid, grid_bytes, L, px, py, pz, v, frac);
+  level_gather<UNI>(grid, grid_bytes, L, px, py, pz, v, frac);
   return level_interp(v, frac);
 }
 
@@ -637,48 +619,25 @@ __device__ __forceinline__ half8_t frag_load(const uint4* wl, int f, int lane) {
   return __builtin_bit_cast(half8_t, v);
 }
 
-// Activation choice.  GEN == false is the hot-path configuration of the reference's base.json
-// (hidden ReLU, outputs None, sigma Exponential) with every activation a compile-time constant;
-// GEN == true evaluates the runtime enums (any tcnn activation) and is a separate kernel
-// instance, so the hot kernel never carries the if-converted exp/log/sin variants.
-template <bool GEN, uint32_t FAST>
-__device__ __forceinline__ float act_sel(uint32_t runtime_act, float v) {
-  if constexpr (GEN) return activate(runtime_act, v);
-  else if constexpr (FAST == NRF_ACT_RELU) return fmaxf(v, 0.0f);
-  else if constexpr (FAST == NRF_ACT_EXPONENTIAL) return expf(v);
-  else return v;
-}
-
 // pack two D fragments (after the hidden activation, rounded to fp16) into one B fragment.
-// Hot path: ReLU commutes with the (monotonic, sign-preserving) rounding to fp16, so it is applied
+// The activations of this instance are compile-time constants (hidden ReLU, outputs None, sigma Exponential: the
+// reference's base.json); any other combination runs in the generic instance (nrf_generic.h).
+// ReLU commutes with the (monotonic, sign-preserving) rounding to fp16, so it is applied
 // to the packed halves: one v_pk_max_f16 per two values instead of two v_max_f32 per value.
-template <bool GEN>
-__device__ __forceinline__ half8_t pack_acc(uint32_t act, float4_t lo, float4_t hi) {
+__device__ __forceinline__ half8_t pack_acc(float4_t lo, float4_t hi) {
   half8_t r;
-  if constexpr (GEN) {
-    r[0] = (half_t)activate(act, lo[0]);
-    r[1] = (half_t)activate(act, lo[1]);
-    r[2] = (half_t)activate(act, lo[2]);
-    r[3] = (half_t)activate(act, lo[3]);
-    r[4] = (half_t)activate(act, hi[0]);
-    r[5] = (half_t)activate(act, hi[1]);
-    r[6] = (half_t)activate(act, hi[2]);
-    r[7] = (half_t)activate(act, hi[3]);
-  } else {
-    r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
-    r[4] = (half_t)hi[0]; r[5] = (half_t)hi[1]; r[6] = (half_t)hi[2]; r[7] = (half_t)hi[3];
-    const half8_t zero8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-    r = __builtin_elementwise_max(r, zero8);
-  }
-  return r;
+  r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
+  r[4] = (half_t)hi[0]; r[5] = (half_t)hi[1]; r[6] = (half_t)hi[2]; r[7] = (half_t)hi[3];
+  const half8_t zero8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  return __builtin_elementwise_max(r, zero8);
 }
 
 // feat[n]  : B fragment of the density MLP input  (hash features 8g..8g+7 of sample c, tile n)
 // dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
 // out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
-template <int NT, bool GEN, int D0_BASE = FRAG_D0>
-__device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, int lane, const half8_t (&feat)[NT],
-                                          const half4_t (&dirf)[NT], float4_t (&out)[NT]) {
+template <int NT, int D0_BASE = FRAG_D0>
+__device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8_t (&feat)[NT], const half4_t (&dirf)[NT],
+                                          float4_t (&out)[NT]) {
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
   float4_t acc[NT][4];
   half8_t hb[NT][2];
@@ -691,8 +650,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc<GEN>(M.density_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc<GEN>(M.density_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
   }
   // ---- density layer 1: 64 -> 16
   float4_t dacc[NT];
@@ -710,10 +669,10 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     half8_t r;
-    r[0] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][0]);
-    r[1] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][1]);
-    r[2] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][2]);
-    r[3] = (half_t)act_sel<GEN, NRF_ACT_NONE>(M.density_output_activation, dacc[n][3]);
+    r[0] = (half_t)dacc[n][0];
+    r[1] = (half_t)dacc[n][1];
+    r[2] = (half_t)dacc[n][2];
+    r[3] = (half_t)dacc[n][3];
     r[4] = dirf[n][0];
     r[5] = dirf[n][1];
     r[6] = dirf[n][2];
@@ -730,8 +689,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc<GEN>(M.rgb_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc<GEN>(M.rgb_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
   }
   // ---- rgb layer 1: 64 -> 64
 #pragma unroll
@@ -747,8 +706,8 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc<GEN>(M.rgb_activation, acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc<GEN>(M.rgb_activation, acc[n][2], acc[n][3]);
+    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
+    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
   }
   // ---- rgb layer 2: 64 -> 16 (3 used)
 #pragma unroll
@@ -762,23 +721,12 @@ __device__ __forceinline__ void mlp_tiles(const DevModel& M, const uint4* wl, in
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     // network_output rows 0..2 (fp16) and extract_density row 3 (nerf_network.h:49-61):
-    // fp32 activation of the fp16 density output, stored as fp16.
-    float s = sig_pre[n];
-    if constexpr (GEN) {
-      switch (M.sigma_activation) {  // wrap_a_activation handles exactly these (nerf_network.h:32-47)
-        case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
-        case NRF_ACT_EXPONENTIAL: s = expf(s); break;
-        case NRF_ACT_SIGMOID: s = 1.0f / (1.0f + expf(-s)); break;
-        default: break;
-      }
-    } else {
-      s = expf(s);
-    }
+    // fp32 activation (Exponential) of the fp16 density output, stored as fp16.
     float4_t o;
-    o[0] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][0]);
-    o[1] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][1]);
-    o[2] = (float)(half_t)act_sel<GEN, NRF_ACT_NONE>(M.rgb_output_activation, dacc[n][2]);
-    o[3] = (float)(half_t)s;
+    o[0] = (float)(half_t)dacc[n][0];
+    o[1] = (float)(half_t)dacc[n][1];
+    o[2] = (float)(half_t)dacc[n][2];
+    o[3] = (float)(half_t)expf(sig_pre[n]);
     out[n] = o;
   }
 }

@@ -15,6 +15,7 @@
 // time for the parity tests (include/nerfhip.h "stage entry points").
 
 #include "nrf_device.h"
+#include "nrf_generic.h"
 #include "nrf_launch.h"
 
 namespace nrf {
@@ -67,17 +68,11 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define NRF_ACC(acc, a, b)
 #endif
 
-__device__ __forceinline__ void stage_weights(const DevModel& M, uint4* wl, LevelParams* lvs) {
-  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
-  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
-  __syncthreads();
-}
-
 
 // Encodes and evaluates the S (<= 16*NT) samples queued in the wave's LDS
 // slots; results go to W->out[slot].  Lane (g, c): sample c of each tile,
 // hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
-template <int NT, bool GEN>
+template <int NT>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  int S, int base, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
@@ -110,10 +105,10 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) {
         const LevelParams L = lvs[4 * jl + g];
-        const uint32_t uni = GEN ? 0u : (M.uni_modes >> (2 * jl)) & 3u;
-        if (uni == 2u) level_gather<GEN, 2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else if (uni == 1u) level_gather<GEN, 1>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else level_gather<GEN, 0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
+        if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else if (uni == 1u) level_gather<1>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
       }
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp(gv[jl], gf[jl]);
@@ -125,7 +120,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   float4_t o[NT];
-  mlp_tiles<NT, GEN>(M, wl, lane, feat, dirf, o);
+  mlp_tiles<NT>(wl, lane, feat, dirf, o);
   if (g == 0) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -140,33 +135,118 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
 // At most NT_MAX tiles are evaluated together: NT_MAX = 2 keeps the kernel under 128 VGPRs
 // (4 waves per SIMD); the 20 KiB of weight fragments are then read from LDS once per 32 samples.
 constexpr int NT_MAX = 2;
+
+// The generic instance's pass (nrf_generic.h): <= 32 of the queued samples, features through LDS rows.
+// DENSITY_ONLY: sigma only (density-grid generation); rgb = 0.
+template <bool DENSITY_ONLY>
+__device__ __forceinline__ void gen_network_from_lds(const DevModel& M, const GenModel& G, const LevelParams* lvs, WaveLds* W,
+                                                     const GenLds& Lw, int S, int base, int lane, float density_scale) {
+  const int g = lane >> 4, c = lane & 15;
+  float p01[GEN_TILES][3];
+  bool valid[GEN_TILES];
+  int ray[GEN_TILES];
+#pragma unroll
+  for (int n = 0; n < GEN_TILES; ++n) {
+    const int slot = base + 16 * n + c;
+    valid[n] = slot < S;
+    ray[n] = 0;
+    p01[n][0] = p01[n][1] = p01[n][2] = 0.5f;
+    if (valid[n]) {
+      const float4 p = W->pos[slot];
+      float px = M.pos_w * p.x; px = px + 0.5f;  // linear_transformer(1/(2 bound), 0.5), R/src/nerf_render.cu:311-312
+      float py = M.pos_w * p.y; py = py + 0.5f;
+      float pz = M.pos_w * p.z; pz = pz + 0.5f;
+      p01[n][0] = px; p01[n][1] = py; p01[n][2] = pz;
+      ray[n] = __builtin_bit_cast(int, p.w) & 63;
+    }
+  }
+  gen_encode_rows(M, G, lvs, Lw, lane, p01, valid);
+  gen_wave_sync();
+  float4_t o[GEN_TILES];
+  gen_mlps<DENSITY_ONLY>(M, G, Lw, lane, ray, o);
+  if (g == 0) {
+#pragma unroll
+    for (int n = 0; n < GEN_TILES; ++n) {
+      const int slot = base + 16 * n + c;
+      float sigma = o[n][3];
+      if (density_scale != 1.0f) sigma = density_scale * sigma;
+      if (slot < S) W->out[slot] = make_float4(o[n][0], o[n][1], o[n][2], sigma);
+    }
+  }
+  gen_wave_sync();  // the next pass overwrites the rows
+}
+
 template <bool GEN>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
-                                                 int S, int lane, float density_scale) {
-  for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
-    const int ntile = (S - base + 15) >> 4;
-    if (ntile <= 1) network_from_lds<1, GEN>(M, wl, lvs, W, S, base, lane, density_scale);
-    else network_from_lds<NT_MAX, GEN>(M, wl, lvs, W, S, base, lane, density_scale);
+                                                 const GenLds& Lw, int S, int lane, float density_scale) {
+  if constexpr (GEN) {
+    const GenModel& G = *M.gen;
+    for (int base = 0; base < S; base += GEN_SAMPLES)  // wave-uniform
+      gen_network_from_lds<false>(M, G, lvs, W, Lw, S, base, lane, density_scale);
+  } else {
+    for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
+      const int ntile = (S - base + 15) >> 4;
+      if (ntile <= 1) network_from_lds<1>(M, wl, lvs, W, S, base, lane, density_scale);
+      else network_from_lds<NT_MAX>(M, wl, lvs, W, S, base, lane, density_scale);
+    }
   }
+}
+
+// LDS map of the kernels that evaluate the network.
+//   hot instance:     [20 KiB weight fragments][level table][RENDER_WAVES x WaveLds][march tables]
+//   generic instance: [level table][RENDER_WAVES x WaveLds][RENDER_WAVES x direction rows][RENDER_WAVES x (X, Y)][march tables]
+// (the generic instance streams its weights from global memory; WaveLds::dirf holds the density MLP's output there)
+struct LdsMap {
+  uint4* wl;            // hot: weight fragments; generic: the (X, Y) region (what the dilated bitfield borrows during ray setup)
+  LevelParams* lvs;
+  WaveLds* W;           // this wave's block
+  GenLds gen;           // this wave's generic regions
+  unsigned char* tables;
+};
+template <bool GEN>
+__device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M, int wave, int n_waves) {
+  LdsMap m;
+  if constexpr (GEN) {
+    const GenModel& G = *M.gen;
+    m.lvs = reinterpret_cast<LevelParams*>(smem);
+    unsigned char* waves = smem + LDS_LEVEL_BYTES;
+    m.W = reinterpret_cast<WaveLds*>(waves) + wave;
+    unsigned char* dir = waves + n_waves * (int)sizeof(WaveLds);
+    unsigned char* act = dir + n_waves * gen_dir_bytes(G);
+    m.wl = reinterpret_cast<uint4*>(act);
+    m.gen.dens = reinterpret_cast<half_t*>(&m.W->dirf[0][0]);
+    m.gen.dir = reinterpret_cast<half_t*>(dir + wave * gen_dir_bytes(G));
+    m.gen.X = reinterpret_cast<half_t*>(act + wave * gen_act_bytes(G));
+    m.gen.Y = m.gen.X + GEN_SAMPLES * G.act_stride;
+    m.tables = act + n_waves * gen_act_bytes(G);
+  } else {
+    m.wl = reinterpret_cast<uint4*>(smem);
+    m.lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
+    m.W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+    m.gen.dens = m.gen.dir = m.gen.X = m.gen.Y = nullptr;
+    m.tables = smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
+  }
+  return m;
 }
 
 // ------------------------------------------------------- the render kernel ----
 // 256 threads, >= 4 waves per SIMD (four workgroups per CU, 39.9 KB of LDS each): caps the kernel at
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
+// (the generic instance is bound by its LDS rows, not by registers: no 128-VGPR cap there)
 template <bool GEN, bool COARSE_LDS, int MARCH>
-__global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
+__global__ __launch_bounds__(RENDER_THREADS, GEN ? 2 : 4) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
                                                      float4* __restrict__ rgba, float* __restrict__ depth,
                                                      unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* wl = reinterpret_cast<uint4*>(smem);
-  LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
-
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  WaveLds* W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+  const LdsMap lm = lds_map<GEN>(smem, M, wave, RENDER_WAVES);
+  uint4* wl = lm.wl;
+  LevelParams* lvs = lm.lvs;
+  WaveLds* W = lm.W;
   // march tables: coarse occupancy bits + cell-boundary table (staged once per workgroup)
-  uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + LDS_FIXED_BYTES);
+  uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(lm.tables);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
   // LDS timeline of a workgroup:
   //  (1) nothing: ray generation and the slab test against the box of occupied cells need no table; if no
@@ -176,6 +256,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
   //      dilated coarse occupancy of the per-ray visibility walk (~40 dependent bit lookups per ray: from
   //      global memory that was 26 % of all wave cycles); direction encoding of the surviving rays;
   //  (3) the weight fragments overwrite the borrowed area, unless the walk left no ray alive.
+  // (generic instance: the borrowed area is the activation rows, which the first network pass overwrites)
   uint32_t* dil_lds = reinterpret_cast<uint32_t*>(wl);
   const bool use_dil_lds = COARSE_LDS && M.occ_dilated != nullptr && M.lds_dilated_words > 0;
 
@@ -309,23 +390,29 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
       if (any) t_skip = first;
     }
     if (alive) {  // direction encoding: only rays that will evaluate the network need it
-      half_t e[16];
       float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
       float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
       float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
-      encode_dir16(M, u0, u1, u2, e);
+      if constexpr (GEN) {
+        gen_encode_dir(M, *M.gen, u0, u1, u2, lm.gen.dir + (size_t)lane * M.gen->dir_stride);
+      } else {
+        half_t e[16];
+        encode_dir16(M, u0, u1, u2, e);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        half2_t h;
-        h.x = e[2 * j];
-        h.y = e[2 * j + 1];
-        W->dirf[lane][j] = h2_bits(h);
+        for (int j = 0; j < 8; ++j) {
+          half2_t h;
+          h.x = e[2 * j];
+          h.y = e[2 * j + 1];
+          W->dirf[lane][j] = h2_bits(h);
+        }
       }
     }
     // ---- (3) the weight fragments replace the dilated bitfield
     if (__syncthreads_or(alive ? 1 : 0) != 0) {
-      for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
-      __syncthreads();
+      if constexpr (!GEN) {
+        for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+        __syncthreads();
+      }
     }
   }
   if (!valid_tile) return;  // no barrier after this point
@@ -388,7 +475,7 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 
     if (S > 0) {
       // ---- network on the S queued samples (sample-major MFMA tiles)
-      network_dispatch<GEN>(M, wl, lvs, W, S, lane, P.density_scale);
+      network_dispatch<GEN>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
       wave_sync();
     }
     NRF_STAMP(t2);
@@ -466,9 +553,8 @@ __global__ __launch_bounds__(RENDER_THREADS, 4) void render_kernel(const DevMode
 }
 
 // ------------------------------------------------------------ stage kernels ----
-// GEN == false: the same per-level specialisation render_kernel uses (uni_modes of the level's
+// Hot instance: the same per-level specialisation render_kernel uses (uni_modes of the level's
 // group of four), so the bit-exact encode test covers the hot path's index arithmetic.
-template <bool GEN>
 __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, const float* __restrict__ pos01, uint32_t n,
                                                           uint32_t* __restrict__ out) {
   __shared__ LevelParams lvs[16];
@@ -479,14 +565,39 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
     const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
-    if (GEN) {
-      out[i] = encode_level<true>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
-    } else {
-      const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
-      if (uni == 2u) out[i] = encode_level<false, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
-      else if (uni == 1u) out[i] = encode_level<false, 1>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
-      else out[i] = encode_level<false, 0>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
+    if (uni == 2u) out[i] = encode_level<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    else if (uni == 1u) out[i] = encode_level<1>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    else out[i] = encode_level<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+  }
+}
+
+// Generic instance: one thread per (sample, level) writes F halves of the row [feat_w]; level 0's thread also
+// writes the zero padding (grid.h:959-969).
+__global__ __launch_bounds__(256) void gen_encode_grid_kernel(const DevModel M, const float* __restrict__ pos01, uint32_t n,
+                                                              half_t* __restrict__ out) {
+  __shared__ LevelParams lvs[16];
+  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+  __syncthreads();
+  const GenModel& G = *M.gen;
+  const half_t* __restrict__ grid = reinterpret_cast<const half_t*>(M.grid);
+  const uint64_t total = (uint64_t)n * G.n_levels;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t s = (uint32_t)(i / G.n_levels), level = (uint32_t)(i - (uint64_t)s * G.n_levels);
+    const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
+    half_t* row = out + (size_t)s * G.feat_w;
+    half_t r[8];
+    switch (G.F) {
+      case 1: { half_t q[1]; gen_level<1>(grid, lvs[level], G.interp, px, py, pz, q); r[0] = q[0]; } break;
+      case 2: { half_t q[2]; gen_level<2>(grid, lvs[level], G.interp, px, py, pz, q); r[0] = q[0]; r[1] = q[1]; } break;
+      case 4: { half_t q[4]; gen_level<4>(grid, lvs[level], G.interp, px, py, pz, q);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) r[f] = q[f]; } break;
+      default: gen_level<8>(grid, lvs[level], G.interp, px, py, pz, r); break;
     }
+    for (uint32_t f = 0; f < G.F; ++f) row[level * G.F + f] = r[f];
+    if (level == 0)
+      for (uint32_t j = G.feat_raw; j < G.feat_w; ++j) row[j] = (half_t)0.0f;
   }
 }
 
@@ -505,6 +616,13 @@ __global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const
   }
 }
 
+__global__ __launch_bounds__(256) void gen_encode_dir_kernel(const DevModel M, const float* __restrict__ dir01, uint32_t n,
+                                                             half_t* __restrict__ out) {
+  const GenModel& G = *M.gen;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    gen_encode_dir(M, G, dir01[3 * (size_t)i], dir01[3 * (size_t)i + 1], dir01[3 * (size_t)i + 2], out + (size_t)i * G.dir_w);
+}
+
 // Both MLPs on pre-encoded inputs: one wave = 64 samples per trip.
 // feat fp16 [n][32], dirfeat fp16 [n][16] -> out fp16 [n][4] = (r, g, b, sigma)
 // HBM-bound (104 B and 20 480 FLOP per sample): every lane reads 16 B of its sample's feature row and 8 B
@@ -513,7 +631,7 @@ __global__ __launch_bounds__(256) void encode_dir_kernel(const DevModel M, const
 // while the current one goes through the 80 MFMAs.
 constexpr int LDS_WFRAG_ALL_BYTES = N_FRAGS_ALL * 64 * 16;  // 24576
 constexpr int MLP_TILES = 2;  // 16-sample tiles per trip
-template <bool GEN, bool REPEAT>
+template <bool REPEAT>
 __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
                                                           uint2* __restrict__ out, uint32_t repeat) {
@@ -562,7 +680,7 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
           df[t] = __builtin_bit_cast(half4_t, dv[t]);
         }
       }
-      mlp_tiles<T, GEN, FRAG_D0_NATURAL>(M, wl, lane, f, df, o);
+      mlp_tiles<T, FRAG_D0_NATURAL>(wl, lane, f, df, o);
     }
     if (g == 0) {
 #pragma unroll
@@ -579,18 +697,61 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
   }
 }
 
+// Generic instance of the stage above: feat fp16 [n][feat_w], dirfeat fp16 [n][dir_w] -> out fp16 [n][4].
+// One wave = 32 samples per trip: rows copied into the wave's LDS regions, then the same gen_mlps as render_kernel.
+__global__ __launch_bounds__(256) void gen_mlp_forward_kernel(const DevModel M, const half_t* __restrict__ feat,
+                                                              const half_t* __restrict__ dirfeat, uint32_t n,
+                                                              uint2* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const GenModel& G = *M.gen;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id(), g = lane >> 4, c = lane & 15;
+  const LdsMap lm = lds_map<true>(smem, M, wave, 4);
+  const uint32_t wave_global = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
+  const uint32_t n_chunks = (n + GEN_SAMPLES - 1) / GEN_SAMPLES;
+  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
+    const uint32_t first = chunk * GEN_SAMPLES;
+    for (uint32_t r = 0; r < (uint32_t)GEN_SAMPLES; ++r) {  // rows of the chunk, 64 lanes across the columns
+      const uint32_t s = first + r;
+      half_t* xr = lm.gen.X + (size_t)r * G.act_stride;
+      half_t* dr = lm.gen.dir + (size_t)r * G.dir_stride;
+      for (uint32_t j = lane; j < G.feat_k; j += 64u) xr[j] = (s < n && j < G.feat_w) ? feat[(size_t)s * G.feat_w + j] : (half_t)0.0f;
+      for (uint32_t j = lane; j < G.dir_w; j += 64u) dr[j] = s < n ? dirfeat[(size_t)s * G.dir_w + j] : (half_t)0.0f;
+    }
+    gen_wave_sync();
+    int ray[GEN_TILES];
+#pragma unroll
+    for (int t = 0; t < GEN_TILES; ++t) ray[t] = 16 * t + c;
+    float4_t o[GEN_TILES];
+    gen_mlps<false>(M, G, lm.gen, lane, ray, o);
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < GEN_TILES; ++t) {
+        const uint32_t s = first + 16u * t + c;
+        if (s < n) out[s] = make_uint2(pack_h2(o[t][0], o[t][1]), pack_h2(o[t][2], o[t][3]));
+      }
+    }
+    gen_wave_sync();
+  }
+}
+
 // Whole network on raw march output through the SAME code path as render_kernel.
+// DENSITY_ONLY (generic or hot): sigma only, rgb untouched (density-grid generation evaluates positions without directions).
 template <bool GEN>
 __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const float* __restrict__ xyz,
                                                       const float* __restrict__ dir, uint32_t n, float* __restrict__ sigma,
                                                       float* __restrict__ rgb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* wl = reinterpret_cast<uint4*>(smem);
-  LevelParams* lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
-  stage_weights(M, wl, lvs);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  WaveLds* W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+  const LdsMap lm = lds_map<GEN>(smem, M, wave, 4);
+  uint4* wl = lm.wl;
+  LevelParams* lvs = lm.lvs;
+  if constexpr (!GEN)
+    for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
+  __syncthreads();
+  WaveLds* W = lm.W;
   const uint32_t wave_global = blockIdx.x * 4 + wave;
   const uint32_t n_waves = gridDim.x * 4;
   const uint32_t n_chunks = (n + 63u) >> 6;
@@ -600,21 +761,25 @@ __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const
     if (i < n) {
       W->pos[lane] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
                                  __builtin_bit_cast(float, lane));
-      half_t e[16];
       float u0 = 0.5f * dir[3 * (size_t)i]; u0 = u0 + 0.5f;
       float u1 = 0.5f * dir[3 * (size_t)i + 1]; u1 = u1 + 0.5f;
       float u2 = 0.5f * dir[3 * (size_t)i + 2]; u2 = u2 + 0.5f;
-      encode_dir16(M, u0, u1, u2, e);
+      if constexpr (GEN) {
+        gen_encode_dir(M, *M.gen, u0, u1, u2, lm.gen.dir + (size_t)lane * M.gen->dir_stride);
+      } else {
+        half_t e[16];
+        encode_dir16(M, u0, u1, u2, e);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        half2_t h;
-        h.x = e[2 * j];
-        h.y = e[2 * j + 1];
-        W->dirf[lane][j] = h2_bits(h);
+        for (int j = 0; j < 8; ++j) {
+          half2_t h;
+          h.x = e[2 * j];
+          h.y = e[2 * j + 1];
+          W->dirf[lane][j] = h2_bits(h);
+        }
       }
     }
     wave_sync();
-    network_dispatch<GEN>(M, wl, lvs, W, S, lane, 1.0f);
+    network_dispatch<GEN>(M, wl, lvs, W, lm.gen, S, lane, 1.0f);
     wave_sync();
     if (i < n) {
       const float4 so = W->out[lane];
@@ -713,6 +878,42 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
   }
 }
 
+// ---- density grid from the network (NerfRender::generate_density_grid, R/src/nerf_render.cu:388-429) ----
+// Cell positions of one cascade: init_xyzs (render_utils.h:91-108: -1.f + 2.f/(H-1)*id per axis, x-major cell order)
+// scaled by dd_scale's k = bound_c - bound_c/H (nerf_render.cu:410-413); a constant direction (the density does not
+// depend on it).
+__global__ __launch_bounds__(256) void density_positions_kernel(uint32_t H, float k, float* __restrict__ xyz, float* __restrict__ dir) {
+  const uint32_t n = H * H * H;
+  const float step = 2.f / (float)(H - 1);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t id[3] = {i / (H * H), (i % (H * H)) / H, i % H};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float v = step * (float)id[a];
+      v = -1.f + v;
+      xyz[3 * (size_t)i + a] = k * v;
+      dir[3 * (size_t)i + a] = a == 2 ? 1.0f : 0.0f;
+    }
+  }
+}
+
+// dd_scale (k = 0.001691) + dg_update (render_utils.h:120-128), n_iterations times from the reference's initial value
+// 1/64 (nerf_render.cu:393): g = max(g * decay, k * sigma) for g >= 0.
+__global__ __launch_bounds__(256) void density_update_kernel(const float* __restrict__ sigma, uint32_t n, float decay, int n_iterations,
+                                                             float* __restrict__ grid) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float tmp = 0.001691f * sigma[i];
+    float g = 1.0f / 64;
+    for (int it = 0; it < n_iterations; ++it) {
+      if (g >= 0) {
+        const float gd = g * decay;
+        g = gd > tmp ? gd : tmp;
+      }
+    }
+    grid[i] = g;
+  }
+}
+
 // gathered [shard][view][tiles_per_shard][64][C] -> row-major [view][H][W][C]
 __global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ gathered, int shard_count, int tiles_per_shard,
                                                      int C, int W, int H, int tiles_x, int n_views, float* __restrict__ out) {
@@ -758,6 +959,15 @@ static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
   return (int)g;
 }
 
+// Dynamic LDS above 64 KiB has to be announced per kernel (gfx950 has 160 KiB per CU).
+template <typename K>
+static hipError_t allow_lds(K kernel, int bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  if (bytes > 160 * 1024) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+static int gen_lds_bytes(const DevModel& M, int waves) { return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)M.gen_wave_bytes); }
+
 hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
                          hipStream_t st) {
   ViewBatch VB = VBin;
@@ -766,10 +976,15 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
-  const int lds = LDS_FIXED_BYTES + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
+  const int lds = (M.generic ? gen_lds_bytes(M, RENDER_WAVES) : LDS_FIXED_BYTES) +
+                  (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
 #define NRF_LAUNCH_RENDER(G, C, U)                                                                                       \
-  hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, VB, (float4*)rgba,     \
-                     (float*)depth, (unsigned long long*)counters)
+  do {                                                                                                                   \
+    hipError_t e_ = allow_lds(render_kernel<G, C, U>, lds);                                                              \
+    if (e_ != hipSuccess) return e_;                                                                                     \
+    hipLaunchKernelGGL((render_kernel<G, C, U>), dim3(blocks), dim3(RENDER_THREADS), lds, st, M, P, VB, (float4*)rgba,   \
+                       (float*)depth, (unsigned long long*)counters);                                                    \
+  } while (0)
   // hot instances: compile-time activations, march tables in LDS; a power-of-two grid with either one cascade and
   // mip_bound == 1 (MARCH_UNIT) or several cascades and a power-of-two bound (MARCH_POW2)
   const bool pow2_h = (M.H & (M.H - 1)) == 0;
@@ -777,7 +992,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   int eb = 0;
   const bool pow2_bound = M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
   const bool pow2 = lds_tab && pow2_h && M.cascade > 1 && pow2_bound;
-  if (M.generic_act) {
+  if (M.generic) {
     if (lds_tab) NRF_LAUNCH_RENDER(true, true, MARCH_GENERIC); else NRF_LAUNCH_RENDER(true, false, MARCH_GENERIC);
   } else {
     if (unit) NRF_LAUNCH_RENDER(false, true, MARCH_UNIT);
@@ -791,33 +1006,42 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 
 hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st) {
   if (!n) return hipSuccess;
-  if (M.generic_act)
-    hipLaunchKernelGGL(encode_grid_kernel<true>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
-                       (uint32_t*)out);
+  if (M.generic)
+    hipLaunchKernelGGL(gen_encode_grid_kernel, dim3(grid_for((uint64_t)n * M.n_levels)), dim3(256), 0, st, M, (const float*)pos01, n,
+                       (half_t*)out);
   else
-    hipLaunchKernelGGL(encode_grid_kernel<false>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+    hipLaunchKernelGGL(encode_grid_kernel, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
                        (uint32_t*)out);
   return hipGetLastError();
 }
 
 hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(encode_dir_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, (const float*)dir01, n, (uint32_t*)out);
+  if (M.generic)
+    hipLaunchKernelGGL(gen_encode_dir_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, (const float*)dir01, n, (half_t*)out);
+  else
+    hipLaunchKernelGGL(encode_dir_kernel, dim3(grid_for(n)), dim3(256), 0, st, M, (const float*)dir01, n, (uint32_t*)out);
   return hipGetLastError();
 }
 
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,
                               hipStream_t st) {
   if (!n) return hipSuccess;
-  const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
-#define NRF_LAUNCH_MLP(G, R)                                                                                                \
-  hipLaunchKernelGGL((mlp_forward_kernel<G, R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M, \
-                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out, repeat)
-  if (M.generic_act) {
-    if (repeat > 1) NRF_LAUNCH_MLP(true, true); else NRF_LAUNCH_MLP(true, false);
-  } else {
-    if (repeat > 1) NRF_LAUNCH_MLP(false, true); else NRF_LAUNCH_MLP(false, false);
+  if (M.generic) {
+    const int lds = gen_lds_bytes(M, 4);
+    hipError_t e = allow_lds(gen_mlp_forward_kernel, lds);
+    if (e != hipSuccess) return e;
+    const uint64_t chunks = ((uint64_t)n + GEN_SAMPLES - 1) / GEN_SAMPLES;
+    for (uint32_t r = 0; r < (repeat ? repeat : 1u); ++r)  // (the repeat count is a measurement aid of the hot instance)
+      hipLaunchKernelGGL(gen_mlp_forward_kernel, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), lds, st, M, (const half_t*)feat,
+                         (const half_t*)dirfeat, n, (uint2*)out);
+    return hipGetLastError();
   }
+  const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
+#define NRF_LAUNCH_MLP(R)                                                                                                \
+  hipLaunchKernelGGL((mlp_forward_kernel<R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M, \
+                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out, repeat)
+  if (repeat > 1) NRF_LAUNCH_MLP(true); else NRF_LAUNCH_MLP(false);
 #undef NRF_LAUNCH_MLP
   return hipGetLastError();
 }
@@ -825,12 +1049,27 @@ hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* d
 hipError_t launch_network(const DevModel& M, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, hipStream_t st) {
   if (!n) return hipSuccess;
   const uint64_t chunks = ((uint64_t)n + 63) / 64;
-  if (M.generic_act)
-    hipLaunchKernelGGL(network_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
+  if (M.generic) {
+    const int lds = gen_lds_bytes(M, 4);
+    hipError_t e = allow_lds(network_kernel<true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(network_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), lds, st, M,
                        (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
-  else
+  } else {
     hipLaunchKernelGGL(network_kernel<false>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
                        (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_density_positions(uint32_t H, float k, void* xyz, void* dir, hipStream_t st) {
+  hipLaunchKernelGGL(density_positions_kernel, dim3(grid_for((uint64_t)H * H * H)), dim3(256), 0, st, H, k, (float*)xyz, (float*)dir);
+  return hipGetLastError();
+}
+
+hipError_t launch_density_update(const void* sigma, uint32_t n, float decay, int n_iterations, void* grid, hipStream_t st) {
+  hipLaunchKernelGGL(density_update_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float*)sigma, n, decay, n_iterations,
+                     (float*)grid);
   return hipGetLastError();
 }
 
@@ -895,6 +1134,7 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
 
 int render_lds_bytes() { return LDS_FIXED_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
+int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes) { return LDS_LEVEL_BYTES + RENDER_WAVES * ((int)sizeof(WaveLds) + (int)gen_wave_bytes); }
 
 
 }  // namespace nrf

@@ -16,6 +16,8 @@ hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, v
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,
                               hipStream_t st);
 hipError_t launch_network(const DevModel& M, const void* xyz, const void* dir, uint32_t n, void* sigma, void* rgb, hipStream_t st);
+hipError_t launch_density_positions(uint32_t H, float k, void* xyz, void* dir, hipStream_t st);
+hipError_t launch_density_update(const void* sigma, uint32_t n, float decay, int n_iterations, void* grid, hipStream_t st);
 hipError_t launch_generate_rays(const DevModel& M, const FrameParams& P, void* rays_o, void* rays_d, void* nears, void* fars,
                                 hipStream_t st);
 hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, const void* rays_d, const void* rays_t,
@@ -28,4 +30,5 @@ hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
 int render_lds_bytes();
 int render_lds_table_max_bytes();
+int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes);  // generic instance: LDS of render_kernel without the march tables
 }  // namespace nrf

@@ -99,6 +99,9 @@ void NerfRender::reload_network_from_file(const std::string& network_config_path
     reset_network();
     // NerfNetwork::deserialize (nerf_network.h:424-443): size check + fp32 -> fp16 + upload
     if (m_group) check(nrf_group_load_model(m_group, &m_desc), "Can't set params");
+    // a snapshot without a density grid (the reference's load_snapshot would throw on the missing key,
+    // nerf_render.cu:447): evaluate one from the network
+    if (m_group && m_density_grid.empty()) generate_density_grid();
   } else {
     throw std::runtime_error{"Input file with wrong extension!"};
   }
@@ -166,10 +169,14 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
     }
     return out;
   };
-  m_density_grid = numbers("density_grid", "density_grid");
   const uint64_t H = d.density_grid_size;
-  if (m_density_grid.size() != H * H * H * d.cascade) {
-    throw std::runtime_error{"Incompatible number of grid cascades."};
+  if (snapshot.contains("density_grid") || snapshot.contains("density_grid_binary")) {
+    m_density_grid = numbers("density_grid", "density_grid");
+    if (m_density_grid.size() != H * H * H * d.cascade) {
+      throw std::runtime_error{"Incompatible number of grid cascades."};
+    }
+  } else {
+    m_density_grid.clear();  // generate_density_grid() after the network is up (reload_network_from_file)
   }
   m_params = numbers("params", "params");
   m_network_config_path = filepath_string;
@@ -195,7 +202,15 @@ void NerfRender::reset_network() {
   const std::string gtype = to_lower(enc.value("type", default_type.c_str()));
   d.grid_type = gtype == "hash" ? NRF_GRID_HASH : (gtype == "dense" ? NRF_GRID_DENSE : NRF_GRID_TILED);
   d.n_features_per_level = enc.value("n_features_per_level", 2u);
-  if (d.n_features_per_level == 0) throw std::runtime_error{"GridEncoding: n_features_per_level must be 1, 2, 4 or 8"};  // grid.h:1403-1411
+  if (d.n_features_per_level != 1 && d.n_features_per_level != 2 && d.n_features_per_level != 4 && d.n_features_per_level != 8)
+    throw std::runtime_error{"GridEncoding: n_features_per_level must be 1, 2, 4, or 8."};  // grid.h:1403-1411
+  {
+    const std::string interp = to_lower(enc.value("interpolation", "Linear"));  // grid.h:1383
+    if (interp == "linear") d.interpolation = NRF_INTERP_LINEAR;
+    else if (interp == "nearest") d.interpolation = NRF_INTERP_NEAREST;
+    else if (interp == "smoothstep") d.interpolation = NRF_INTERP_SMOOTHSTEP;
+    else throw std::runtime_error{"Invalid interpolation type: " + interp};
+  }
   if (enc.contains("n_features") && enc.value("n_features", 0u) > 0) {
     if (enc.contains("n_levels")) throw std::runtime_error{"GridEncoding: may not specify n_features and n_levels simultaneously (one determines the other)"};
     d.n_levels = enc.value("n_features", 0u) / d.n_features_per_level;
@@ -246,7 +261,7 @@ void NerfRender::reset_network() {
 
   d.params = m_params.data();
   d.n_params = m_params.size();
-  d.density_grid = m_density_grid.data();
+  d.density_grid = m_density_grid.empty() ? nullptr : m_density_grid.data();
   d.n_density_grid = m_density_grid.size();
   m_have_network = true;
 }
@@ -305,9 +320,15 @@ void NerfRender::generate_rays(Camera cam, Matrix4f pos, int threadid) {
 }
 
 void NerfRender::generate_density_grid() {
-  // the reference's implementation is dead and incomplete (nerf_render.cu:388-429: the density query
-  // is commented out); snapshots always carry their grid
-  throw std::runtime_error{"generate_density_grid is not implemented (dead code in the reference as well)"};
+  // reference nerf_render.cu:388-429 (dead there: the density query is commented out at :415); completed behind
+  // nrf_generate_density_grid with the reference's constants: decay 0.95 (:392), start value 1/64 (:393), scale
+  // 0.001691 (:417).  16 passes: (1/64) * 0.95^16 < 0.01, so a cell the network finds empty falls below the march's
+  // threshold min(0.01, mean_density) (render_utils.h:560) whenever the scene's mean density is at least 0.01.
+  if (!m_have_network || !m_group) throw std::runtime_error{"generate_density_grid: no network loaded"};
+  float mean = 0.0f;
+  for (nrf_context* ctx : m_ctx) check(nrf_generate_density_grid(ctx, 16, 0.95f, &mean), "nrf_generate_density_grid");
+  m_desc.mean_density = mean;
+  std::printf("density grid generated from the network: mean_density %g\n", mean);
 }
 
 nrf_stats NerfRender::last_stats(int gpu) const {

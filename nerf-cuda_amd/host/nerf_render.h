@@ -63,7 +63,9 @@ class NerfRender {
   std::vector<Image> render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses);
   // device ray buffers of the reference are internal to the fused kernel; this fills host copies
   void generate_rays(Camera cam, Matrix4f pos, int threadid);
-  void generate_density_grid();  // dead code in the reference (nerf_render.cu:388-429): throws
+  // the density grid from the network (nerf_render.cu:388-429, dead and incomplete in the reference; completed in
+  // nrf_generate_density_grid); reload_network_from_file calls it for a snapshot that carries no density grid
+  void generate_density_grid();
   void load_snapshot(const std::string& filepath_string);
 
   // additions (the reference has no accessors)

@@ -23,13 +23,14 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
-NRF_ABI_VERSION = 2
+NRF_ABI_VERSION = 3
 NRF_MAX_VIEWS = 32
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
 
 ACT = {"none": 0, "relu": 1, "exponential": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5, "sine": 6}
 DIR_SH, DIR_FREQUENCY, DIR_IDENTITY = 0, 1, 2
 GRID_HASH, GRID_DENSE, GRID_TILED = 0, 1, 2
+INTERP = {"linear": 0, "nearest": 1, "smoothstep": 2}  # T/.../grid.h:1383, common.h string_to_interpolation_type
 
 
 class ModelDesc(C.Structure):
@@ -41,6 +42,7 @@ class ModelDesc(C.Structure):
         ("log2_hashmap_size", C.c_uint32),
         ("base_resolution", C.c_uint32),
         ("per_level_scale", C.c_float),
+        ("interpolation", C.c_uint32),
         ("n_neurons", C.c_uint32),
         ("density_hidden_layers", C.c_uint32),
         ("density_activation", C.c_uint32),
@@ -138,6 +140,8 @@ _SIGS = {
     "nrf_default_per_level_scale": (C.c_int, [C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "nrf_load_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
     "nrf_set_resolution": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nrf_generate_density_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_float)]),
+    "nrf_read_density_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_float)]),
     "nrf_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "nrf_render": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(Frame)]),
     "nrf_set_max_views": (C.c_int, [C.c_void_p, C.c_int]),
@@ -296,8 +300,12 @@ def desc_from_config(config: dict, params: np.ndarray | None = None, density_gri
     if pls <= 0.0:
         pls = 2.0
     d.per_level_scale = pls
-    if enc.get("interpolation", "Linear").lower() != "linear":
-        raise NotImplementedError("only Linear grid interpolation is on the hot path")
+    interp = enc.get("interpolation", "Linear").lower()
+    if interp not in INTERP:
+        raise RuntimeError(f"Invalid interpolation type: {interp}")
+    d.interpolation = INTERP[interp]
+    if F not in (1, 2, 4, 8):
+        raise RuntimeError("GridEncoding: n_features_per_level must be 1, 2, 4, or 8.")  # grid.h:1403-1411
 
     # network blocks, T/src/network.cu:127-143 + nerf_network.h:117-135
     def mlp(cfg):
@@ -350,9 +358,14 @@ def desc_from_config(config: dict, params: np.ndarray | None = None, density_gri
         return np.frombuffer(blob, np.float32 if kind == "float" else np.float16).astype(np.float32)
 
     p = np.ascontiguousarray(params if params is not None else numbers("params"), dtype=np.float32)
-    g = np.ascontiguousarray(density_grid if density_grid is not None else numbers("density_grid"), dtype=np.float32)
     d.params = p.ctypes.data_as(C.POINTER(C.c_float))
     d.n_params = p.size
+    if density_grid is None and "density_grid" not in snap and "density_grid_binary" not in snap:
+        # no grid in the snapshot: NerfRender::generate_density_grid (nrf_generate_density_grid) makes one from the network
+        d.density_grid = None
+        d.n_density_grid = 0
+        return d, (p, None)
+    g = np.ascontiguousarray(density_grid if density_grid is not None else numbers("density_grid"), dtype=np.float32)
     d.density_grid = g.ctypes.data_as(C.POINTER(C.c_float))
     d.n_density_grid = g.size
     return d, (p, g)
@@ -407,6 +420,18 @@ class NerfHip:
     def set_resolution(self, width: int, height: int):
         _check(self.lib.nrf_set_resolution(self.h, width, height))
         self.width, self.height = width, height
+
+    def generate_density_grid(self, n_iterations: int = 16, decay: float = 0.95) -> float:
+        """nrf_generate_density_grid; returns the new mean_density."""
+        m = C.c_float()
+        _check(self.lib.nrf_generate_density_grid(self.h, int(n_iterations), C.c_float(decay), C.byref(m)))
+        return float(m.value)
+
+    def read_density_grid(self, n_cells: int):
+        grid = np.empty(n_cells, np.float32)
+        m = C.c_float()
+        _check(self.lib.nrf_read_density_grid(self.h, grid.ctypes.data, n_cells, C.byref(m)))
+        return grid, float(m.value)
 
     def set_options(self, opts: Options):
         _check(self.lib.nrf_set_options(self.h, C.byref(opts)))
@@ -542,6 +567,14 @@ class NerfGroup:
     def set_options(self, opts):
         _check(self.lib.nrf_group_set_options(self.h, C.byref(opts)))
 
+    def generate_density_grid(self, n_iterations: int = 16, decay: float = 0.95) -> float:
+        """Every member evaluates the density grid from its replica of the network (nrf_generate_density_grid)."""
+        m = C.c_float()
+        for i in range(self.lib.nrf_group_size(self.h)):
+            ctx = C.c_void_p(self.lib.nrf_group_member(self.h, i))
+            _check(self.lib.nrf_generate_density_grid(ctx, int(n_iterations), C.c_float(decay), C.byref(m)))
+        return float(m.value)
+
     def set_resolution(self, width, height):
         _check(self.lib.nrf_group_set_resolution(self.h, width, height))
         self.width, self.height = width, height
@@ -615,6 +648,13 @@ class NerfRender:
         self.load_snapshot(path)
         self.reset_network()
         self.group.load_model(self.desc)
+        if self.desc.n_density_grid == 0:  # the snapshot carries no density grid
+            self.generate_density_grid()
+
+    def generate_density_grid(self):  # nerf_render.cu:388-429 (dead in the reference; see nrf_generate_density_grid)
+        if self.desc is None:
+            raise RuntimeError("generate_density_grid: no network loaded")
+        self.desc.mean_density = self.group.generate_density_grid(16, 0.95)
 
     def set_resolution(self, resolution):  # nerf_render.cu:186-236
         self.resolution = (int(resolution[0]), int(resolution[1]))

@@ -29,28 +29,52 @@ N_MLP = N_D0 + N_D1 + N_R0 + N_R1 + N_R2  # 10240
 
 
 def base_config(log2_hashmap_size=19, n_levels=16, base_resolution=16, sh_degree=4, rgb_output_activation="None",
-                dir_otype="SphericalHarmonics", n_frequencies=2, grid_type=None, per_level_scale=None):
-    """The four network blocks of reference configs/nerf/base.json."""
+                dir_otype="SphericalHarmonics", n_frequencies=2, grid_type=None, per_level_scale=None,
+                n_features_per_level=2, interpolation=None, n_neurons=64, density_hidden_layers=1, rgb_hidden_layers=2,
+                activation="ReLU", density_output_activation="None", sigma_activation=None, density_n_output=None):
+    """The four network blocks of reference configs/nerf/base.json (defaults), or any other shape the
+    reference's JSON vocabulary can describe."""
     if dir_otype == "SphericalHarmonics":
         dir_nested = {"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": sh_degree}
     elif dir_otype == "Frequency":
         dir_nested = {"n_dims_to_encode": 3, "otype": "Frequency", "n_frequencies": n_frequencies}
     else:
         dir_nested = {"n_dims_to_encode": 3, "otype": "Identity"}
-    encoding = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+    encoding = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
                 "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution}
     if grid_type:  # "Hash" (default) | "Dense" | "Tiled": tcnn GridEncoding `type` (grid.h:1365-1386)
         encoding["type"] = grid_type
     if per_level_scale:
         encoding["per_level_scale"] = float(per_level_scale)
+    if interpolation:  # "Linear" (default) | "Nearest" | "Smoothstep"
+        encoding["interpolation"] = interpolation
+    network = {"otype": "FullyFusedMLP", "activation": activation, "output_activation": density_output_activation,
+               "n_neurons": n_neurons, "n_hidden_layers": density_hidden_layers}
+    if sigma_activation:
+        network["sigma_activation"] = sigma_activation
+    if density_n_output:
+        network["n_output_dims"] = int(density_n_output)
     return {
         "encoding": encoding,
-        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
-                    "n_hidden_layers": 1},
+        "network": network,
         "dir_encoding": {"otype": "Composite", "nested": [dir_nested, {"otype": "Identity", "n_bins": 4, "degree": 4}]},
-        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": rgb_output_activation,
-                        "n_neurons": 64, "n_hidden_layers": 2},
+        "rgb_network": {"otype": "FullyFusedMLP", "activation": activation, "output_activation": rgb_output_activation,
+                        "n_neurons": n_neurons, "n_hidden_layers": rgb_hidden_layers},
     }
+
+
+def network_shape(config):
+    """(feat_raw, feat_w, width, density_hidden, rgb_hidden, dir_raw, dir_w) of a config's four blocks
+    (widths as NerfNetwork derives them, reference nerf_network.h:95-135)."""
+    enc, net, rgb = config["encoding"], config["network"], config["rgb_network"]
+    feat_raw = int(enc.get("n_levels", 16)) * int(enc.get("n_features_per_level", 2))
+    nested = config["dir_encoding"]["nested"][0]
+    ot = nested["otype"].lower()
+    dir_raw = {"sphericalharmonics": int(nested.get("degree", 4)) ** 2, "frequency": 6 * int(nested.get("n_frequencies", 12)),
+               "identity": 3}[ot]
+    pad16 = lambda v: (v + 15) // 16 * 16  # noqa: E731
+    return (feat_raw, pad16(feat_raw), int(net.get("n_neurons", 128)), int(net.get("n_hidden_layers", 5)),
+            int(rgb.get("n_hidden_layers", 5)), dir_raw, pad16(dir_raw))
 
 
 def _occupancy(x, y, z):
@@ -134,14 +158,57 @@ def mlp_weights(seed=1337, sigma_log_median=3.6, rgb_mean=0.5):
     return np.concatenate([m.reshape(-1) for m in (D0, D1, R0, R1, R2)]).astype(np.float32)
 
 
+def mlp_weights_general(shape, seed=1337, sigma_log_median=3.6, rgb_mean=0.5):
+    """MLP parameters for any network shape (see network_shape), calibrated like mlp_weights: sigma = exp(g0) with a
+    median of ~36 and rgb around 0.5 on simulated inputs.  Order: density first | hidden... | last, rgb likewise
+    (reference nerf_network.h:273-291), each matrix row-major [out][in]."""
+    feat_raw, feat_w, width, dens_hidden, rgb_hidden, dir_raw, dir_w = shape
+    rng = np.random.default_rng(seed)
+
+    def matrices(n_in, hidden, first_std, hidden_std, last_std):
+        dims = [n_in] + [width] * hidden + [16]
+        out = []
+        for i in range(len(dims) - 1):
+            std = (first_std * math.sqrt(32.0 / dims[i]) if i == 0 else
+                   (last_std if i == len(dims) - 2 else hidden_std) * math.sqrt(64.0 / dims[i]))
+            out.append(rng.normal(0.0, std, (dims[i + 1], dims[i])).astype(np.float32))
+        return out
+
+    def forward(mats, x):
+        for m in mats[:-1]:
+            x = np.maximum(x @ m.T, 0.0)
+        return x
+
+    D = matrices(feat_w, dens_hidden, 0.5, 0.25, 0.3)
+    D[-1][0] = rng.uniform(0.0, 1.0, width)                     # density row: positive -> g0 > 0
+    R = matrices(16 + dir_w, rgb_hidden, 0.25, 0.2, 0.2)
+    R[-1][:3] = np.abs(rng.normal(0.0, 0.2, (3, width)))        # colour rows: positive
+    feat = np.zeros((2048, feat_w), np.float32)
+    feat[:, :feat_raw] = _simulate_features(rng, 2048)[:, np.arange(feat_raw) % 32]
+    h = forward(D, feat)
+    D[-1][0] *= sigma_log_median / max(float((h @ D[-1][0]).mean()), 1e-3)
+    g = h @ D[-1].T
+    dirf = np.ones((2048, dir_w), np.float32)
+    dirf[:, :dir_raw] = rng.uniform(-1.0, 1.0, (2048, dir_raw))
+    h2 = forward(R, np.concatenate([g, dirf], axis=1).astype(np.float32))
+    for c in range(3):
+        R[-1][c] *= rgb_mean / max(float((h2 @ R[-1][c]).mean()), 1e-3)
+    return np.concatenate([m.reshape(-1) for m in D + R]).astype(np.float32)
+
+
+BASE_SHAPE = (32, 32, 64, 1, 2, 16, 16)
+
+
 def make_scene(n_grid_params, seed=1337, H=128, cascade=1, bound=1.0, scale=0.33, config=None):
     """Returns (config dict with a `snapshot` block but without the two big arrays,
     params float32 [n_params], density_grid float32 [C*H^3]).  `n_grid_params` is the
-    number of hash-table values (2 * total entries), which depends on the level table."""
+    number of hash-table values (F * total entries), which depends on the level table."""
     cfg = dict(config or base_config())
     rng = np.random.default_rng(seed + 1)
     table = rng.uniform(-0.5, 0.5, n_grid_params).astype(np.float32)
-    params = np.concatenate([mlp_weights(seed), table])
+    shape = network_shape(cfg)
+    mlp = mlp_weights(seed) if shape[:5] == BASE_SHAPE[:5] and shape[6] == 16 else mlp_weights_general(shape, seed)
+    params = np.concatenate([mlp, table])
     grid = density_grid(H, cascade, bound)
     cfg["snapshot"] = {
         "aabb": [-bound, -bound, -bound, bound, bound, bound],
@@ -193,14 +260,16 @@ def write_snapshot(path, config, params, density_grid, binary=None):
         dt = np.float16 if binary == "__half" else np.float32
         snap["params_binary"] = np.asarray(params, np.float32).astype(dt).tobytes()
         snap["params_type"] = binary
-        snap["density_grid_binary"] = np.asarray(density_grid, np.float32).astype(dt).tobytes()
-        snap["density_grid_type"] = binary
+        if density_grid is not None:
+            snap["density_grid_binary"] = np.asarray(density_grid, np.float32).astype(dt).tobytes()
+            snap["density_grid_type"] = binary
         cfg["snapshot"] = snap
         with open(path, "wb") as f:
             f.write(msgpack.packb(cfg, use_single_float=True, use_bin_type=True))
         return
     snap["params"] = np.asarray(params, np.float32).tolist()
-    snap["density_grid"] = np.asarray(density_grid, np.float32).tolist()
+    if density_grid is not None:  # None: a snapshot without a grid (NerfRender::generate_density_grid makes one)
+        snap["density_grid"] = np.asarray(density_grid, np.float32).tolist()
     cfg["snapshot"] = snap
     with open(path, "wb") as f:
         f.write(msgpack.packb(cfg, use_single_float=True))

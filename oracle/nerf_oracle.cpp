@@ -115,7 +115,7 @@ inline uint32_t next_multiple(uint32_t v, uint32_t d) { return (v + d - 1) / d *
 struct nrfo_model {
   nrf_model_desc d;
   nrf_level_table lv;
-  uint32_t feat_width;     // 2L padded to 16 (nerf_network.h:103-111)
+  uint32_t feat_width;     // L*F padded to 16 (nerf_network.h:103-111)
   uint32_t dir_width;      // padded dir encoding width (alignment 16)
   uint32_t dir_raw;        // unpadded
   uint32_t rgb_in;         // nerf_network.h:127-130
@@ -241,8 +241,8 @@ uint64_t mlp_params(const std::vector<uint32_t>& dims) {
 
 int dir_widths(const nrf_model_desc& d, uint32_t& raw, uint32_t& padded) {
   switch (d.dir_encoding) {
-    case NRF_DIR_SH:
-      if (d.sh_degree < 1 || d.sh_degree > 4) return fail(NRF_E_UNSUPPORTED, "oracle: SH degree must be 1..4");
+    case NRF_DIR_SH:  // spherical_harmonics.h:394-412: degree 1..8
+      if (d.sh_degree < 1 || d.sh_degree > 8) return fail(NRF_E_INVALID, "SphericalHarmonics: degree must be 1..8");
       raw = d.sh_degree * d.sh_degree;
       break;
     case NRF_DIR_FREQUENCY: raw = 3 * d.n_frequencies * 2; break;
@@ -250,6 +250,7 @@ int dir_widths(const nrf_model_desc& d, uint32_t& raw, uint32_t& padded) {
     default: return fail(NRF_E_UNSUPPORTED, "unknown dir encoding");
   }
   padded = next_multiple(raw, 16u);  // T/src/encoding.cu:97-117 with alignment 16
+  if (raw == 0 || padded > 112) return fail(NRF_E_UNSUPPORTED, "oracle: direction encoding wider than 112");
   return NRF_OK;
 }
 
@@ -258,8 +259,17 @@ int dir_widths(const nrf_model_desc& d, uint32_t& raw, uint32_t& padded) {
 extern "C" {
 
 int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
-  if (!d || !out || !d->params || !d->density_grid) return fail(NRF_E_INVALID, "null argument");
-  if (d->n_features_per_level != 2) return fail(NRF_E_UNSUPPORTED, "oracle: n_features_per_level must be 2");
+  if (!d || !out || !d->params) return fail(NRF_E_INVALID, "null argument");
+  const uint32_t F = d->n_features_per_level;
+  if (F != 1 && F != 2 && F != 4 && F != 8)  // grid.h:1403-1411
+    return fail(NRF_E_INVALID, "GridEncoding: n_features_per_level must be 1, 2, 4, or 8.");
+  if (d->interpolation > NRF_INTERP_SMOOTHSTEP) return fail(NRF_E_INVALID, "Invalid interpolation type");
+  if (d->n_neurons != 16 && d->n_neurons != 32 && d->n_neurons != 64 && d->n_neurons != 128)  // fully_fused_mlp.cu:700-725
+    return fail(NRF_E_INVALID, "FullyFusedMLP: n_neurons must be 16, 32, 64 or 128");
+  if (d->density_hidden_layers < 1 || d->rgb_hidden_layers < 1)  // fully_fused_mlp.cu:653-655
+    return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");
+  if (d->density_n_output < 1 || d->density_n_output > 16)  // wider outputs go through CUTLASS in tcnn (out of scope)
+    return fail(NRF_E_UNSUPPORTED, "oracle: density n_output_dims must be 1..16");
   nrfo_model* m = new nrfo_model;
   m->d = *d;
   int rc = level_table(*d, m->lv);
@@ -267,18 +277,18 @@ int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
   rc = dir_widths(*d, m->dir_raw, m->dir_width);
   if (rc) { delete m; return rc; }
   m->W = d->n_neurons;
-  m->feat_width = next_multiple(d->n_levels * 2, 16u);
+  m->feat_width = next_multiple(d->n_levels * F, 16u);
   m->rgb_in = next_multiple(m->dir_width + 16u, 16u);
   mlp_dims(m->feat_width, m->W, d->density_hidden_layers, m->dens_dims);
   mlp_dims(m->rgb_in, m->W, d->rgb_hidden_layers, m->rgb_dims);
-  const uint64_t n_grid = (uint64_t)m->lv.offset[d->n_levels] * 2;
+  const uint64_t n_grid = (uint64_t)m->lv.offset[d->n_levels] * F;  // grid.h:927
   const uint64_t expect = mlp_params(m->dens_dims) + mlp_params(m->rgb_dims) + n_grid;
   if (d->n_params != expect) {  // R/include/nerf-cuda/nerf_network.h:425-427
     delete m;
     return fail(NRF_E_PARAMS, "Can't set params because number of parameters and model size do not match");
   }
   const uint64_t H = d->density_grid_size;
-  if (d->n_density_grid != H * H * H * d->cascade) {  // R/src/nerf_render.cu:467-469
+  if (d->density_grid && d->n_density_grid != H * H * H * d->cascade) {  // R/src/nerf_render.cu:467-469
     delete m;
     return fail(NRF_E_PARAMS, "Incompatible number of grid cascades.");
   }
@@ -298,7 +308,8 @@ int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
   take(m->rgb_dims, m->rgb_w);
   m->grid.resize(n_grid);
   for (uint64_t i = 0; i < n_grid; ++i) m->grid[i] = f2h(p[i]);
-  m->density_grid.assign(d->density_grid, d->density_grid + d->n_density_grid);
+  if (d->density_grid) m->density_grid.assign(d->density_grid, d->density_grid + d->n_density_grid);
+  else m->density_grid.assign((size_t)(H * H * H * d->cascade), 0.0f);  // none in the snapshot: see nrfo_density_grid
   m->d.params = nullptr;
   m->d.density_grid = nullptr;
   *out = m;
@@ -306,6 +317,12 @@ int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
 }
 
 void nrfo_destroy(nrfo_model* m) { delete m; }
+
+// padded encoding widths = the input widths of the two MLPs (nerf_network.h:103-130)
+void nrfo_widths(const nrfo_model* m, uint32_t* feat_width, uint32_t* dir_width) {
+  if (feat_width) *feat_width = m->feat_width;
+  if (dir_width) *dir_width = m->dir_width;
+}
 
 // T/include/tiny-cuda-nn/encodings/grid.h:100-117
 uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32_t y, uint32_t z) {
@@ -325,10 +342,10 @@ uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32
 
 namespace {
 
-// One sample of kernel_grid<half,3,2>: T/include/tiny-cuda-nn/encodings/grid.h:186-267,
-// pos_fract: T/include/tiny-cuda-nn/common_device.h:414-422 (Linear interpolation).
+// One sample of kernel_grid<half,3,F>: T/include/tiny-cuda-nn/encodings/grid.h:186-267,
+// pos_fract: T/include/tiny-cuda-nn/common_device.h:414-422, smoothstep :379-381.
 void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
-  const uint32_t L = m->d.n_levels;
+  const uint32_t L = m->d.n_levels, F = m->d.n_features_per_level;
   for (uint32_t level = 0; level < L; ++level) {
     const float scale = m->lv.scale[level];
     float pos[3];
@@ -338,10 +355,22 @@ void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
       v = v + 0.5f;
       const int tmp = (int)floorf(v);
       pg[dim] = (uint32_t)tmp;
-      pos[dim] = v - (float)tmp;
+      float fr = v - (float)tmp;
+      if (m->d.interpolation == NRF_INTERP_SMOOTHSTEP) {  // val*val*(3.0f - 2.0f*val)
+        const float sq = fr * fr;
+        const float b = 2.0f * fr;
+        fr = sq * (3.0f - b);
+      }
+      pos[dim] = fr;
     }
-    const uint16_t* table = m->grid.data() + (size_t)m->lv.offset[level] * 2;
-    uint16_t r0 = 0, r1 = 0;  // fp16 accumulators, grid.h:236
+    const uint16_t* table = m->grid.data() + (size_t)m->lv.offset[level] * F;
+    uint16_t* res = out + (size_t)level * F;
+    if (m->d.interpolation == NRF_INTERP_NEAREST) {  // grid.h:215-232: the entry at floor(pos), no weights
+      const uint32_t e = nrfo_grid_index(m, level, pg[0], pg[1], pg[2]);
+      for (uint32_t f = 0; f < F; ++f) res[f] = table[(size_t)e * F + f];
+      continue;
+    }
+    for (uint32_t f = 0; f < F; ++f) res[f] = 0;  // fp16 accumulators, grid.h:236
     for (uint32_t idx = 0; idx < 8; ++idx) {
       float weight = 1;
       uint32_t pl[3];
@@ -355,18 +384,94 @@ void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
         }
       }
       const uint32_t e = nrfo_grid_index(m, level, pl[0], pl[1], pl[2]);
-      const float d0 = h2f(table[2 * e + 0]);
-      const float d1 = h2f(table[2 * e + 1]);
-      r0 = hadd(r0, f2h(weight * d0));  // grid.h:260: result += (T)(weight * data)
-      r1 = hadd(r1, f2h(weight * d1));
+      for (uint32_t f = 0; f < F; ++f)  // grid.h:260: result += (T)(weight * data)
+        res[f] = hadd(res[f], f2h(weight * h2f(table[(size_t)e * F + f])));
     }
-    out[2 * level + 0] = r0;
-    out[2 * level + 1] = r1;
   }
-  for (uint32_t j = 2 * L; j < m->feat_width; ++j) out[j] = f2h(1.0f);  // alignment padding
+  for (uint32_t j = F * L; j < m->feat_width; ++j) out[j] = 0;  // alignment padding is ZERO for grids, grid.h:959-969
 }
 
-// T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:57-96 (degree <= 4),
+// kernel_sh's polynomial table, T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:66-152 (degree <= 8): the
+// published real-SH formulae as that file states them, each evaluated in C++ operator order with every fp32
+// operation individually rounded.
+void sh_coefficients(uint32_t degree, float x, float y, float z, float* c) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+  const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
+  c[0] = 0.28209479177387814f;
+  if (degree <= 1) return;
+  c[1] = -0.48860251190291987f * y;
+  c[2] = 0.48860251190291987f * z;
+  c[3] = -0.48860251190291987f * x;
+  if (degree <= 2) return;
+  c[4] = 1.0925484305920792f * xy;
+  c[5] = -1.0925484305920792f * yz;
+  c[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  c[7] = -1.0925484305920792f * xz;
+  c[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  if (degree <= 3) return;
+  c[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  c[10] = 2.8906114426405538f * xy * z;
+  c[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  c[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  c[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  c[14] = 1.4453057213202769f * z * (x2 - y2);
+  c[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  if (degree <= 4) return;
+  c[16] = 2.5033429417967046f * xy * (x2 - y2);
+  c[17] = 1.7701307697799304f * yz * (-3.0f * x2 + y2);
+  c[18] = 0.94617469575756008f * xy * (7.0f * z2 - 1.0f);
+  c[19] = 0.66904654355728921f * yz * (3.0f - 7.0f * z2);
+  c[20] = -3.1735664074561294f * z2 + 3.7024941420321507f * z4 + 0.31735664074561293f;
+  c[21] = 0.66904654355728921f * xz * (3.0f - 7.0f * z2);
+  c[22] = 0.47308734787878004f * (x2 - y2) * (7.0f * z2 - 1.0f);
+  c[23] = 1.7701307697799304f * xz * (-x2 + 3.0f * y2);
+  c[24] = -3.7550144126950569f * x2 * y2 + 0.62583573544917614f * x4 + 0.62583573544917614f * y4;
+  if (degree <= 5) return;
+  c[25] = 0.65638205684017015f * y * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+  c[26] = 8.3026492595241645f * xy * z * (x2 - y2);
+  c[27] = -0.48923829943525038f * y * (3.0f * x2 - y2) * (9.0f * z2 - 1.0f);
+  c[28] = 4.7935367849733241f * xy * z * (3.0f * z2 - 1.0f);
+  c[29] = 0.45294665119569694f * y * (14.0f * z2 - 21.0f * z4 - 1.0f);
+  c[30] = 0.1169503224534236f * z * (-70.0f * z2 + 63.0f * z4 + 15.0f);
+  c[31] = 0.45294665119569694f * x * (14.0f * z2 - 21.0f * z4 - 1.0f);
+  c[32] = 2.3967683924866621f * z * (x2 - y2) * (3.0f * z2 - 1.0f);
+  c[33] = -0.48923829943525038f * x * (x2 - 3.0f * y2) * (9.0f * z2 - 1.0f);
+  c[34] = 2.0756623148810411f * z * (-6.0f * x2 * y2 + x4 + y4);
+  c[35] = 0.65638205684017015f * x * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+  if (degree <= 6) return;
+  c[36] = 1.3663682103838286f * xy * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
+  c[37] = 2.3666191622317521f * yz * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+  c[38] = 2.0182596029148963f * xy * (x2 - y2) * (11.0f * z2 - 1.0f);
+  c[39] = -0.92120525951492349f * yz * (3.0f * x2 - y2) * (11.0f * z2 - 3.0f);
+  c[40] = 0.92120525951492349f * xy * (-18.0f * z2 + 33.0f * z4 + 1.0f);
+  c[41] = 0.58262136251873131f * yz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+  c[42] = 6.6747662381009842f * z2 - 20.024298714302954f * z4 + 14.684485723822165f * z6 - 0.31784601133814211f;
+  c[43] = 0.58262136251873131f * xz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+  c[44] = 0.46060262975746175f * (x2 - y2) * (11.0f * z2 * (3.0f * z2 - 1.0f) - 7.0f * z2 + 1.0f);
+  c[45] = -0.92120525951492349f * xz * (x2 - 3.0f * y2) * (11.0f * z2 - 3.0f);
+  c[46] = 0.50456490072872406f * (11.0f * z2 - 1.0f) * (-6.0f * x2 * y2 + x4 + y4);
+  c[47] = 2.3666191622317521f * xz * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+  c[48] = 10.247761577878714f * x2 * y4 - 10.247761577878714f * x4 * y2 + 0.6831841051919143f * x6 - 0.6831841051919143f * y6;
+  if (degree <= 7) return;
+  c[49] = 0.70716273252459627f * y * (-21.0f * x2 * y4 + 35.0f * x4 * y2 - 7.0f * x6 + y6);
+  c[50] = 5.2919213236038001f * xy * z * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
+  c[51] = -0.51891557872026028f * y * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + 5.0f * x4 + y4);
+  c[52] = 4.1513246297620823f * xy * z * (x2 - y2) * (13.0f * z2 - 3.0f);
+  c[53] = -0.15645893386229404f * y * (3.0f * x2 - y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
+  c[54] = 0.44253269244498261f * xy * z * (-110.0f * z2 + 143.0f * z4 + 15.0f);
+  c[55] = 0.090331607582517306f * y * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
+  c[56] = 0.068284276912004949f * z * (315.0f * z2 - 693.0f * z4 + 429.0f * z6 - 35.0f);
+  c[57] = 0.090331607582517306f * x * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
+  c[58] = 0.07375544874083044f * z * (x2 - y2) * (143.0f * z2 * (3.0f * z2 - 1.0f) - 187.0f * z2 + 45.0f);
+  c[59] = -0.15645893386229404f * x * (x2 - 3.0f * y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
+  c[60] = 1.0378311574405206f * z * (13.0f * z2 - 3.0f) * (-6.0f * x2 * y2 + x4 + y4);
+  c[61] = -0.51891557872026028f * x * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + x4 + 5.0f * y4);
+  c[62] = 2.6459606618019f * z * (15.0f * x2 * y4 - 15.0f * x4 * y2 + x6 - y6);
+  c[63] = 0.70716273252459627f * x * (-35.0f * x2 * y4 + 21.0f * x4 * y2 - x6 + 7.0f * y6);
+}
+
+// T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:57-152 (degree <= 8),
 // T/include/tiny-cuda-nn/encodings/frequency.h:56-92, identity.h:64-65.
 void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
   const nrf_model_desc& d = m->d;
@@ -375,24 +480,8 @@ void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
     uint16_t* o = out;
     for (uint32_t j = 0; j < pad; ++j) *o++ = f2h(1.0f);  // SH pads in FRONT (:57-64)
     const float x = d01[0] * 2.f - 1.f, y = d01[1] * 2.f - 1.f, z = d01[2] * 2.f - 1.f;
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    float c[16];
-    c[0] = 0.28209479177387814f;
-    c[1] = -0.48860251190291987f * y;
-    c[2] = 0.48860251190291987f * z;
-    c[3] = -0.48860251190291987f * x;
-    c[4] = 1.0925484305920792f * xy;
-    c[5] = -1.0925484305920792f * yz;
-    c[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-    c[7] = -1.0925484305920792f * xz;
-    c[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-    c[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-    c[10] = 2.8906114426405538f * xy * z;
-    c[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-    c[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-    c[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-    c[14] = 1.4453057213202769f * z * (x2 - y2);
-    c[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    float c[64];
+    sh_coefficients(d.sh_degree, x, y, z, c);
     for (uint32_t j = 0; j < m->dir_raw; ++j) o[j] = f2h(c[j]);
   } else if (d.dir_encoding == NRF_DIR_FREQUENCY) {
     const float PI = 3.14159265358979323846f;
@@ -472,7 +561,7 @@ void network_one(const nrfo_model* m, float density_scale, const float xyz[3], c
     float u = 0.5f * dir[c];
     d01[c] = u + 0.5f;
   }
-  uint16_t feat[64], dirfeat[64], out4[4];
+  uint16_t feat[128], dirfeat[128], out4[4];
   encode_grid_one(m, p01, feat);
   encode_dir_one(m, d01, dirfeat);
   network_encoded_one(m, feat, dirfeat, out4);
@@ -832,6 +921,49 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
 #ifdef _OPENMP
   omp_set_num_threads(saved);
 #endif
+  return NRF_OK;
+}
+
+// NerfRender::generate_density_grid, R/src/nerf_render.cu:388-429, completed as nerfhip.h nrf_generate_density_grid
+// documents (the reference's version is dead: its density query is commented out at :415): init_xyzs
+// (render_utils.h:91-108), dd_scale by bound_c - bound_c/H (nerf_render.cu:409-413), the density of the network at
+// that position (the render path's own affine map + encoding + density MLP + sigma activation, fp16), dd_scale by
+// 0.001691 (:417), dg_update (render_utils.h:120-128) n_iterations times from 1/64 (:393).
+int nrfo_density_grid(const nrfo_model* m, int n_iterations, float decay, float* grid, float* mean_density) {
+  if (!m || !grid || n_iterations < 1) return fail(NRF_E_INVALID, "bad argument");
+  const uint32_t H = m->d.density_grid_size, C = m->d.cascade;
+  const int64_t n = (int64_t)H * H * H;
+  const float step = 2.f / (float)(H - 1);
+  for (uint32_t cas = 0; cas < C; ++cas) {
+    const float bound = (float)(1u << cas) < m->d.bound ? (float)(1u << cas) : m->d.bound;
+    const float half_grid_size = bound / (float)H;
+    const float k = bound - half_grid_size;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      const uint32_t id[3] = {(uint32_t)(i / ((int64_t)H * H)), (uint32_t)((i % ((int64_t)H * H)) / H), (uint32_t)(i % H)};
+      float xyz[3];
+      for (int a = 0; a < 3; ++a) {
+        float v = step * (float)id[a];
+        v = -1.f + v;
+        xyz[a] = k * v;
+      }
+      const float dir[3] = {0.0f, 0.0f, 1.0f};
+      float sigma, rgb[3];
+      network_one(m, 1.0f, xyz, dir, &sigma, rgb);
+      const float tmp = 0.001691f * sigma;
+      float g = 1.0f / 64;
+      for (int it = 0; it < n_iterations; ++it) {
+        if (g >= 0) {
+          const float gd = g * decay;
+          g = gd > tmp ? gd : tmp;
+        }
+      }
+      grid[(size_t)cas * n + i] = g;
+    }
+  }
+  double sum = 0.0;
+  for (int64_t i = 0; i < n * C; ++i) sum += grid[i] > 0.0f ? (double)grid[i] : 0.0;
+  if (mean_density) *mean_density = (float)(sum / (double)(n * C));
   return NRF_OK;
 }
 

@@ -46,6 +46,8 @@ enum {
 const char* nrfo_last_error(void);
 int nrfo_create(const nrf_model_desc* d, nrfo_model** out);
 void nrfo_destroy(nrfo_model* m);
+/* padded widths of the position / direction encodings (fp16 values per sample) */
+void nrfo_widths(const nrfo_model* m, uint32_t* feat_width, uint32_t* dir_width);
 
 /* fp16 helpers (round-to-nearest-even, IEEE binary16) */
 uint16_t nrfo_f32_to_f16(float f);
@@ -79,6 +81,9 @@ int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, 
 int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W,
                 int H, const nrf_options* o, int schedule, int n_threads, float* rgba,
                 float* depth, nrf_stats* stats);
+/* NerfRender::generate_density_grid (nerf_render.cu:388-429) as nerfhip.h's nrf_generate_density_grid completes it:
+ * grid [cascade * H^3] (x-major cells), mean_density = mean(max(g, 0))                                           */
+int nrfo_density_grid(const nrfo_model* m, int n_iterations, float decay, float* grid, float* mean_density);
 /* nerf_render.cu:352-359 with saturation (DESIGN.md deviation D-2)          */
 void nrfo_quantize_u8(const float* rgba, const float* depth, int n_px, uint8_t* rgb,
                       uint8_t* depth_u8);

@@ -16,7 +16,7 @@ def build_model(log2_hashmap_size=19, H=128, cascade=1, bound=1.0, seed=1337, **
                          "density_grid_size": H, "params": [0.0], "density_grid": [0.0]}
     d0, _ = nh.desc_from_config(probe)
     lt = nh.level_table(d0)
-    n_grid = int(lt.offset[d0.n_levels]) * 2
+    n_grid = int(lt.offset[d0.n_levels]) * int(d0.n_features_per_level)
     cfg, params, grid = syn.make_scene(n_grid, seed=seed, H=H, cascade=cascade, bound=bound, config=cfg)
     desc, keep = nh.desc_from_config(cfg, params, grid)
     return desc, keep, cfg

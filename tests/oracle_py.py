@@ -36,6 +36,8 @@ def lib():
     L.nrfo_create.argtypes = [C.POINTER(nh.ModelDesc), C.POINTER(vp)]
     L.nrfo_destroy.argtypes = [vp]
     L.nrfo_destroy.restype = None
+    L.nrfo_widths.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.nrfo_widths.restype = None
     L.nrfo_f32_to_f16.argtypes = [C.c_float]
     L.nrfo_f32_to_f16.restype = C.c_uint16
     L.nrfo_f16_to_f32.argtypes = [C.c_uint16]
@@ -55,6 +57,7 @@ def lib():
     L.nrfo_composite.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.nrfo_render.argtypes = [vp, fp, fp, C.c_int, C.c_int, C.POINTER(nh.Options), C.c_int, C.c_int, vp, vp,
                               C.POINTER(nh.Stats)]
+    L.nrfo_density_grid.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(C.c_float)]
     L.nrfo_quantize_u8.argtypes = [vp, vp, C.c_int, vp, vp]
     L.nrfo_quantize_u8.restype = None
     L.nrfo_max_threads.restype = C.c_int
@@ -91,6 +94,9 @@ class Oracle:
         h = C.c_void_p()
         _ck(self.L.nrfo_create(C.byref(desc), C.byref(h)))
         self.h = h
+        fw, dw = C.c_uint32(), C.c_uint32()
+        self.L.nrfo_widths(h, C.byref(fw), C.byref(dw))
+        self.feat_width, self.dir_width = int(fw.value), int(dw.value)  # padded encoding widths (MLP input widths)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -102,13 +108,13 @@ class Oracle:
 
     def encode_grid(self, pos01):
         pos01 = _f32(pos01).reshape(-1, 3)
-        out = np.empty((len(pos01), 32), np.uint16)
+        out = np.empty((len(pos01), self.feat_width), np.uint16)
         _ck(self.L.nrfo_encode_grid(self.h, pos01.ctypes.data, len(pos01), out.ctypes.data))
         return out
 
-    def encode_dir(self, dir01, width=16):
+    def encode_dir(self, dir01):
         dir01 = _f32(dir01).reshape(-1, 3)
-        out = np.empty((len(dir01), width), np.uint16)
+        out = np.empty((len(dir01), self.dir_width), np.uint16)
         _ck(self.L.nrfo_encode_dir(self.h, dir01.ctypes.data, len(dir01), out.ctypes.data))
         return out
 
@@ -150,6 +156,12 @@ class Oracle:
 
     def composite(self, sigmas, rgbs, deltas, rays_t, state):
         return composite(sigmas, rgbs, deltas, rays_t, state)
+
+    def density_grid(self, n_cells, n_iterations=16, decay=0.95):
+        grid = np.empty(n_cells, np.float32)
+        mean = C.c_float()
+        _ck(self.L.nrfo_density_grid(self.h, int(n_iterations), C.c_float(decay), grid.ctypes.data, C.byref(mean)))
+        return grid, float(mean.value)
 
     def render(self, cam, pose, W, H, opts=None, schedule=SCHED_REFERENCE, n_threads=0):
         opts = opts or nh.default_options()

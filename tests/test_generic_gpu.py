@@ -1,0 +1,229 @@
+"""The GENERIC instance of the fused kernel (nerf-cuda_amd/csrc/nrf_generic.h) against the oracle: every network
+shape of the reference's JSON vocabulary outside the base.json shape -- direction encodings at real widths
+(Frequency with tcnn's default 12 frequencies, SphericalHarmonics to degree 8), n_neurons 16/32/128, other
+hidden-layer counts, n_features_per_level 1/4/8, fewer levels, Nearest / Smoothstep interpolation.
+
+Tolerances as in test_parity_gpu.py: hash-grid and SH encodings BIT-EXACT, Frequency 4e-3 (v_sin_f32 on
+arguments up to 2^11 pi against libm's sinf; the reference itself uses __sinf), MLP outputs a few fp16 ulps
+(fp32 summation order), frames max |d| <= 2/255 and PSNR >= 45 dB."""
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import oracle_py as op
+import synthetic as syn
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_parity_gpu import dev, mlp_close, sync  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    h = nh.NerfHip(0)
+    yield h
+    h.close()
+
+
+SHAPES = {
+    # a10: direction encodings at real widths (rgb input 16 + 80 / 16 + 64 ... columns)
+    "freq12": dict(dir_otype="Frequency", n_frequencies=12),
+    "freq10": dict(dir_otype="Frequency", n_frequencies=10),
+    "freq4": dict(dir_otype="Frequency", n_frequencies=4),
+    "sh5": dict(sh_degree=5),
+    "sh6": dict(sh_degree=6),
+    "sh7": dict(sh_degree=7),
+    "sh8": dict(sh_degree=8),
+    # MLP shapes (fully_fused_mlp.cu:700-725, 636-687)
+    "w32_h2_h3": dict(n_neurons=32, density_hidden_layers=2, rgb_hidden_layers=3),
+    "w128_h1_h1": dict(n_neurons=128, density_hidden_layers=1, rgb_hidden_layers=1),
+    "w16_h3_h4": dict(n_neurons=16, density_hidden_layers=3, rgb_hidden_layers=4),
+    "w64_h2_h2": dict(density_hidden_layers=2),
+    # grid shapes (grid.h:1365-1411)
+    "F1_L16": dict(n_features_per_level=1),
+    "F4_L8": dict(n_features_per_level=4, n_levels=8),
+    "F8_L16_w128": dict(n_features_per_level=8, n_neurons=128),
+    "F2_L5": dict(n_levels=5),
+    "F2_L11_sh8_w32": dict(n_levels=11, sh_degree=8, n_neurons=32),
+    "nearest": dict(interpolation="Nearest"),
+    "smoothstep_F4": dict(interpolation="Smoothstep", n_features_per_level=4, n_levels=6),
+    # activations + explicit density width
+    "sigmoid_softplus": dict(activation="Softplus", rgb_output_activation="Sigmoid", sigma_activation="ReLU", density_n_output=1),
+}
+
+
+def _inputs(n, seed):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p01 = (np.float32(0.5) * xyz + np.float32(0.5)).astype(np.float32)
+    d01 = (np.float32(0.5) * d + np.float32(0.5)).astype(np.float32)
+    return xyz, d, p01, d01
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_generic_shape_stage_by_stage_and_frame(ctx, name):
+    kw = SHAPES[name]
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, **kw)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    n = 3001  # ragged: not a multiple of 32
+    xyz, d, p01, d01 = _inputs(n, 5)
+    p01[:4] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [1 - 2 ** -24, 2 ** -24, 0.5]]
+    # ---- encodings
+    feat_w = o.encode_grid(p01)
+    out = torch.empty((n, o.feat_width), dtype=torch.int16, device="cuda")
+    p_d = dev(p01)
+    sync()
+    ctx.encode_grid(p_d.data_ptr(), n, out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), feat_w)          # bit-exact, zero padding included
+    dir_w = o.encode_dir(d01)
+    outd = torch.empty((n, o.dir_width), dtype=torch.int16, device="cuda")
+    d_d = dev(d01)
+    sync()
+    ctx.encode_dir(d_d.data_ptr(), n, outd.data_ptr())
+    got = outd.cpu().numpy().view(np.uint16)
+    if kw.get("dir_otype") == "Frequency":
+        np.testing.assert_allclose(got.view(np.float16).astype(np.float32), dir_w.view(np.float16).astype(np.float32), atol=4e-3)
+        np.testing.assert_array_equal(got[:, 6 * kw["n_frequencies"]:], dir_w[:, 6 * kw["n_frequencies"]:])  # trailing ones
+    else:
+        np.testing.assert_array_equal(got, dir_w)
+    # ---- both MLPs on the oracle's encodings
+    want = o.mlp_forward(feat_w, dir_w).view(np.float16).astype(np.float32)
+    out4 = torch.empty((n, 4), dtype=torch.float16, device="cuda")
+    f_d, dd_d = dev(feat_w.view(np.int16)), dev(dir_w.view(np.int16))
+    sync()
+    ctx.mlp_forward(f_d.data_ptr(), dd_d.data_ptr(), n, out4.data_ptr())
+    got4 = out4.cpu().numpy().astype(np.float32)
+    mlp_close(got4[:, :3], want[:, :3], f"{name}: rgb (mlp_forward)")
+    if kw.get("sigma_activation") == "ReLU":
+        mlp_close(got4[:, 3], want[:, 3], f"{name}: sigma (mlp_forward)")
+    else:
+        mlp_close(np.log(got4[:, 3]), np.log(want[:, 3]), f"{name}: log sigma (mlp_forward)")
+    # ---- the whole network from raw march output (the render kernel's own code path)
+    if kw.get("dir_otype") != "Frequency":  # (Frequency inputs differ by the __sinf tolerance before the MLP amplifies them)
+        sig_w, rgb_w = o.network(xyz, d)
+        sig = torch.empty(n, dtype=torch.float32, device="cuda")
+        rgb = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+        x_d, dv = dev(xyz), dev(d)
+        sync()
+        ctx.network(x_d.data_ptr(), dv.data_ptr(), n, sig.data_ptr(), rgb.data_ptr())
+        mlp_close(rgb.cpu().numpy(), rgb_w, f"{name}: rgb (network)")
+        if kw.get("sigma_activation") == "ReLU":
+            mlp_close(sig.cpu().numpy(), sig_w, f"{name}: sigma (network)")
+        else:
+            mlp_close(np.log(sig.cpu().numpy()), np.log(sig_w), f"{name}: log sigma (network)")
+    # ---- a frame
+    W, H = 72, 48
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(215, 25)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    ctx.render(cam, pose)
+    rgba, depth = ctx.read_f32()
+    st = ctx.stats()
+    wantf, wdepth, wst = o.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
+    assert st.n_samples > 0 and wst.n_samples * 0.995 - 8 <= st.n_samples <= wst.n_samples * 1.5 + 64
+    assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0, name
+    assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+
+
+def test_generic_instance_full_size_and_batches(ctx):
+    """Frequency-12 directions on the full-size table (T = 2^19) at 1920x1080: the generic instance's LDS map with the
+    march tables, batched views bit-identical to single renders, and a crop against the oracle."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128, dir_otype="Frequency", n_frequencies=12)
+    ctx.load_model(desc)
+    W, H = 1920, 1080
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    cam = syn.default_camera(W, H)
+    poses = [syn.orbit_pose(30, 30), syn.orbit_pose(200, 15)]
+    singles = []
+    for p in poses:
+        ctx.render(cam, p)
+        singles.append(ctx.read_f32())
+    assert ctx.stats().n_samples > 5_000_000
+    ctx.set_max_views(2)
+    ctx.render_views(np.stack([cam, cam]), np.stack(poses))
+    for v in range(2):
+        rgba, depth = ctx.read_view_f32(v)
+        np.testing.assert_array_equal(rgba, singles[v][0])
+        np.testing.assert_array_equal(depth, singles[v][1])
+    ctx.set_max_views(1)
+    assert np.all(np.isfinite(singles[0][0])) and singles[0][0][..., 3].min() >= 0 and singles[0][0][..., 3].max() <= 1 + 1e-5
+    # a 128x64 crop through the object against the oracle (same rays: the crop is a shifted principal point)
+    cw, ch, x0, y0 = 128, 64, 900, 500
+    ccam = cam.copy()
+    ccam[2] -= x0
+    ccam[3] -= y0
+    want, wdepth, _ = op.Oracle(desc).render(ccam, poses[0], cw, ch, schedule=op.SCHED_PER_RAY)
+    got = singles[0][0][y0:y0 + ch, x0:x0 + cw]
+    assert np.abs(got - want).max() <= 2.0 / 255.0 and models.psnr(got, want) >= 45.0
+
+
+def test_unsupported_shapes_are_refused_loudly(ctx):
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    for field, value, code in (("n_neurons", 48, nh.NRF_E_INVALID), ("n_features_per_level", 3, nh.NRF_E_INVALID),
+                               ("sh_degree", 9, nh.NRF_E_INVALID), ("interpolation", 7, nh.NRF_E_INVALID),
+                               ("density_n_output", 32, nh.NRF_E_UNSUPPORTED)):
+        old = getattr(desc, field)
+        setattr(desc, field, value)
+        with pytest.raises(nh.NerfHipError) as e:
+            ctx.load_model(desc)
+        assert e.value.code in (code, nh.NRF_E_PARAMS), (field, e.value)
+        setattr(desc, field, old)
+    ctx.load_model(desc)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cascade=2, bound=2.0), dict(n_neurons=32, n_features_per_level=4, n_levels=8)])
+def test_density_grid_from_the_network(ctx, kw):
+    """f4: NerfRender::generate_density_grid (nerf_render.cu:388-429) completed behind nrf_generate_density_grid.  A
+    model loaded WITHOUT a density grid refuses to render until the grid has been evaluated from the network; the
+    generated grid matches the oracle's (sigma carries the MLP tolerance, so: values within a few fp16 ulps,
+    occupancy bits equal except for cells within that tolerance of the threshold); and with the GPU's grid handed to
+    the oracle, frames agree as for any snapshot."""
+    Hg = 32
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=Hg, **kw)
+    cascade = int(desc.cascade)
+    n_cells = cascade * Hg ** 3
+    d0, k0 = nh.desc_from_config({**cfg, "snapshot": {k: v for k, v in cfg["snapshot"].items()}}, keep[0])  # no grid
+    assert d0.n_density_grid == 0
+    ctx.load_model(d0)
+    ctx.set_options(nh.default_options())
+    W, H = 64, 48
+    ctx.set_resolution(W, H)
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(40, 25)
+    with pytest.raises(nh.NerfHipError) as e:
+        ctx.render(cam, pose)
+    assert e.value.code == nh.NRF_E_STATE and "density grid" in str(e.value)
+    mean = ctx.generate_density_grid(16, 0.95)
+    grid, mean2 = ctx.read_density_grid(n_cells)
+    assert mean == mean2 and np.isfinite(grid).all() and grid.min() >= np.float32(1 / 64) * np.float32(0.95) ** 16 * 0.999
+    # the oracle's grid: same procedure on the CPU
+    want, wmean = op.Oracle(d0).density_grid(n_cells, 16, 0.95)
+    floor = float(want.min())
+    rel = np.abs(grid - want) / np.maximum(np.abs(want), 1e-12)
+    assert rel.max() <= 4 * 2.0 ** -8, rel.max()           # sigma = exp(g0) of an fp16 g0 with the MLP tolerance
+    assert (rel > 0).mean() < 0.3                           # ... and most cells are bit-identical
+    assert abs(mean - wmean) <= 2e-3 * abs(wmean)
+    thresh = min(0.01, wmean)
+    near = np.abs(want - thresh) <= 4 * 2.0 ** -8 * thresh
+    np.testing.assert_array_equal((grid > min(0.01, mean))[~near], (want > thresh)[~near])
+    assert floor < 0.01  # sixteen passes of decay took untouched cells below the threshold
+    # render with the generated grid; the oracle gets the same grid as a snapshot would carry it
+    ctx.render(cam, pose)
+    rgba, depth = ctx.read_f32()
+    assert ctx.stats().n_samples > 0
+    cfg2 = dict(cfg)
+    cfg2["snapshot"] = dict(cfg["snapshot"], mean_density=mean)
+    d2, k2 = nh.desc_from_config(cfg2, keep[0], grid)
+    wantf, wdepth, wst = op.Oracle(d2).render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
+    assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0
+    assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+    # regenerating replaces the tables in place; a snapshot WITH a grid is untouched by all this
+    assert ctx.generate_density_grid(16, 0.95) == mean
+    ctx.load_model(desc)
+    g3, m3 = ctx.read_density_grid(n_cells)
+    np.testing.assert_array_equal(g3, keep[1])

@@ -406,3 +406,36 @@ def test_snapshot_parser_rejects_hostile_input(tmp_path):
         r = _info(f)
         assert r.returncode == 1, (name, r.returncode, r.stderr[-300:])   # 1 = caught exception; a signal would be negative
         assert "error" in r.stderr.lower() or "msgpack" in r.stderr or "must be" in r.stderr, (name, r.stderr[-300:])
+
+
+@pytest.mark.gpu
+def test_snapshot_without_density_grid_renders_in_both_mirrors(tmp_path, snapshot):
+    """f4 through the callers: a snapshot that carries no density grid (the reference's load_snapshot would throw on
+    the missing key) is completed by NerfRender::generate_density_grid -- C++ testbed and Python mirror agree bit for
+    bit, and with the HIP context's own generate + render."""
+    path, desc, keep, cfg = snapshot
+    bare = tmp_path / "nogrid.msgpack"
+    syn.write_snapshot(bare, cfg, keep[0], None)
+    W, H = 96, 64
+    r = subprocess.run([str(HOST / "testbed"), str(bare), str(W), str(H), str(tmp_path) + "/"], capture_output=True, text=True,
+                       timeout=180)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "density grid generated from the network" in r.stdout
+    got = np.fromfile(tmp_path / "image.rgb", np.uint8).reshape(H, W, 3)
+    s = np.float32(W) / np.float32(500.0)
+    cam = np.array([3550.115 / 8, 3554.515 / 8, 3010.45 / 8, 1996.027 / 8], np.float32) * s
+    render = nh.NerfRender(devices=[0])
+    render.reload_network_from_file(bare)
+    render.set_resolution((W, H))
+    rgb, _ = render.render_frame(cam, syn.REFERENCE_MAIN_POSE)
+    render.close()
+    np.testing.assert_array_equal(got, rgb)
+    d0, k0 = nh.desc_from_config(syn.read_snapshot(bare))
+    ctx = nh.NerfHip(0)
+    ctx.load_model(d0)
+    ctx.generate_density_grid(16, 0.95)
+    ctx.set_resolution(W, H)
+    ctx.render(cam, syn.REFERENCE_MAIN_POSE)
+    np.testing.assert_array_equal(ctx.read_u8()[0], got)
+    ctx.close()
+    assert got.min() < 250

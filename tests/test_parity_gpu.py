@@ -309,10 +309,10 @@ def test_model_without_occupied_cells_and_errors(ctx):
     with pytest.raises(nh.NerfHipError) as e:
         ctx.load_model(bad)
     assert e.value.code == nh.NRF_E_PARAMS
-    bad = nh.ModelDesc.from_buffer_copy(desc); bad.n_neurons = 128
+    bad = nh.ModelDesc.from_buffer_copy(desc); bad.n_neurons = 48  # FullyFusedMLP: 16, 32, 64 or 128 (fully_fused_mlp.cu:700-725)
     with pytest.raises(nh.NerfHipError) as e:
         ctx.load_model(bad)
-    assert e.value.code == nh.NRF_E_UNSUPPORTED
+    assert e.value.code == nh.NRF_E_INVALID
     fresh = nh.NerfHip(0)
     with pytest.raises(nh.NerfHipError) as e:
         fresh.render(syn.default_camera(8, 8), syn.orbit_pose(0))
@@ -748,6 +748,8 @@ def test_occupied_boundary_layer_outside_the_outermost_cube(ctx, bound, cascade,
     W, H = 96, 64
     cam = syn.default_camera(W, H) * np.float32(0.5)  # wide field of view: the faces are in the picture
     cam[2:] = (W * 0.5, H * 0.5)
+    o_plain = op.Oracle(desc)  # the same scene without the occupied faces
+    extra = []
     for az, el, radius in ((20, 25, 4.0311), (200, -30, 9.0), (95, 60, 2.0)):
         pose = syn.orbit_pose(az, el, radius=radius)
         ro, rd, nr, fr = _rays(ctx, o, W, H, cam, pose)
@@ -758,15 +760,10 @@ def test_occupied_boundary_layer_outside_the_outermost_cube(ctx, bound, cascade,
         ctx.march(ro.data_ptr(), rd.data_ptr(), nr.data_ptr(), fr.data_ptr(), n, 4, xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr())
         wx, wd, wdl = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), 4)
         np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
-        # the scene of this test: samples exist beyond the outermost cube's faces
-        outer = min(2.0 ** (cascade - 1), bound)
-        emitted = wdl[..., 0] > 0
-        far_out = np.abs(wx[emitted]).max(axis=-1)
-        if bound > outer:
-            assert (far_out > outer * (1 + 2.0 / Hg)).any()
-        elif aabb_half > bound:
-            assert (far_out == bound).any()  # positions beyond +-bound, clamped onto the face
         rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose)
         assert st.n_samples >= wst.n_samples * 0.995 - 8, (st.n_samples, wst.n_samples)  # nothing was culled away
+        extra.append(wst.n_samples - o_plain.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)[2].n_samples)
         assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
         assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+    # the scene of this test: the occupied faces (and, through the index clamp, the space beyond them) add samples
+    assert max(extra) > 1000, extra
