@@ -4,6 +4,8 @@
 // load_snapshot :431-473.
 #include "nerf_render.h"
 
+#include "json_lite.h"
+
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -114,11 +116,21 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
     throw std::runtime_error{"File " + filepath_string + " does not contain a snapshot."};
   }
   const mpk::Value& snapshot = config.at("snapshot");
-  const mpk::Value& aabb = snapshot.at("aabb");
-  if (aabb.type != mpk::Value::NumArray || aabb.nums.size() != 6) throw std::runtime_error{"snapshot.aabb must hold 6 numbers"};
   nrf_model_desc& d = m_desc;
   d = nrf_model_desc{};
   d.abi_version = NRF_ABI_VERSION;
+  m_ngp_per_level_scale = 0.0f;
+  m_ngp_rgb_sigmoid = false;
+  // instant-ngp's own snapshot layout (the reference reads only its array form): see load_ngp_snapshot
+  if (snapshot.contains("nerf") || (snapshot.contains("aabb") && snapshot.at("aabb").type == mpk::Value::Map)) {
+    load_ngp_snapshot(config);
+    m_network_config_path = filepath_string;
+    m_network_config = std::move(config);
+    m_have_snapshot = true;
+    return;
+  }
+  const mpk::Value& aabb = snapshot.at("aabb");
+  if (aabb.type != mpk::Value::NumArray || aabb.nums.size() != 6) throw std::runtime_error{"snapshot.aabb must hold 6 numbers"};
   for (int i = 0; i < 6; ++i) d.aabb[i] = aabb.nums[i];
   d.bound = snapshot.value("bound", 1.0f);                       // member defaults nerf_render.h:55-67
   d.scale = snapshot.value("scale", 0.33f);
@@ -184,6 +196,173 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
   m_have_snapshot = true;
 }
 
+namespace {
+float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+  uint32_t bits;
+  if (e == 0) {
+    if (m == 0) bits = sign;
+    else {
+      int sh = 0;
+      uint32_t mm = m;
+      while (!(mm & 1024u)) { mm <<= 1; ++sh; }
+      bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13);
+    }
+  } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+  else bits = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+std::vector<float> blob_to_floats(const std::string& blob, bool is_float, const char* what) {
+  std::vector<float> out;
+  if (is_float) {
+    if (blob.size() % 4) throw std::runtime_error{std::string(what) + ": size is not a multiple of 4"};
+    out.resize(blob.size() / 4);
+    std::memcpy(out.data(), blob.data(), blob.size());
+  } else {
+    if (blob.size() % 2) throw std::runtime_error{std::string(what) + ": size is not a multiple of 2"};
+    out.resize(blob.size() / 2);
+    for (size_t i = 0; i < out.size(); ++i) {
+      uint16_t h;
+      std::memcpy(&h, blob.data() + 2 * i, 2);
+      out[i] = half_bits_to_float(h);
+    }
+  }
+  return out;
+}
+uint32_t expand_bits(uint32_t v) {  // instant-ngp's morton3D (the reference carries the same helper, render_utils.h:157-170)
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) { return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2); }
+}  // namespace
+
+// instant-ngp's snapshot layout -> the reference's conventions (same mapping as nerfhip.py ngp_snapshot_to_reference,
+// which documents it): bound = aabb_scale / 2, x_ref = x_ngp - 0.5, reference cascade k = instant-ngp cascade k + 1
+// (cascade 0 when aabb_scale == 1) max-pooled with its children, Morton -> x-major, mean over instant-ngp's cascade 0,
+// per_level_scale from aabb_scale when the file leaves it out, logistic colour activation as the rgb output activation.
+void NerfRender::load_ngp_snapshot(const mpk::Value& config) {
+  const mpk::Value& snapshot = config.at("snapshot");
+  static const mpk::Value empty_map = [] { mpk::Value v; v.type = mpk::Value::Map; return v; }();
+  const mpk::Value& nerf = snapshot.contains("nerf") ? snapshot.at("nerf") : empty_map;
+  const mpk::Value& dataset = nerf.contains("dataset") ? nerf.at("dataset") : empty_map;
+  const uint32_t aabb_scale = nerf.value("aabb_scale", dataset.value("aabb_scale", 1u));
+  if (aabb_scale < 1 || (aabb_scale & (aabb_scale - 1))) throw std::runtime_error{"instant-ngp snapshot: aabb_scale must be a power of two"};
+  if (dataset.contains("offset")) {
+    const mpk::Value& off = dataset.at("offset");
+    if (off.type != mpk::Value::NumArray || off.nums.size() != 3) throw std::runtime_error{"instant-ngp snapshot: dataset.offset must hold 3 numbers"};
+    for (float v : off.nums)
+      if (std::fabs(v - 0.5f) > 1e-6f) throw std::runtime_error{"instant-ngp snapshot: dataset.offset other than 0.5 has no counterpart in the reference"};
+  }
+  const uint32_t H = snapshot.value("density_grid_size", 128u);
+  if (H < 4 || (H & (H - 1))) throw std::runtime_error{"instant-ngp snapshot: density_grid_size must be a power of two (Morton order)"};
+  uint32_t n_ngp = 0;
+  for (uint32_t v = aabb_scale; v; v >>= 1) ++n_ngp;  // K + 1 cascades
+  const uint64_t H3 = (uint64_t)H * H * H, cells = H3 * n_ngp;
+  if (!snapshot.contains("density_grid_binary") || snapshot.at("density_grid_binary").type != mpk::Value::Bin)
+    throw std::runtime_error{"instant-ngp snapshot: density_grid_binary is missing"};
+  const std::string& blob = snapshot.at("density_grid_binary").str;
+  const std::string gtype = snapshot.value("density_grid_type", blob.size() == 4 * cells ? "float" : "__half");
+  const std::vector<float> ngp = blob_to_floats(blob, gtype == "float", "snapshot.density_grid_binary");
+  if (ngp.size() < cells) throw std::runtime_error{"Incompatible number of grid cascades."};
+  nrf_model_desc& d = m_desc;
+  d.bound = (float)aabb_scale / 2.0f;
+  d.scale = dataset.value("scale", 0.33f);
+  d.cascade = aabb_scale == 1 ? 1u : n_ngp - 1;
+  d.density_grid_size = H;
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = 0.5f - d.bound; hi[a] = 0.5f + d.bound; }
+  if (snapshot.contains("aabb") && snapshot.at("aabb").type == mpk::Value::Map) {
+    const mpk::Value& bb = snapshot.at("aabb");
+    if (bb.contains("min") && bb.at("min").type == mpk::Value::NumArray && bb.at("min").nums.size() == 3)
+      for (int a = 0; a < 3; ++a) lo[a] = bb.at("min").nums[a];
+    if (bb.contains("max") && bb.at("max").type == mpk::Value::NumArray && bb.at("max").nums.size() == 3)
+      for (int a = 0; a < 3; ++a) hi[a] = bb.at("max").nums[a];
+  }
+  for (int a = 0; a < 3; ++a) { d.aabb[a] = lo[a] - 0.5f; d.aabb[a + 3] = hi[a] - 0.5f; }
+  {
+    double sum = 0.0;  // instant-ngp: mean of max(v, 0) over its cascade 0
+    for (uint64_t i = 0; i < H3; ++i) sum += ngp[i] > 0.0f ? (double)ngp[i] : 0.0;
+    d.mean_density = (float)(sum / (double)H3);
+  }
+  m_density_grid.assign((size_t)H3 * d.cascade, 0.0f);
+  const uint32_t q = H / 4, half = H / 2;
+  for (uint32_t k = 0; k < d.cascade; ++k) {
+    const uint32_t c = aabb_scale == 1 ? 0u : k + 1;
+    const float* own = ngp.data() + (size_t)c * H3;
+    const float* fine = c > 0 ? ngp.data() + (size_t)(c - 1) * H3 : nullptr;
+    float* out = m_density_grid.data() + (size_t)k * H3;
+    for (uint32_t x = 0; x < H; ++x)
+      for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t z = 0; z < H; ++z) {
+          float v = own[morton3d(x, y, z)];
+          if (fine && x >= q && x < q + half && y >= q && y < q + half && z >= q && z < q + half) {
+            const uint32_t fx = 2 * (x - q), fy = 2 * (y - q), fz = 2 * (z - q);  // the eight children in the finer cascade
+            for (uint32_t c8 = 0; c8 < 8; ++c8) v = std::max(v, fine[morton3d(fx + (c8 & 1), fy + ((c8 >> 1) & 1), fz + ((c8 >> 2) & 1))]);
+          }
+          out[((size_t)x * H + y) * H + z] = v;
+        }
+  }
+  if (!snapshot.contains("params_binary") || snapshot.at("params_binary").type != mpk::Value::Bin)
+    throw std::runtime_error{"instant-ngp snapshot: params_binary is missing"};
+  m_params = blob_to_floats(snapshot.at("params_binary").str, snapshot.value("params_type", "__half") == "float", "snapshot.params_binary");
+  // what reset_network cannot derive from the reference's own rules
+  static const mpk::Value no_enc = empty_map;
+  const mpk::Value& enc = config.contains("encoding") ? config.at("encoding") : no_enc;
+  if (!(enc.value("per_level_scale", 0.0f) > 0.0f) && enc.value("n_levels", 16u) > 1) {
+    uint32_t base = enc.value("base_resolution", 0u);
+    if (!base) base = 1u << (enc.value("log2_hashmap_size", 15u) / 3);
+    check(nrf_default_per_level_scale((float)aabb_scale, base, enc.value("n_levels", 16u), &m_ngp_per_level_scale), "per_level_scale");
+  }
+  const std::string rgb_act = to_lower(nerf.value("rgb_activation", "Logistic"));
+  m_ngp_rgb_sigmoid = rgb_act == "logistic" || rgb_act == "sigmoid";
+}
+
+// Camera path of a `transforms.json` (NeRF-synthetic / instant-ngp layout): explicit fl_x / fl_y / cx / cy / w / h when
+// present, else camera_angle_x (camera_angle_y) over the given resolution; frames[i].transform_matrix = camera-to-world.
+void load_camera_path(const std::string& transforms_json, int width, int height, std::vector<Camera>& cams, std::vector<Matrix4f>& poses) {
+  std::ifstream f{transforms_json, std::ios::in | std::ios::binary};
+  if (!f) throw std::runtime_error{"Camera path \"" + transforms_json + "\" does not exist."};
+  const std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const mpk::Value t = mpk::JsonReader(text.data(), text.size()).parse();
+  if (t.type != mpk::Value::Map || !t.contains("frames") || t.at("frames").type != mpk::Value::Array)
+    throw std::runtime_error{"transforms.json: no frames"};
+  const double W = width > 0 ? width : t.value("w", 0.0), H = height > 0 ? height : t.value("h", 0.0);
+  if (!(W > 0) || !(H > 0)) throw std::runtime_error{"transforms.json carries no resolution (w, h): pass width and height"};
+  const double sx = W / t.value("w", W), sy = H / t.value("h", H);
+  double fl_x, fl_y;
+  if (t.contains("fl_x")) fl_x = t.value("fl_x", 0.0) * sx;
+  else if (t.contains("camera_angle_x")) fl_x = 0.5 * W / std::tan(0.5 * t.value("camera_angle_x", 0.0));
+  else throw std::runtime_error{"transforms.json: neither fl_x nor camera_angle_x"};
+  if (t.contains("fl_y")) fl_y = t.value("fl_y", 0.0) * sy;
+  else if (t.contains("camera_angle_y")) fl_y = 0.5 * H / std::tan(0.5 * t.value("camera_angle_y", 0.0));
+  else fl_y = fl_x;
+  const double cx = t.contains("cx") ? t.value("cx", 0.0) * sx : 0.5 * W, cy = t.contains("cy") ? t.value("cy", 0.0) * sy : 0.5 * H;
+  cams.clear();
+  poses.clear();
+  for (const mpk::Value& fr : t.at("frames").arr) {
+    if (!fr.contains("transform_matrix")) throw std::runtime_error{"transforms.json: frame without transform_matrix"};
+    const mpk::Value& m = fr.at("transform_matrix");
+    Matrix4f pose;
+    if (m.type == mpk::Value::Array && m.arr.size() >= 3) {
+      for (size_t r = 0; r < m.arr.size() && r < 4; ++r) {
+        if (m.arr[r].type != mpk::Value::NumArray || m.arr[r].nums.size() != 4) throw std::runtime_error{"transforms.json: transform_matrix rows must hold 4 numbers"};
+        for (int c = 0; c < 4; ++c) pose.m[4 * r + c] = m.arr[r].nums[c];
+      }
+    } else if (m.type == mpk::Value::NumArray && m.nums.size() == 16) {
+      for (int i = 0; i < 16; ++i) pose.m[i] = m.nums[i];
+    } else {
+      throw std::runtime_error{"transforms.json: transform_matrix must be 4x4"};
+    }
+    poses.push_back(pose);
+    cams.push_back(Camera{(float)fl_x, (float)fl_y, (float)cx, (float)cy});
+  }
+}
+
 void NerfRender::reset_network() {
   if (!m_have_snapshot) throw std::runtime_error{"reset_network: no snapshot loaded"};
   const mpk::Value& config = m_network_config;
@@ -222,6 +401,7 @@ void NerfRender::reset_network() {
   if (!base) base = 1u << (d.log2_hashmap_size / 3);
   d.base_resolution = base;
   float pls = enc.value("per_level_scale", 0.0f);
+  if (pls <= 0.0f && m_ngp_per_level_scale > 0.0f) pls = m_ngp_per_level_scale;  // instant-ngp snapshot: derived from aabb_scale
   if (pls <= 0.0f && d.n_levels > 1) check(nrf_default_per_level_scale(d.bound, base, d.n_levels, &pls), "per_level_scale");
   if (pls <= 0.0f) pls = 2.0f;
   d.per_level_scale = pls;
@@ -237,6 +417,7 @@ void NerfRender::reset_network() {
   mlp(net, n1, d.density_hidden_layers, d.density_activation, d.density_output_activation);
   mlp(rgb, n2, d.rgb_hidden_layers, d.rgb_activation, d.rgb_output_activation);
   if (n1 != n2) throw std::runtime_error{"density and rgb networks must share n_neurons"};
+  if (m_ngp_rgb_sigmoid && d.rgb_output_activation == NRF_ACT_NONE) d.rgb_output_activation = NRF_ACT_SIGMOID;  // instant-ngp's logistic
   d.n_neurons = n1;
   d.density_n_output = net.value("n_output_dims", 16u);                // nerf_network.h:120-122
   d.sigma_activation = activation(net, "sigma_activation", "Exponential");  // nerf_network.h:125

@@ -66,6 +66,8 @@ class NerfRender {
   // the density grid from the network (nerf_render.cu:388-429, dead and incomplete in the reference; completed in
   // nrf_generate_density_grid); reload_network_from_file calls it for a snapshot that carries no density grid
   void generate_density_grid();
+  // Reads the reference's snapshot format (nerf_render.cu:431-473) and, in addition, instant-ngp's own layout
+  // (`snapshot.nerf`, `params_binary`, Morton-ordered `density_grid_binary`: see nerf_render.cpp load_ngp_snapshot).
   void load_snapshot(const std::string& filepath_string);
 
   // additions (the reference has no accessors)
@@ -77,6 +79,9 @@ class NerfRender {
 
  private:
   void check(int rc, const char* what) const;
+  void load_ngp_snapshot(const mpk::Value& config);
+  float m_ngp_per_level_scale = 0.0f;  // instant-ngp snapshots: per_level_scale derived from aabb_scale (0: not one)
+  bool m_ngp_rgb_sigmoid = false;      //   ... and instant-ngp's logistic colour activation
   nrf_group* m_group = nullptr;
   std::vector<nrf_context*> m_ctx;  // the group's members (owned by the group)
   mpk::Value m_network_config;
@@ -89,5 +94,8 @@ class NerfRender {
   std::vector<unsigned char> m_batch_image, m_batch_depth;  // render_frames
   std::vector<float> m_rays_o, m_rays_d;
 };
+
+// Camera path from a NeRF-synthetic / instant-ngp `transforms.json` (intrinsics scaled to width x height; 0 = the file's w / h)
+void load_camera_path(const std::string& transforms_json, int width, int height, std::vector<Camera>& cams, std::vector<Matrix4f>& poses);
 
 }  // namespace ngp

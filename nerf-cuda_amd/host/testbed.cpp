@@ -1,7 +1,10 @@
 // testbed.cpp -- mirror of the reference's `testbed` main (src/main.cu:131-206) without the
 // GLFW/Vulkan/DLSS presentation part: load a snapshot, render ONE frame with the hard-coded camera
 // and pose, print "Process time", write image.png / deep.png.
-//   usage: testbed [snapshot.msgpack] [width height] [out_prefix]
+//   usage: testbed [snapshot.msgpack] [width height] [out_prefix] [transforms.json]
+// With a transforms.json (NeRF-synthetic / instant-ngp camera path) every frame of the path is rendered as well, in
+// batches of NRF_MAX_VIEWS views per launch, and written to <out_prefix>path_NNNN.rgb.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +61,26 @@ int main(int argc, char** argv) {
     }
     FILE* f = std::fopen((prefix + "image.rgb").c_str(), "wb");  // raw copy for the parity test
     if (f) { std::fwrite(img.rgb, 1, (size_t)img.W * img.H * 3, f); std::fclose(f); }
+    if (argc > 5) {
+      std::vector<Camera> cams;
+      std::vector<Matrix4f> poses;
+      load_camera_path(argv[5], W, H, cams, poses);
+      const auto p0 = std::chrono::steady_clock::now();
+      size_t done = 0;
+      for (size_t first = 0; first < cams.size(); first += NRF_MAX_VIEWS) {
+        const size_t n = std::min(cams.size() - first, (size_t)NRF_MAX_VIEWS);
+        const std::vector<Image> imgs = render->render_frames(std::vector<Camera>(cams.begin() + first, cams.begin() + first + n),
+                                                              std::vector<Matrix4f>(poses.begin() + first, poses.begin() + first + n));
+        for (size_t i = 0; i < n; ++i, ++done) {
+          char name[64];
+          std::snprintf(name, sizeof(name), "path_%04zu.rgb", first + i);
+          FILE* pf = std::fopen((prefix + name).c_str(), "wb");
+          if (pf) { std::fwrite(imgs[i].rgb, 1, (size_t)W * H * 3, pf); std::fclose(pf); }
+        }
+      }
+      const auto p1 = std::chrono::steady_clock::now();
+      std::printf("camera path: %zu frames, %f s / frame\n", done, std::chrono::duration<double>(p1 - p0).count() / (double)(done ? done : 1));
+    }
     delete render;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -253,11 +253,110 @@ def default_per_level_scale(bound: float, base_resolution: int, n_levels: int) -
     return float(out.value)
 
 
+# --------------------------------------------------------------------------
+# instant-ngp snapshots (the reference itself only reads its own array form, nerf_render.cu:441-453)
+# --------------------------------------------------------------------------
+# Layout, from instant-ngp's public Testbed::save_snapshot / load_snapshot and NerfNetwork (the reference's
+# nerf_network.h is derived from the latter, so the parameter order -- density MLP | rgb MLP | hash grid -- and the
+# row-major [out][in] matrices are the same):
+#   snapshot.params_binary      raw little-endian blob of snapshot.params_type ("__half" | "float"), snapshot.n_params values
+#   snapshot.density_grid_size  128
+#   snapshot.density_grid_binary  (K+1) * 128^3 values ("__half", or "float" in the first format revision -- told apart
+#                               by the blob's size), K = log2(aabb_scale); value of cell (x, y, z) of cascade c at
+#                               c * 128^3 + morton3D(x, y, z); cascade c is the cube of side 2^c around (0.5, 0.5, 0.5)
+#   snapshot.nerf.aabb_scale    (also snapshot.nerf.dataset.aabb_scale); snapshot.nerf.dataset.scale / .offset = 0.33 / 0.5
+#   snapshot.aabb               {"min": [3], "max": [3]} in instant-ngp's unit-cube coordinates
+# Mapping onto the reference's conventions (torch-ngp's, which it restates): coordinates x_ref = x_ngp - 0.5,
+# bound = aabb_scale / 2 (so x_ref / (2 bound) + 0.5 is instant-ngp's position inside its aabb); the reference's cascade k
+# is the cube +-min(2^k, bound), i.e. instant-ngp's cascade k + 1 (cascade 0 for aabb_scale 1), each cell taking the
+# maximum of its own value and of its eight children in the next finer instant-ngp cascade (instant-ngp's own bitfield
+# is max-pooled that way); mean_density = mean(max(v, 0)) over instant-ngp's cascade 0, as instant-ngp computes it;
+# per_level_scale, when the file leaves it out, is instant-ngp's exp(log(2048 aabb_scale / N_min) / (L - 1)); and
+# the colour activation instant-ngp applies outside its network (logistic) becomes rgb_network.output_activation.
+def morton3d(x, y, z):
+    """x | y << 1 | z << 2 bit-interleaved (instant-ngp's morton3D; the reference carries the same helper, render_utils.h:157-170)."""
+    def expand(v):
+        v = (v * 0x00010001) & 0xFF0000FF
+        v = (v * 0x00000101) & 0x0F00F00F
+        v = (v * 0x00000011) & 0xC30C30C3
+        v = (v * 0x00000005) & 0x49249249
+        return v
+    x, y, z = (np.asarray(a, np.uint64) for a in (x, y, z))
+    return (expand(x) | (expand(y) << np.uint64(1)) | (expand(z) << np.uint64(2))).astype(np.uint32)
+
+
+def is_ngp_snapshot(config: dict) -> bool:
+    snap = config.get("snapshot", {})
+    return isinstance(snap, dict) and ("nerf" in snap or isinstance(snap.get("aabb"), dict))
+
+
+def ngp_snapshot_to_reference(config: dict) -> dict:
+    """An instant-ngp snapshot dict -> the same model as a snapshot dict in the reference's own format."""
+    snap = config["snapshot"]
+    nerf = snap.get("nerf", {})
+    dataset = nerf.get("dataset", {})
+    aabb_scale = int(nerf.get("aabb_scale", dataset.get("aabb_scale", 1)))
+    if aabb_scale < 1 or aabb_scale & (aabb_scale - 1):
+        raise RuntimeError("instant-ngp snapshot: aabb_scale must be a power of two")
+    offset = dataset.get("offset", [0.5, 0.5, 0.5])
+    if any(abs(float(v) - 0.5) > 1e-6 for v in offset):
+        raise NotImplementedError("instant-ngp snapshot: dataset.offset other than 0.5 has no counterpart in the reference")
+    H = int(snap.get("density_grid_size", 128))
+    if H & (H - 1):
+        raise RuntimeError("instant-ngp snapshot: density_grid_size must be a power of two (Morton order)")
+    n_ngp = aabb_scale.bit_length()  # K + 1 cascades
+    blob = snap["density_grid_binary"]
+    cells = n_ngp * H ** 3
+    kind = snap.get("density_grid_type")
+    if kind is None:
+        kind = "float" if len(blob) == 4 * cells else "__half"
+    grid = np.frombuffer(blob, np.float32 if kind == "float" else np.float16).astype(np.float32)
+    if grid.size < cells:
+        raise RuntimeError("Incompatible number of grid cascades.")
+    grid = grid[:cells].reshape(n_ngp, H ** 3)
+    ax = np.arange(H, dtype=np.uint32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    m = morton3d(X, Y, Z).reshape(-1)
+    xmajor = grid[:, m].reshape(n_ngp, H, H, H)  # [cascade][x][y][z]
+    bound = aabb_scale / 2.0
+    C = 1 if aabb_scale == 1 else n_ngp - 1
+    out = np.empty((C, H, H, H), np.float32)
+    for k in range(C):
+        c = 0 if aabb_scale == 1 else k + 1
+        own = xmajor[c].copy()
+        if c > 0:  # the inner half of cascade c is covered twice as finely by cascade c - 1
+            fine = xmajor[c - 1].reshape(H // 2, 2, H // 2, 2, H // 2, 2).max(axis=(1, 3, 5))
+            q = H // 4
+            inner = own[q:q + H // 2, q:q + H // 2, q:q + H // 2]
+            np.maximum(inner, fine, out=inner)
+        out[k] = own
+    lo, hi = snap.get("aabb", {}).get("min"), snap.get("aabb", {}).get("max")
+    if lo is None or hi is None:
+        lo, hi = [0.5 - bound] * 3, [0.5 + bound] * 3
+    ref = {k: (dict(v) if isinstance(v, dict) else v) for k, v in config.items() if k != "snapshot"}
+    enc = ref.setdefault("encoding", {})
+    if not float(enc.get("per_level_scale", 0.0)) > 0.0 and int(enc.get("n_levels", 16)) > 1:
+        base = int(enc.get("base_resolution", 0)) or (1 << (int(enc.get("log2_hashmap_size", 15)) // 3))
+        enc["per_level_scale"] = default_per_level_scale(float(aabb_scale), base, int(enc.get("n_levels", 16)))
+    rgb = ref.setdefault("rgb_network", {})
+    if str(rgb.get("output_activation", "None")).lower() == "none":
+        rgb["output_activation"] = "Sigmoid" if str(nerf.get("rgb_activation", "Logistic")).lower() in ("logistic", "sigmoid") else "None"
+    new = {"aabb": [float(v) - 0.5 for v in lo] + [float(v) - 0.5 for v in hi], "bound": float(bound),
+           "scale": float(dataset.get("scale", 0.33)), "cascade": int(C), "density_grid_size": H,
+           "mean_density": float(np.maximum(xmajor[0], 0.0).mean(dtype=np.float64)),
+           "density_grid_binary": out.reshape(-1).tobytes(), "density_grid_type": "float",
+           "params_binary": snap["params_binary"], "params_type": snap.get("params_type", "__half")}
+    ref["snapshot"] = new
+    return ref
+
+
 def desc_from_config(config: dict, params: np.ndarray | None = None, density_grid: np.ndarray | None = None):
     """Build a nrf_model_desc from a snapshot dict in the reference's format
-    (SURVEY.md Appendix B).  Returns (desc, keepalive)."""
+     -- or in instant-ngp's, which is converted first.  Returns (desc, keepalive)."""
     if "snapshot" not in config:
         raise RuntimeError("File does not contain a snapshot.")  # nerf_render.cu:434-436
+    if is_ngp_snapshot(config):
+        config = ngp_snapshot_to_reference(config)
     snap = config["snapshot"]
     enc = dict(config.get("encoding", {}))
     net = dict(config.get("network", {}))

@@ -281,3 +281,83 @@ def read_snapshot(path):
 
     with open(path, "rb") as f:
         return msgpack.unpackb(f.read(), raw=False)
+
+
+def write_ngp_snapshot(path, config, params, density_grid, aabb_scale, grid_dtype="__half"):
+    """The same model in instant-ngp's snapshot layout (nerfhip.py "instant-ngp snapshots"): `density_grid` is the
+    reference's x-major float grid [C][H][H][H] with bound = aabb_scale / 2; it becomes instant-ngp's cascades 1..K
+    (cascade 0 for aabb_scale 1) in Morton order, cascade 0 is left empty, `per_level_scale` is left to the loader
+    and the aabb is written in unit-cube coordinates."""
+    import msgpack
+
+    from nerfhip import morton3d
+
+    snap_in = config["snapshot"]
+    H = int(snap_in["density_grid_size"])
+    C = int(snap_in["cascade"])
+    bound = aabb_scale / 2.0
+    assert float(snap_in["bound"]) == bound and C == (1 if aabb_scale == 1 else aabb_scale.bit_length() - 1)
+    g = np.asarray(density_grid, np.float32).reshape(C, H, H, H)
+    ax = np.arange(H, dtype=np.uint32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    m = morton3d(X, Y, Z).reshape(-1)
+    n_ngp = aabb_scale.bit_length()
+    out = np.zeros((n_ngp, H ** 3), np.float32)
+    for k in range(C):
+        out[0 if aabb_scale == 1 else k + 1, m] = g[k].reshape(-1)
+    dt = np.float16 if grid_dtype == "__half" else np.float32
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in config.items() if k != "snapshot"}
+    cfg["encoding"].pop("per_level_scale", None)
+    aabb = [float(v) + 0.5 for v in snap_in["aabb"]]
+    cfg["snapshot"] = {
+        "version": 1, "n_params": int(np.asarray(params).size), "params_type": "__half",
+        "params_binary": np.asarray(params, np.float32).astype(np.float16).tobytes(),
+        "density_grid_size": H, "density_grid_binary": out.astype(dt).tobytes(),
+        "aabb": {"min": aabb[:3], "max": aabb[3:]},
+        "nerf": {"aabb_scale": int(aabb_scale), "rgb_activation": "None",
+                 "dataset": {"aabb_scale": int(aabb_scale), "scale": float(snap_in.get("scale", 0.33)), "offset": [0.5, 0.5, 0.5]}},
+    }
+    with open(path, "wb") as f:
+        f.write(msgpack.packb(cfg, use_single_float=True, use_bin_type=True))
+
+
+def write_transforms_json(path, poses, width, height, camera_angle_x=0.6911112070083618):
+    """A camera path in the NeRF-synthetic / instant-ngp `transforms.json` layout."""
+    import json
+
+    frames = [{"file_path": f"./frame_{i:04d}", "transform_matrix": np.asarray(p, np.float64).reshape(4, 4).tolist()}
+              for i, p in enumerate(poses)]
+    with open(path, "w") as f:
+        json.dump({"camera_angle_x": camera_angle_x, "w": int(width), "h": int(height), "frames": frames}, f)
+
+
+def load_transforms_json(path, width=None, height=None):
+    """`transforms.json` -> (cams [n][4] = fl_x, fl_y, cx, cy; poses [n][4][4]; width, height).  Intrinsics: explicit
+    fl_x / fl_y / cx / cy / w / h when present, else from camera_angle_x (camera_angle_y) over the given resolution."""
+    import json
+
+    with open(path) as f:
+        t = json.load(f)
+    W = int(width or t.get("w", 0))
+    H = int(height or t.get("h", 0))
+    if W <= 0 or H <= 0:
+        raise RuntimeError("transforms.json carries no resolution (w, h): pass width and height")
+    sx = W / float(t.get("w", W))
+    sy = H / float(t.get("h", H))
+    if "fl_x" in t:
+        fl_x = float(t["fl_x"]) * sx
+    elif "camera_angle_x" in t:
+        fl_x = 0.5 * W / math.tan(0.5 * float(t["camera_angle_x"]))
+    else:
+        raise RuntimeError("transforms.json: neither fl_x nor camera_angle_x")
+    if "fl_y" in t:
+        fl_y = float(t["fl_y"]) * sy
+    elif "camera_angle_y" in t:
+        fl_y = 0.5 * H / math.tan(0.5 * float(t["camera_angle_y"]))
+    else:
+        fl_y = fl_x
+    cx = float(t["cx"]) * sx if "cx" in t else 0.5 * W
+    cy = float(t["cy"]) * sy if "cy" in t else 0.5 * H
+    poses = np.stack([np.asarray(fr["transform_matrix"], np.float32).reshape(4, 4) for fr in t["frames"]])
+    cams = np.tile(np.array([fl_x, fl_y, cx, cy], np.float32), (len(poses), 1))
+    return cams, poses, W, H
