@@ -625,6 +625,10 @@ __device__ __forceinline__ half8_t frag_load(const uint4* wl, int f, int lane) {
 // ReLU commutes with the (monotonic, sign-preserving) rounding to fp16, so it is applied
 // to the packed halves: one v_pk_max_f16 per two values instead of two v_max_f32 per value.
 __device__ __forceinline__ half8_t pack_acc(float4_t lo, float4_t hi) {
+#ifdef NRF_PROBE_NO_PACK  // scripts/mlp_probe only: the MFMA chain with NO re-packing work (wrong values, same dependencies)
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(half8_t, __builtin_bit_cast(u4, lo) ^ __builtin_bit_cast(u4, hi));  // 4 full-rate VALU instead of 8 half-rate
+#endif
   half8_t r;
   r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
   r[4] = (half_t)hi[0]; r[5] = (half_t)hi[1]; r[6] = (half_t)hi[2]; r[7] = (half_t)hi[3];
@@ -635,16 +639,32 @@ __device__ __forceinline__ half8_t pack_acc(float4_t lo, float4_t hi) {
 // feat[n]  : B fragment of the density MLP input  (hash features 8g..8g+7 of sample c, tile n)
 // dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
 // out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
-template <int NT, int D0_BASE = FRAG_D0>
-__device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8_t (&feat)[NT], const half4_t (&dirf)[NT],
-                                          float4_t (&out)[NT]) {
+// frag(f) returns weight fragment f (FRAG_*) of this lane: from LDS (LdsFrags) or from registers.
+struct LdsFrags {
+  const uint4* wl;
+  int lane;
+  __device__ __forceinline__ half8_t operator()(int f) const { return frag_load(wl, f, lane); }
+};
+// Outputs of mlp_tiles for NT tiles of 16 samples (fp16 values, as the reference's network_output holds them):
+//   rg[n], bx[n]  packed halves (r, g) and (b, row 3 of the rgb output) of sample c of tile n -- valid in lanes g == 0
+//   sigma         extract_density's activation of density row 0 (nerf_network.h:49-61), for sample c of tile g --
+//                 valid in lanes g < NT: the sixteen density values of every tile are first moved into lane row g
+//                 (v_permlane16_swap), so that ONE expf sequence serves all tiles of the pass
+template <int NT>
+struct MlpOut {
+  uint32_t rg[NT], bx[NT];
+  half_t sigma;
+};
+template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags>
+__device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out) {
+  static_assert(NT == 1 || NT == 2 || NT == 4, "tiles per pass");
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
   float4_t acc[NT][4];
   half8_t hb[NT][2];
   // ---- density layer 0: 32 -> 64
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const half8_t a = frag_load(wl, D0_BASE + m, lane);
+    const half8_t a = frag(D0_BASE + m);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, feat[n], zero);
   }
@@ -659,13 +679,13 @@ __device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8
   for (int n = 0; n < NT; ++n) dacc[n] = zero;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const half8_t a = frag_load(wl, FRAG_D1 + s, lane);
+    const half8_t a = frag(FRAG_D1 + s);
 #pragma unroll
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
   }
   // density output (fp16), rows 4g..4g+3; rgb input = [density out | dir encoding]
   half8_t rin[NT];
-  float sig_pre[NT];
+  uint32_t d01[NT];  // packed halves of density rows 4g, 4g + 1 (row 0 = the density itself lives in lanes g == 0)
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     half8_t r;
@@ -678,12 +698,24 @@ __device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8
     r[6] = dirf[n][2];
     r[7] = dirf[n][3];
     rin[n] = r;
-    sig_pre[n] = (float)r[0];  // density row 0 lives in lanes g == 0
+    half2_t lo;
+    lo.x = r[0]; lo.y = r[1];
+    d01[n] = h2_bits(lo);
   }
+  // tile n's lane row 0 -> lane row n of one register (v_permlane16_swap: odd rows of the first operand <-> even rows
+  // of the second; v_permlane32_swap: upper half of the first <-> lower half of the second)
+  uint32_t dall = d01[0];
+  if constexpr (NT >= 2) dall = __builtin_amdgcn_permlane16_swap(d01[0], d01[1], false, false)[0];
+  if constexpr (NT == 4) {
+    const uint32_t hi = __builtin_amdgcn_permlane16_swap(d01[2], d01[3], false, false)[0];
+    dall = __builtin_amdgcn_permlane32_swap(dall, hi, false, false)[0];
+  }
+  // extract_density: fp32 activation (Exponential) of the fp16 density output, stored as fp16
+  out.sigma = (half_t)expf((float)bits_h2(dall).x);
   // ---- rgb layer 0: 32 -> 64
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const half8_t a = frag_load(wl, FRAG_R0 + m, lane);
+    const half8_t a = frag(FRAG_R0 + m);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, rin[n], zero);
   }
@@ -699,7 +731,7 @@ __device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8
     for (int n = 0; n < NT; ++n) acc[n][m] = zero;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const half8_t a = frag_load(wl, FRAG_R1 + 2 * m + s, lane);
+      const half8_t a = frag(FRAG_R1 + 2 * m + s);
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, hb[n][s], acc[n][m]);
     }
@@ -714,20 +746,14 @@ __device__ __forceinline__ void mlp_tiles(const uint4* wl, int lane, const half8
   for (int n = 0; n < NT; ++n) dacc[n] = zero;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const half8_t a = frag_load(wl, FRAG_R2 + s, lane);
+    const half8_t a = frag(FRAG_R2 + s);
 #pragma unroll
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
   }
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    // network_output rows 0..2 (fp16) and extract_density row 3 (nerf_network.h:49-61):
-    // fp32 activation (Exponential) of the fp16 density output, stored as fp16.
-    float4_t o;
-    o[0] = (float)(half_t)dacc[n][0];
-    o[1] = (float)(half_t)dacc[n][1];
-    o[2] = (float)(half_t)dacc[n][2];
-    o[3] = (float)(half_t)expf(sig_pre[n]);
-    out[n] = o;
+  for (int n = 0; n < NT; ++n) {  // network_output rows 0..2 (fp16)
+    out.rg[n] = pack_h2(dacc[n][0], dacc[n][1]);
+    out.bx[n] = pack_h2(dacc[n][2], dacc[n][3]);
   }
 }
 

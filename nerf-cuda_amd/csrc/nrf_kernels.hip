@@ -119,16 +119,21 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     feat[n] = __builtin_bit_cast(half8_t, fv);
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
-  float4_t o[NT];
-  mlp_tiles<NT>(wl, lane, feat, dirf, o);
-  if (g == 0) {
+  MlpOut<NT> o;
+  mlp_tiles<NT>(LdsFrags{wl, lane}, feat, dirf, o);
+  if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int slot = base + 16 * n + c;
-      float sigma = o[n][3];
-      if (density_scale != 1.0f) sigma = density_scale * sigma;  // R/src/nerf_render.cu:328 (float multiply)
-      if (slot < S) W->out[slot] = make_float4(o[n][0], o[n][1], o[n][2], sigma);
+      const half2_t rg = bits_h2(o.rg[n]), bx = bits_h2(o.bx[n]);
+      if (slot < S) *reinterpret_cast<float3*>(&W->out[slot]) = make_float3((float)rg.x, (float)rg.y, (float)bx.x);
     }
+  }
+  if (g < NT) {  // lane row g holds the densities of tile g
+    const int slot = base + 16 * g + c;
+    float sigma = (float)o.sigma;
+    if (density_scale != 1.0f) sigma = density_scale * sigma;  // R/src/nerf_render.cu:328 (float multiply)
+    if (slot < S) W->out[slot].w = sigma;
   }
 }
 
@@ -629,18 +634,20 @@ __global__ __launch_bounds__(256) void gen_encode_dir_kernel(const DevModel M, c
 // of its direction row (the natural-K-order copy of the first weight matrix makes that the B fragment),
 // a wave reads 1 KiB + 512 B contiguous per 16-sample tile, and the next chunk's rows are in flight
 // while the current one goes through the 80 MFMAs.
-constexpr int LDS_WFRAG_ALL_BYTES = N_FRAGS_ALL * 64 * 16;  // 24576
 constexpr int MLP_TILES = 2;  // 16-sample tiles per trip
+struct RegFrags {  // the lane's weight fragments, held in registers for the kernel's life (80 VGPRs)
+  const half8_t* w;
+  __device__ __forceinline__ half8_t operator()(int f) const { return w[f]; }
+};
 template <bool REPEAT>
 __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
-                                                          uint2* __restrict__ out, uint32_t repeat) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* wl = reinterpret_cast<uint4*>(smem);
-  for (int i = threadIdx.x; i < N_FRAGS_ALL * 64; i += blockDim.x) wl[i] = M.wfrag[i];
-  __syncthreads();
+                                                          half_t* __restrict__ out, uint32_t repeat) {
   constexpr int T = MLP_TILES, CH = 16 * T;
   const int lane = lane_id(), g = lane >> 4, c = lane & 15;
+  half8_t wreg[N_FRAGS_ALL];
+#pragma unroll
+  for (int f = 0; f < N_FRAGS_ALL; ++f) wreg[f] = __builtin_bit_cast(half8_t, M.wfrag[f * 64 + lane]);
   const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t n_chunks = (n + CH - 1) / CH;
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
       f[t] = __builtin_bit_cast(half8_t, fv[t]);
       df[t] = __builtin_bit_cast(half4_t, dv[t]);
     }
-    float4_t o[T];
+    MlpOut<T> o;
     // REPEAT (nrf_mlp_forward_repeat): the same rows `repeat` times from registers -- the rate of the MFMA chain
     // with its re-packing, without the HBM stream; the empty asm keeps the evaluations from being merged
     for (uint32_t r = 0; r < (REPEAT ? repeat : 1u); ++r) {
@@ -680,14 +687,21 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
           df[t] = __builtin_bit_cast(half4_t, dv[t]);
         }
       }
-      mlp_tiles<T, FRAG_D0_NATURAL>(wl, lane, f, df, o);
+      mlp_tiles<T, FRAG_D0_NATURAL>(RegFrags{wreg}, f, df, o);
     }
-    if (g == 0) {
+    if (g == 0) {  // (r, g, b): six bytes of the sample's eight
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t s = chunk * CH + 16u * t + c;
-        if (s < n) out[s] = make_uint2(pack_h2(o[t][0], o[t][1]), pack_h2(o[t][2], o[t][3]));
+        if (s < n) {
+          *reinterpret_cast<uint32_t*>(out + 4 * (size_t)s) = o.rg[t];
+          out[4 * (size_t)s + 2] = bits_h2(o.bx[t]).x;
+        }
       }
+    }
+    if (g < T) {  // sigma of tile g lives in lane row g
+      const uint32_t s = chunk * CH + 16u * g + c;
+      if (s < n) out[4 * (size_t)s + 3] = o.sigma;
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -1039,8 +1053,8 @@ hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* d
   }
   const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
 #define NRF_LAUNCH_MLP(R)                                                                                                \
-  hipLaunchKernelGGL((mlp_forward_kernel<R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), LDS_WFRAG_ALL_BYTES, st, M, \
-                     (const uint4*)feat, (const uint2*)dirfeat, n, (uint2*)out, repeat)
+  hipLaunchKernelGGL((mlp_forward_kernel<R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), 0, st, M,                  \
+                     (const uint4*)feat, (const uint2*)dirfeat, n, (half_t*)out, repeat)
   if (repeat > 1) NRF_LAUNCH_MLP(true); else NRF_LAUNCH_MLP(false);
 #undef NRF_LAUNCH_MLP
   return hipGetLastError();
