@@ -19,6 +19,11 @@ pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_W
 pass sq2 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pass grbm GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 pass sq3 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
+# VALU instruction classes: fp32 add / mul / fma and plain int32 issue in 2 cycles per wave64 instruction on gfx950,
+# conversions, packed fp16 and v_fma_mix in 4, transcendentals in 8 (scripts/issue_rate) -- the cycle-weighted VALU load
+pass sq4 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 || true
+pass sq5 SQ_INSTS_VALU_ADD_F16 SQ_INSTS_VALU_MUL_F16 SQ_INSTS_VALU_FMA_F16 SQ_INSTS_VALU_TRANS_F16 || true
+pass sq6 SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_IOPS || true
 # TA / TCP blocks take two counters per pass (more: "exceeds the capabilities of the hardware", and rocprofv3 hangs)
 pass ta1 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum || true
 pass ta2 TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum || true
