@@ -658,6 +658,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     const bool uses_hash = Lv.hashed && Lv.size < stride;
     if (uses_hash && (Lv.size & (Lv.size - 1)) == 0) Lv.mode = LV_HASH_POW2;
     else if (!uses_hash && dims == 3 && Lv.res >= 2 && (uint64_t)Lv.res * Lv.res * Lv.res <= Lv.size) Lv.mode = LV_DENSE;
+    else if (!uses_hash && Lv.res == 65536u && (Lv.size & (Lv.size - 1)) == 0 && Lv.size >= 65536u)
+      Lv.mode = LV_XY_POW2;  // the uint32 stride wrapped to 0 after the y term: (x + y * 65536) & (size - 1), see nrf_device.h
     else Lv.mode = LV_GENERIC;
     generic_grid = generic_grid || Lv.mode == LV_GENERIC;
   }
@@ -665,7 +667,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   const bool generic = generic_grid || F != 2 || L != 16 || Wn != 64 || d->density_hidden_layers != 1 || d->rgb_hidden_layers != 2 ||
                        dir_w != 16 || d->interpolation != NRF_INTERP_LINEAR ||
                        !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
-                         d->density_output_activation == NRF_ACT_NONE && d->rgb_output_activation == NRF_ACT_NONE &&
+                         d->density_output_activation == NRF_ACT_NONE &&
+                         (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                          d->sigma_activation == NRF_ACT_EXPONENTIAL);
   std::vector<_Float16> frags;
   GenModel G;
@@ -699,7 +702,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   grid16.reserve(n_grid + (size_t)F * (16 * 4096 + ((size_t)1 << d->log2_hashmap_size)));
   for (uint32_t l = 0; l < L; ++l) {
     LevelParams& Lv = lp[l];
-    if (Lv.mode == LV_HASH_POW2)  // aligned to its own (power-of-two) size: `hash & mask | offset` (level_gather, UNI == 2)
+    if (Lv.mode == LV_HASH_POW2 || Lv.mode == LV_XY_POW2)  // aligned to its own (power-of-two) size: `index & mask | offset` (level_gather)
       while ((grid16.size() / F) % Lv.size != 0) grid16.push_back((_Float16)0.0f);
     Lv.offset = (uint32_t)(grid16.size() / F);
     const float* src = gp + (size_t)lv.offset[l] * F;
@@ -723,8 +726,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     const bool hashed_pow2 = L.mode == LV_HASH_POW2;
     L.off_b = L.offset << 2;
     L.my_b = hashed_pow2 ? (2654435761u << 2) : (L.res << 2);
-    L.mz_b = hashed_pow2 ? (805459861u << 2) : ((L.res * L.res) << 2);
-    L.mask_b = hashed_pow2 ? ((L.size - 1) << 2) : 0xffffffffu;
+    L.mz_b = hashed_pow2 ? (805459861u << 2) : ((L.res * L.res) << 2);  // LV_XY_POW2: res * res == 0 in uint32, as in grid_index
+    L.mask_b = (hashed_pow2 || L.mode == LV_XY_POW2) ? ((L.size - 1) << 2) : 0xffffffffu;
   }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));

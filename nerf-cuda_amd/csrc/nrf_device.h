@@ -34,7 +34,10 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 enum : uint32_t {
   LV_DENSE = 0,    // x + y*res + z*res^2, then one conditional subtract (index < 2*size always)
   LV_HASH_POW2 = 1,  // fast_hash & (size-1)
-  LV_GENERIC = 2   // literal restatement with integer modulo (tiled grids, non-pow2 hash sizes)
+  LV_GENERIC = 2,  // literal restatement with integer modulo (tiled grids, non-pow2 hash sizes)
+  LV_XY_POW2 = 3   // res == 2^16 on a power-of-two table: grid_index's uint32 stride (grid.h:106-109) wraps to 0 after
+                   // the y term, so `hashmap_size < stride` is false and the level is (x + y * res) & (size - 1), no hash,
+                   // no z.  instant-ngp's geometry reaches it: 2048 * aabb_scale = 65536 at aabb_scale 32.
 };
 
 struct LevelParams {
@@ -93,8 +96,9 @@ struct DevModel {
   uint32_t uni_modes;    // 2 bits per unrolled step jl = 0..3 of the fused kernel (levels 4*jl + g): 0 mixed, 1 all dense,
                          // 2 all power-of-two hashed (host: nrf_load_model)
   uint32_t generic;      // 0: the shape of the reference's base.json (L = 16, F = 2, 64 neurons, 1 + 2 hidden layers, a
-                         // 16-wide direction encoding, hidden ReLU / outputs None / sigma Exponential, linear interpolation,
-                         // every level dense or power-of-two hashed): the register-resident instance (this file);
+                         // 16-wide direction encoding, hidden ReLU / density output None / sigma Exponential / rgb output
+                         // None or Sigmoid, linear interpolation, every level dense, power-of-two hashed or LV_XY_POW2):
+                         // the register-resident instance (this file);
                          // 1: everything else: the generic instance (nrf_generic.h), described by `gen`
   const struct GenModel* gen;  // device memory; nullptr unless generic
   uint32_t gen_wave_bytes;     // generic instance: LDS bytes per wave of the direction rows + activation rows
@@ -496,15 +500,17 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
 #pragma unroll
       for (int c = 0; c < 8; ++c) off[c] = ax[c & 1] + ay[(c >> 1) & 1] + az[(c >> 2) & 1];
     } else {
-      // lanes of one instruction mix dense and hashed levels: both 2-term forms, one v_cndmask per corner
-      // (ax already carries the level offset for dense lanes; hashed levels are aligned, see above)
-      const uint32_t am[2] = {(ax[0] & mask) | level_off, (ax[1] & mask) | level_off};
+      // lanes of one instruction mix dense and hashed levels: both 2-term forms, one v_cndmask per corner.
+      // The additive form is masked as well: dense levels carry mask = ~0, an LV_XY_POW2 level its (size - 1) << 2
+      // with mz_b = 0 (nrf_load_model); the level offset is added last (hashed / XY levels are aligned, see above)
+      const uint32_t axr[2] = {gx << 2, (gx << 2) + 4u};
+      const uint32_t am[2] = {(axr[0] & mask) | level_off, (axr[1] & mask) | level_off};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t b = ay[q & 1], d = az[q >> 1];
         const uint32_t bd_x = (b ^ d) & mask, bd_s = b + d;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) off[2 * q + e] = hashed ? (am[e] ^ bd_x) : (ax[e] + bd_s);
+        for (int e = 0; e < 2; ++e) off[2 * q + e] = hashed ? (am[e] ^ bd_x) : (((axr[e] + bd_s) & mask) + level_off);
       }
     }
   }
@@ -655,8 +661,12 @@ struct MlpOut {
   uint32_t rg[NT], bx[NT];
   half_t sigma;
 };
+// rgb_sigmoid (wave-uniform): the rgb MLP's output activation is Sigmoid instead of None -- tcnn's logistic
+// 1 / (1 + expf(-x)) on the fp32 sums (common_device.h:84-88), which is how instant-ngp's colour activation reaches
+// this network when one of its snapshots is loaded (nerfhip.py "instant-ngp snapshots").
 template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags>
-__device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out) {
+__device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
+                                          bool rgb_sigmoid = false) {
   static_assert(NT == 1 || NT == 2 || NT == 4, "tiles per pass");
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
   float4_t acc[NT][4];
@@ -749,6 +759,12 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
     const half8_t a = frag(FRAG_R2 + s);
 #pragma unroll
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
+  }
+  if (rgb_sigmoid) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dacc[n][r] = 1.0f / (1.0f + expf(-dacc[n][r]));
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {  // network_output rows 0..2 (fp16)

@@ -17,7 +17,8 @@
 //   with A = weight fragments streamed from global memory / L2 (they are the same for every wave of the chip) and
 //   B = one ds_read_b128 per lane from the activation rows; X and Y swap roles from layer to layer.  The first rgb
 //   layer reads its input columns from two places: columns 0..15 = the density MLP's output, the rest = the
-//   ray's direction encoding, computed once per ray into the wave's LDS.
+//   sample's direction encoding, evaluated per pass from the ray's direction into 32 LDS rows (a per-ray buffer
+//   of the widest encodings -- 64 rays x 88 halves -- would cost a workgroup per CU).
 #pragma once
 
 #include "nrf_device.h"
@@ -49,18 +50,19 @@ struct GenModel {
   uint32_t rgb_in;     // 16 + dir_w
   uint32_t n_dens, n_rgb;   // matmuls of the density / rgb MLP (hidden layers + 1)
   uint32_t act_stride; // halves per row of the activation buffers X, Y
-  uint32_t dir_stride; // halves per row of the per-ray direction buffer
+  uint32_t dir_stride; // halves per row of the per-pass direction rows
   uint32_t pad0, pad1;
   GenLayer layer[GEN_MAX_LAYERS];  // density layers, then rgb layers
 };
 
 // LDS bytes per wave of the two generic regions (see render_kernel's LDS map)
-__host__ __device__ inline uint32_t gen_dir_bytes(const GenModel& G) { return 64u * G.dir_stride * 2u; }
+__host__ __device__ inline uint32_t gen_dir_bytes(const GenModel& G) { return (uint32_t)GEN_SAMPLES * G.dir_stride * 2u; }
 __host__ __device__ inline uint32_t gen_act_bytes(const GenModel& G) { return 2u * GEN_SAMPLES * G.act_stride * 2u; }
 
 struct GenLds {
   half_t* dens;  // [GEN_SAMPLES][16]: output of the density MLP = columns 0..15 of the rgb MLP's input
-  half_t* dir;   // [64 rays][dir_stride]
+  half_t* dir;   // [GEN_SAMPLES][dir_stride]: direction encoding of the pass's samples
+  float* rayd;   // [64 rays][3]: 0.5 d + 0.5 of every ray (nerf_render.cu:313-314)
   half_t* X;     // [GEN_SAMPLES][act_stride]
   half_t* Y;
 };
@@ -294,7 +296,7 @@ __device__ __forceinline__ void gen_wave_sync() {
 }
 
 // Both MLPs (nerf_network.h:148-196) on the rows X[0..31][0..feat_k) of the wave; ray[n] = row of the direction
-// buffer that belongs to sample 16 n + c.  Results: lanes g == 0 hold (r, g, b, sigma) of sample c of tile n.
+// rows that belongs to sample 16 n + c.  Results: lanes g == 0 hold (r, g, b, sigma) of sample c of tile n.
 // DENSITY_ONLY: stop after the density MLP (sigma only; density-grid generation).
 template <bool DENSITY_ONLY>
 __device__ __forceinline__ void gen_mlps(const DevModel& M, const GenModel& G, const GenLds& Lw, int lane, const int (&ray)[GEN_TILES],

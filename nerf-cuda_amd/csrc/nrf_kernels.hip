@@ -120,7 +120,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   MlpOut<NT> o;
-  mlp_tiles<NT>(LdsFrags{wl, lane}, feat, dirf, o);
+  mlp_tiles<NT>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
   if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -166,6 +166,15 @@ __device__ __forceinline__ void gen_network_from_lds(const DevModel& M, const Ge
     }
   }
   gen_encode_rows(M, G, lvs, Lw, lane, p01, valid);
+  if constexpr (!DENSITY_ONLY) {  // direction rows of the pass: lane r < 32 encodes the direction of sample base + r
+    const int slot = base + lane;
+    if (lane < GEN_SAMPLES && slot < S) {
+      const int r = __builtin_bit_cast(int, W->pos[slot].w) & 63;
+      gen_encode_dir(M, G, Lw.rayd[3 * r], Lw.rayd[3 * r + 1], Lw.rayd[3 * r + 2], Lw.dir + (size_t)lane * G.dir_stride);
+    }
+#pragma unroll
+    for (int n = 0; n < GEN_TILES; ++n) ray[n] = 16 * n + c;
+  }
   gen_wave_sync();
   float4_t o[GEN_TILES];
   gen_mlps<DENSITY_ONLY>(M, G, Lw, lane, ray, o);
@@ -200,7 +209,8 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
 // LDS map of the kernels that evaluate the network.
 //   hot instance:     [20 KiB weight fragments][level table][RENDER_WAVES x WaveLds][march tables]
 //   generic instance: [level table][RENDER_WAVES x WaveLds][RENDER_WAVES x direction rows][RENDER_WAVES x (X, Y)][march tables]
-// (the generic instance streams its weights from global memory; WaveLds::dirf holds the density MLP's output there)
+// (the generic instance streams its weights from global memory; WaveLds::dirf holds the density MLP's output and the
+//  rays' directions there)
 struct LdsMap {
   uint4* wl;            // hot: weight fragments; generic: the (X, Y) region (what the dilated bitfield borrows during ray setup)
   LevelParams* lvs;
@@ -219,7 +229,8 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     unsigned char* dir = waves + n_waves * (int)sizeof(WaveLds);
     unsigned char* act = dir + n_waves * gen_dir_bytes(G);
     m.wl = reinterpret_cast<uint4*>(act);
-    m.gen.dens = reinterpret_cast<half_t*>(&m.W->dirf[0][0]);
+    m.gen.dens = reinterpret_cast<half_t*>(&m.W->dirf[0][0]);   // 1 KiB: [32][16] halves
+    m.gen.rayd = reinterpret_cast<float*>(&m.W->dirf[32][0]);    // 768 B of the second KiB
     m.gen.dir = reinterpret_cast<half_t*>(dir + wave * gen_dir_bytes(G));
     m.gen.X = reinterpret_cast<half_t*>(act + wave * gen_act_bytes(G));
     m.gen.Y = m.gen.X + GEN_SAMPLES * G.act_stride;
@@ -229,6 +240,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
     m.W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
     m.gen.dens = m.gen.dir = m.gen.X = m.gen.Y = nullptr;
+    m.gen.rayd = nullptr;
     m.tables = smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
   }
   return m;
@@ -399,7 +411,9 @@ __global__ __launch_bounds__(RENDER_THREADS, GEN ? 2 : 4) void render_kernel(con
       float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
       float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
       if constexpr (GEN) {
-        gen_encode_dir(M, *M.gen, u0, u1, u2, lm.gen.dir + (size_t)lane * M.gen->dir_stride);
+        lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
+        lm.gen.rayd[3 * lane + 1] = u1;
+        lm.gen.rayd[3 * lane + 2] = u2;
       } else {
         half_t e[16];
         encode_dir16(M, u0, u1, u2, e);
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
           df[t] = __builtin_bit_cast(half4_t, dv[t]);
         }
       }
-      mlp_tiles<T, FRAG_D0_NATURAL>(RegFrags{wreg}, f, df, o);
+      mlp_tiles<T, FRAG_D0_NATURAL>(RegFrags{wreg}, f, df, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
     }
     if (g == 0) {  // (r, g, b): six bytes of the sample's eight
 #pragma unroll
@@ -779,7 +793,9 @@ __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const
       float u1 = 0.5f * dir[3 * (size_t)i + 1]; u1 = u1 + 0.5f;
       float u2 = 0.5f * dir[3 * (size_t)i + 2]; u2 = u2 + 0.5f;
       if constexpr (GEN) {
-        gen_encode_dir(M, *M.gen, u0, u1, u2, lm.gen.dir + (size_t)lane * M.gen->dir_stride);
+        lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
+        lm.gen.rayd[3 * lane + 1] = u1;
+        lm.gen.rayd[3 * lane + 2] = u2;
       } else {
         half_t e[16];
         encode_dir16(M, u0, u1, u2, e);

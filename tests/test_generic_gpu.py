@@ -227,3 +227,37 @@ def test_density_grid_from_the_network(ctx, kw):
     ctx.load_model(desc)
     g3, m3 = ctx.read_density_grid(n_cells)
     np.testing.assert_array_equal(g3, keep[1])
+
+
+def test_instant_ngp_geometry_runs_in_the_register_resident_instance(ctx):
+    """instant-ngp's level geometry at aabb_scale 32 (per_level_scale from 2048 * 32 / 16: the finest level has
+    res = 65536) meets grid_index's uint32 stride overflow (grid.h:106-109): stride wraps to 0 after the y term, the
+    level is (x + y * res) & (size - 1) without hash and without z.  Oracle and kernel follow the uint32 arithmetic
+    literally; the hot instance covers the level (LV_XY_POW2) and instant-ngp's logistic colours (rgb output Sigmoid),
+    so such a model renders at the base shape's speed.  Encoding bit-exact, frames at the usual tolerance."""
+    pls = nh.default_per_level_scale(32.0, 16, 16)
+    for log2T, H in ((12, 32), (19, 32)):
+        desc, keep, cfg = models.build_model(log2_hashmap_size=log2T, H=H, bound=16.0, cascade=5, per_level_scale=pls,
+                                             rgb_output_activation="Sigmoid")
+        assert nh.level_table(desc).resolution[15] == 65536
+        ctx.load_model(desc)
+        o = op.Oracle(desc)
+        rng = np.random.default_rng(4)
+        pos = np.concatenate([rng.random((6000, 3), dtype=np.float32),
+                              np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.999999, 1e-7, 0.5], [0.25, 1, 1]], np.float32)])
+        want = o.encode_grid(pos)
+        out = torch.empty((len(pos), 32), dtype=torch.int16, device="cuda")
+        p_d = dev(pos)
+        sync()
+        ctx.encode_grid(p_d.data_ptr(), len(pos), out.data_ptr())
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), want)
+        W, Hh = 96, 64
+        cam, pose = syn.default_camera(W, Hh), syn.orbit_pose(60, 25)
+        ctx.set_options(nh.default_options())
+        ctx.set_resolution(W, Hh)
+        ctx.render(cam, pose)
+        rgba, depth = ctx.read_f32()
+        wantf, wdepth, wst = o.render(cam, pose, W, Hh, schedule=op.SCHED_PER_RAY)
+        assert ctx.stats().n_samples > 0
+        assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0
+        assert rgba[..., :3].max() <= 1.0 + 1e-3  # logistic colours + white background stay in range
