@@ -103,22 +103,27 @@ int expected_params(const nrf_model_desc& d, const nrf_level_table& t, uint64_t&
 //   input layers   kmap(g,j) = 2(4(j>>1) + g) + (j&1)      (density: lane group g holds levels g, 4+g, 8+g, 12+g)
 //                  kmap(g,j) = j<4 ? 4g+j : 16+4g+(j-4)    (rgb: [density out | dir enc])
 //   hidden->next   kmap(s,g,j) = 16(2s + (j>>2)) + 4g + (j&3)   (a D fragment re-used in-lane as B)
-void pack_fragments(const std::vector<_Float16>& w16, std::vector<_Float16>& frags) {
-  frags.assign((size_t)N_FRAGS_ALL * 64 * 8, (_Float16)0.0f);
+void pack_fragments(const std::vector<_Float16>& w16, uint32_t rgb_in, std::vector<_Float16>& frags) {
+  frags.assign((size_t)N_FRAGS_WIDE_ALL * 64 * 8, (_Float16)0.0f);
   const _Float16* D0 = w16.data();              // [64][32]
   const _Float16* D1 = D0 + 64 * 32;            // [16][64]
-  const _Float16* R0 = D1 + 16 * 64;            // [64][32]
-  const _Float16* R1 = R0 + 64 * 32;            // [64][64]
+  const _Float16* R0 = D1 + 16 * 64;            // [64][rgb_in]: 32 for a 16-wide direction encoding, up to 96 (wide instance)
+  const _Float16* R1 = R0 + 64 * (size_t)rgb_in;  // [64][64]
   const _Float16* R2 = R1 + 64 * 64;            // [16][64]
   auto khid = [](int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); };
   auto put = [&](int f, const _Float16* Wm, int in, int m, auto kmap) {
     for (int l = 0; l < 64; ++l)
-      for (int j = 0; j < 8; ++j) frags[((size_t)f * 64 + l) * 8 + j] = Wm[(size_t)(16 * m + (l & 15)) * in + kmap(l >> 4, j)];
+      for (int j = 0; j < 8; ++j) {
+        const int k = kmap(l >> 4, j);
+        frags[((size_t)f * 64 + l) * 8 + j] = k < in ? Wm[(size_t)(16 * m + (l & 15)) * in + k] : (_Float16)0.0f;
+      }
   };
   for (int m = 0; m < 4; ++m) put(FRAG_D0 + m, D0, 32, m, [](int g, int j) { return 2 * (4 * (j >> 1) + g) + (j & 1); });
   for (int m = 0; m < 4; ++m) put(FRAG_D0_NATURAL + m, D0, 32, m, [](int g, int j) { return 8 * g + j; });
   for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
-  for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, (int)rgb_in, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int s = 1; s < RK_WIDE; ++s)  // wide instance: the columns beyond the first 32, natural order; zero beyond rgb_in
+    for (int m = 0; m < 4; ++m) put(FRAG_R0X + 4 * (s - 1) + m, R0, (int)rgb_in, m, [&](int g, int j) { return 32 * s + 8 * g + j; });
   for (int m = 0; m < 4; ++m)
     for (int s = 0; s < 2; ++s) put(FRAG_R1 + 2 * m + s, R1, 64, m, [&](int g, int j) { return khid(s, g, j); });
   for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
@@ -167,6 +172,7 @@ struct nrf_context {
   void* d_dilated = nullptr;
   void* d_ctab = nullptr;
   void* d_gen = nullptr;
+  void* d_wfrag_gen = nullptr;  // wide models: generic-layout fragments for the stage entry points
   GenModel gen{};  // host copy of the generic instance's description (valid when dm.generic)
   std::vector<float> host_grid;  // the float density grid the march tables were built from
   bool grid_missing = false;     // loaded without a density grid and none generated yet
@@ -207,6 +213,8 @@ void free_model(nrf_context* c) {
   if (c->d_ctab) (void)hipFree(c->d_ctab);
   if (c->d_dilated) (void)hipFree(c->d_dilated);
   if (c->d_gen) (void)hipFree(c->d_gen);
+  if (c->d_wfrag_gen) (void)hipFree(c->d_wfrag_gen);
+  c->d_wfrag_gen = nullptr;
   c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = c->d_gen = nullptr;
   c->model_loaded = false;
 }
@@ -473,6 +481,10 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
       const uint64_t used = (uint64_t)render_gen_lds_fixed_bytes(M.gen_wave_bytes);
       budget = used + budget <= 160u * 1024u ? budget : 160u * 1024u - used;
     }
+    if (M.wide) {  // three workgroups per CU: (160 KiB / 3 - fixed part) for the tables
+      const uint64_t room = 160u * 1024u / 3u - (uint64_t)render_wide_lds_fixed_bytes();
+      budget = budget < room ? budget : room;
+    }
     if (coarse_shift && 4 * (words + fl) <= budget) {
       M.lds_coarse_words = (uint32_t)words;
       M.lds_ctab_floats = (uint32_t)fl;
@@ -664,18 +676,22 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     generic_grid = generic_grid || Lv.mode == LV_GENERIC;
   }
   // The register-resident instance is the shape of the reference's base.json; everything else is the generic one.
+  // (a Frequency direction encoding of 32..80 values keeps the register-resident instance: its `wide` form)
+  const bool wide = dir_w > 16 && dir_w <= 16u * (2u * RK_WIDE - 1u) && d->dir_encoding == NRF_DIR_FREQUENCY;
   const bool generic = generic_grid || F != 2 || L != 16 || Wn != 64 || d->density_hidden_layers != 1 || d->rgb_hidden_layers != 2 ||
-                       dir_w != 16 || d->interpolation != NRF_INTERP_LINEAR ||
+                       !(dir_w == 16 || wide) || d->interpolation != NRF_INTERP_LINEAR ||
                        !(d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
                          d->density_output_activation == NRF_ACT_NONE &&
                          (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                          d->sigma_activation == NRF_ACT_EXPONENTIAL);
-  std::vector<_Float16> frags;
+  std::vector<_Float16> frags, frags_gen;
   GenModel G;
   std::memset(&G, 0, sizeof(G));
-  if (!generic) {
-    pack_fragments(w16, frags);
-  } else {
+  if (!generic) pack_fragments(w16, rgb_in, frags);
+  // the generic description + fragments: the generic instance's model, and -- for a wide model -- what the stage
+  // entry points nrf_encode_dir / nrf_mlp_forward run on (rows of the padded widths)
+  if (generic || wide) {
+    std::vector<_Float16>& fr = generic ? frags : frags_gen;
     G.F = F; G.interp = d->interpolation; G.n_levels = L; G.feat_raw = feat_raw; G.feat_w = feat_w;
     G.feat_k = next_multiple(feat_w, 32u); G.width = Wn; G.dir_raw = raw; G.dir_w = dir_w; G.rgb_in = rgb_in;
     G.n_dens = d->density_hidden_layers + 1; G.n_rgb = d->rgb_hidden_layers + 1;
@@ -684,15 +700,15 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     G.dir_stride = dir_w + 8;
     const _Float16* wp = w16.data();
     for (size_t i = 0; i < layers.size(); ++i) {
-      G.layer[i].frag_off = (uint32_t)(frags.size() / (64 * 8));
+      G.layer[i].frag_off = (uint32_t)(fr.size() / (64 * 8));
       G.layer[i].k_steps = (layers[i].K + 31) / 32;
       G.layer[i].n_tiles = layers[i].N / 16;
       G.layer[i].act = layers[i].act;
-      pack_generic_layer(wp, layers[i].N, layers[i].K, frags);
+      pack_generic_layer(wp, layers[i].N, layers[i].K, fr);
       wp += (size_t)layers[i].N * layers[i].K;
     }
   }
-  const uint32_t gen_wave_bytes = generic ? gen_dir_bytes(G) + gen_act_bytes(G) : 0u;
+  const uint32_t gen_wave_bytes = (generic || wide) ? gen_dir_bytes(G) + gen_act_bytes(G) : 0u;
   if (generic && render_gen_lds_fixed_bytes(gen_wave_bytes) > 160 * 1024)
     return fail(NRF_E_UNSUPPORTED, "HIP path: this network shape needs more LDS than a CU has");
   // Device copy of the table: the reference's entries level by level; a dense level is followed by
@@ -731,7 +747,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
-  if (generic) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
+  if (generic || wide) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
+  if (wide) HIP_TRY(upload(&c->d_wfrag_gen, frags_gen.data(), frags_gen.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -775,6 +792,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     M.uni_modes |= (all_dense ? 1u : (all_hash ? 2u : 0u)) << (2 * jl);
   }
   M.generic = generic ? 1u : 0u;
+  M.wide = (!generic && wide) ? 1u : 0u;
   M.gen = (const GenModel*)c->d_gen;
   M.gen_wave_bytes = gen_wave_bytes;
   c->gen = G;
@@ -1094,10 +1112,21 @@ int nrf_encode_grid(nrf_context* c, const void* pos01, uint32_t n, void* out, vo
   STAGE_EPILOGUE();
 }
 
+// A wide model's rows (direction encodings of 32..80 values) go through the generic stage kernels: same arithmetic,
+// generic-layout fragments; the fused kernel and nrf_network run the wide instance itself.
+static DevModel stage_model(const nrf_context* c) {
+  DevModel m = c->dm;
+  if (m.wide) {
+    m.generic = 1u;
+    m.wfrag = (const uint4*)c->d_wfrag_gen;
+  }
+  return m;
+}
+
 int nrf_encode_dir(nrf_context* c, const void* dir01, uint32_t n, void* out, void* stream) {
   STAGE_PROLOGUE();
   if (n && (!dir01 || !out)) return fail(NRF_E_INVALID, "null argument");
-  HIP_TRY(launch_encode_dir(c->dm, dir01, n, out, st));
+  HIP_TRY(launch_encode_dir(stage_model(c), dir01, n, out, st));
   STAGE_EPILOGUE();
 }
 
@@ -1106,7 +1135,7 @@ int nrf_mlp_forward_repeat(nrf_context* c, const void* feat, const void* dirfeat
   STAGE_PROLOGUE();
   if (n && (!feat || !dirfeat || !out)) return fail(NRF_E_INVALID, "null argument");
   if (repeat < 1) return fail(NRF_E_INVALID, "repeat must be >= 1");
-  HIP_TRY(launch_mlp_forward(c->dm, feat, dirfeat, n, out, repeat, st));
+  HIP_TRY(launch_mlp_forward(stage_model(c), feat, dirfeat, n, out, repeat, st));
   STAGE_EPILOGUE();
 }
 

@@ -68,8 +68,13 @@ enum : int {
   N_FRAGS = 20,       // what render_kernel / network_kernel keep in LDS
   FRAG_D0_NATURAL = 20,  // density 32->64 again with the natural K order (k = 8g + j): mlp_forward_kernel reads its
                          // [n][32] input rows as one 16-byte load per lane
-  N_FRAGS_ALL = 24
+  N_FRAGS_ALL = 24,
+  // "wide" instance (direction encodings of 32..80 values: an rgb input of up to 96 columns = RK_WIDE K steps):
+  FRAG_R0X = 24,         // rgb first layer, K steps s = 1, 2: fragment FRAG_R0X + 4 (s - 1) + m, natural K order
+                         // (column 32 s + 8 g + j, i.e. direction entry 32 s - 16 + 8 g + j); zero beyond the real width
+  N_FRAGS_WIDE_ALL = 32
 };
+constexpr int RK_WIDE = 3;  // K steps of the wide instance's first rgb layer
 
 struct DevModel {
   const uint32_t* grid;      // half2 entries
@@ -96,12 +101,15 @@ struct DevModel {
   uint32_t uni_modes;    // 2 bits per unrolled step jl = 0..3 of the fused kernel (levels 4*jl + g): 0 mixed, 1 all dense,
                          // 2 all power-of-two hashed (host: nrf_load_model)
   uint32_t generic;      // 0: the shape of the reference's base.json (L = 16, F = 2, 64 neurons, 1 + 2 hidden layers, a
-                         // 16-wide direction encoding, hidden ReLU / density output None / sigma Exponential / rgb output
-                         // None or Sigmoid, linear interpolation, every level dense, power-of-two hashed or LV_XY_POW2):
-                         // the register-resident instance (this file);
+                         // 16-wide direction encoding -- or a Frequency encoding of up to 80 values: `wide` --, hidden
+                         // ReLU / density output None / sigma Exponential / rgb output None or Sigmoid, linear
+                         // interpolation, every level dense, power-of-two hashed or LV_XY_POW2): the register-resident
+                         // instance (this file);
                          // 1: everything else: the generic instance (nrf_generic.h), described by `gen`
   const struct GenModel* gen;  // device memory; nullptr unless generic
   uint32_t gen_wave_bytes;     // generic instance: LDS bytes per wave of the direction rows + activation rows
+  uint32_t wide;               // register-resident instance with a 32..80-wide Frequency direction encoding: the first rgb
+                               // layer takes RK_WIDE K steps, the extra direction entries are evaluated in-lane per sample
   uint32_t coarse_shift;    // 2 or 0
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
@@ -607,6 +615,27 @@ __device__ __forceinline__ void encode_dir16(const DevModel& M, float d01x, floa
   }
 }
 
+// Wide instance: the eight Frequency-encoding entries e0 .. e0 + 7 (e0 a multiple of 8) of one direction, as the lane's
+// B fragment of an extra K step of the first rgb layer.  frequency.h:72-89: entry e belongs to input dimension
+// e / (2 nf), octave (e / 2) % nf, phase (e % 2) * pi/2; entries from 6 nf on are the padding ones.  With u = e / 2 < 3 nf
+// the division is two compares.
+__device__ __forceinline__ half8_t dir_entries8(uint32_t nf, uint32_t e0, float d01x, float d01y, float d01z) {
+  const float PI = 3.14159265358979323846f;
+  half8_t r;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t u = (e0 >> 1) + (uint32_t)p;
+    const uint32_t feat = (u >= nf ? 1u : 0u) + (u >= 2u * nf ? 1u : 0u);
+    const uint32_t k = u - feat * nf;
+    const float in = feat == 0u ? d01x : (feat == 1u ? d01y : d01z);
+    const float xs = ldexpf(in, (int)k) * PI;
+    const bool pad = u >= 3u * nf;
+    r[2 * p] = pad ? (half_t)1.0f : f2h_rne(__sinf(xs));
+    r[2 * p + 1] = pad ? (half_t)1.0f : f2h_rne(__sinf(xs + PI / 2));
+  }
+  return r;
+}
+
 // ------------------------------------------------------------- fused MLP ----
 // Both MLPs of NerfNetwork::inference_mixed_precision_impl (nerf_network.h:148-196)
 // for NT tiles of 16 samples held by ONE wavefront, entirely in registers:
@@ -646,10 +675,11 @@ __device__ __forceinline__ half8_t pack_acc(float4_t lo, float4_t hi) {
 // dirf[n]  : 4 halves = dir-encoding entries 4g..4g+3 of that sample
 // out[n]   : valid in lanes g == 0: (r, g, b, sigma) as fp32 values of the fp16 outputs
 // frag(f) returns weight fragment f (FRAG_*) of this lane: from LDS (LdsFrags) or from registers.
+// In LDS the fragments 0 .. N_FRAGS - 1 are followed directly by the wide instance's FRAG_R0X ones.
 struct LdsFrags {
   const uint4* wl;
   int lane;
-  __device__ __forceinline__ half8_t operator()(int f) const { return frag_load(wl, f, lane); }
+  __device__ __forceinline__ half8_t operator()(int f) const { return frag_load(wl, f >= FRAG_R0X ? f - FRAG_R0X + N_FRAGS : f, lane); }
 };
 // Outputs of mlp_tiles for NT tiles of 16 samples (fp16 values, as the reference's network_output holds them):
 //   rg[n], bx[n]  packed halves (r, g) and (b, row 3 of the rgb output) of sample c of tile n -- valid in lanes g == 0
@@ -664,9 +694,11 @@ struct MlpOut {
 // rgb_sigmoid (wave-uniform): the rgb MLP's output activation is Sigmoid instead of None -- tcnn's logistic
 // 1 / (1 + expf(-x)) on the fp32 sums (common_device.h:84-88), which is how instant-ngp's colour activation reaches
 // this network when one of its snapshots is loaded (nerfhip.py "instant-ngp snapshots").
-template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags>
+// RK > 1 (wide instance): dirx[n][s - 1] = B fragment of K step s of the first rgb layer = direction entries
+// 32 s - 16 + 8 g .. + 7 of sample c of tile n (dir_entries8).
+template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags, int RK = 1>
 __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
-                                          bool rgb_sigmoid = false) {
+                                          bool rgb_sigmoid = false, const half8_t (*dirx)[RK_WIDE - 1] = nullptr) {
   static_assert(NT == 1 || NT == 2 || NT == 4, "tiles per pass");
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
   float4_t acc[NT][4];
@@ -722,12 +754,22 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
   }
   // extract_density: fp32 activation (Exponential) of the fp16 density output, stored as fp16
   out.sigma = (half_t)expf((float)bits_h2(dall).x);
-  // ---- rgb layer 0: 32 -> 64
+  // ---- rgb layer 0: 32 (or 32 RK) -> 64
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const half8_t a = frag(FRAG_R0 + m);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, rin[n], zero);
+  }
+  if constexpr (RK > 1) {
+#pragma unroll
+    for (int s = 1; s < RK; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const half8_t a = frag(FRAG_R0X + 4 * (s - 1) + m);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, dirx[n][s - 1], acc[n][m]);
+      }
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {

@@ -36,6 +36,10 @@ struct WaveLds {
 static_assert(sizeof(WaveLds) == 2048 + 24 * SLOTS, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
+// network instances of the kernels below
+enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2 };
+constexpr int LDS_WFRAG_WIDE_BYTES = (N_FRAGS + 4 * (RK_WIDE - 1)) * 64 * 16;  // 28672: + the extra K steps of the first rgb layer
+constexpr int LDS_RAYD_BYTES = 64 * 3 * 4;  // wide instance: 0.5 d + 0.5 of every ray of a wave (fp32)
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
 constexpr int RENDER_WAVES = 4;  // waves (8x8 pixel tiles) per workgroup
 constexpr int RENDER_THREADS = 64 * RENDER_WAVES;
@@ -72,12 +76,15 @@ __device__ __forceinline__ unsigned long long stamp() {
 // Encodes and evaluates the S (<= 16*NT) samples queued in the wave's LDS
 // slots; results go to W->out[slot].  Lane (g, c): sample c of each tile,
 // hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
-template <int NT>
+// RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
+// evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
+template <int NT, int RK = 1>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
-                                                 int S, int base, int lane, float density_scale) {
+                                                 const float* rayd, int S, int base, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
   half8_t feat[NT];
   half4_t dirf[NT];
+  half8_t dirx[NT][RK_WIDE - 1];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int slot = base + 16 * n + c;
@@ -114,13 +121,22 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp(gv[jl], gf[jl]);
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
+      if constexpr (RK > 1) {
+        const float dx = rayd[3 * ray], dy = rayd[3 * ray + 1], dz = rayd[3 * ray + 2];
+#pragma unroll
+        for (int s = 1; s < RK; ++s) dirx[n][s - 1] = dir_entries8(M.n_frequencies, 32u * s - 16u + 8u * (uint32_t)g, dx, dy, dz);
+      }
+    } else if constexpr (RK > 1) {
+      const half8_t z8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+      for (int s = 1; s < RK; ++s) dirx[n][s - 1] = z8;
     }
     const uint4 fv = make_uint4(fb[0], fb[1], fb[2], fb[3]);
     feat[n] = __builtin_bit_cast(half8_t, fv);
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   MlpOut<NT> o;
-  mlp_tiles<NT>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
+  mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
   if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -190,24 +206,26 @@ __device__ __forceinline__ void gen_network_from_lds(const DevModel& M, const Ge
   gen_wave_sync();  // the next pass overwrites the rows
 }
 
-template <bool GEN>
+template <int NET>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const GenLds& Lw, int S, int lane, float density_scale) {
-  if constexpr (GEN) {
+  constexpr int RK = NET == NET_WIDE ? RK_WIDE : 1;
+  if constexpr (NET == NET_GENERIC) {
     const GenModel& G = *M.gen;
     for (int base = 0; base < S; base += GEN_SAMPLES)  // wave-uniform
       gen_network_from_lds<false>(M, G, lvs, W, Lw, S, base, lane, density_scale);
   } else {
     for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      if (ntile <= 1) network_from_lds<1>(M, wl, lvs, W, S, base, lane, density_scale);
-      else network_from_lds<NT_MAX>(M, wl, lvs, W, S, base, lane, density_scale);
+      if (ntile <= 1) network_from_lds<1, RK>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      else network_from_lds<NT_MAX, RK>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
     }
   }
 }
 
 // LDS map of the kernels that evaluate the network.
 //   hot instance:     [20 KiB weight fragments][level table][RENDER_WAVES x WaveLds][march tables]
+//   wide instance:    [28 KiB weight fragments][level table][RENDER_WAVES x WaveLds][RENDER_WAVES x ray directions][march tables]
 //   generic instance: [level table][RENDER_WAVES x WaveLds][RENDER_WAVES x direction rows][RENDER_WAVES x (X, Y)][march tables]
 // (the generic instance streams its weights from global memory; WaveLds::dirf holds the density MLP's output and the
 //  rays' directions there)
@@ -218,10 +236,10 @@ struct LdsMap {
   GenLds gen;           // this wave's generic regions
   unsigned char* tables;
 };
-template <bool GEN>
+template <int NET>
 __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M, int wave, int n_waves) {
   LdsMap m;
-  if constexpr (GEN) {
+  if constexpr (NET == NET_GENERIC) {
     const GenModel& G = *M.gen;
     m.lvs = reinterpret_cast<LevelParams*>(smem);
     unsigned char* waves = smem + LDS_LEVEL_BYTES;
@@ -236,14 +254,24 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.gen.Y = m.gen.X + GEN_SAMPLES * G.act_stride;
     m.tables = act + n_waves * gen_act_bytes(G);
   } else {
+    constexpr int WF = NET == NET_WIDE ? LDS_WFRAG_WIDE_BYTES : LDS_WFRAG_BYTES;
     m.wl = reinterpret_cast<uint4*>(smem);
-    m.lvs = reinterpret_cast<LevelParams*>(smem + LDS_WFRAG_BYTES);
-    m.W = reinterpret_cast<WaveLds*>(smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES) + wave;
+    m.lvs = reinterpret_cast<LevelParams*>(smem + WF);
+    m.W = reinterpret_cast<WaveLds*>(smem + WF + LDS_LEVEL_BYTES) + wave;
     m.gen.dens = m.gen.dir = m.gen.X = m.gen.Y = nullptr;
-    m.gen.rayd = nullptr;
-    m.tables = smem + LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
+    unsigned char* after = smem + WF + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
+    m.gen.rayd = NET == NET_WIDE ? reinterpret_cast<float*>(after + wave * LDS_RAYD_BYTES) : nullptr;
+    m.tables = after + (NET == NET_WIDE ? n_waves * LDS_RAYD_BYTES : 0);
   }
   return m;
+}
+
+// copies the instance's weight fragments into LDS (hot: 0 .. N_FRAGS - 1; wide: followed by FRAG_R0X ..)
+template <int NET>
+__device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
+  for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  if constexpr (NET == NET_WIDE)
+    for (int i = threadIdx.x; i < 4 * (RK_WIDE - 1) * 64; i += blockDim.x) wl[N_FRAGS * 64 + i] = M.wfrag[FRAG_R0X * 64 + i];
 }
 
 // ------------------------------------------------------- the render kernel ----
@@ -251,14 +279,15 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
 // (the generic instance is bound by its LDS rows, not by registers: no 128-VGPR cap there)
-template <bool GEN, bool COARSE_LDS, int MARCH>
-__global__ __launch_bounds__(RENDER_THREADS, GEN ? 2 : 4) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
+template <int NET, bool COARSE_LDS, int MARCH>
+__global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NET_WIDE ? 3 : 4)) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
                                                      float4* __restrict__ rgba, float* __restrict__ depth,
                                                      unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool GEN = NET == NET_GENERIC;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const LdsMap lm = lds_map<GEN>(smem, M, wave, RENDER_WAVES);
+  const LdsMap lm = lds_map<NET>(smem, M, wave, RENDER_WAVES);
   uint4* wl = lm.wl;
   LevelParams* lvs = lm.lvs;
   WaveLds* W = lm.W;
@@ -424,12 +453,17 @@ __global__ __launch_bounds__(RENDER_THREADS, GEN ? 2 : 4) void render_kernel(con
           h.y = e[2 * j + 1];
           W->dirf[lane][j] = h2_bits(h);
         }
+        if constexpr (NET == NET_WIDE) {  // the entries beyond the first sixteen are evaluated per sample (dir_entries8)
+          lm.gen.rayd[3 * lane] = u0;
+          lm.gen.rayd[3 * lane + 1] = u1;
+          lm.gen.rayd[3 * lane + 2] = u2;
+        }
       }
     }
     // ---- (3) the weight fragments replace the dilated bitfield
     if (__syncthreads_or(alive ? 1 : 0) != 0) {
       if constexpr (!GEN) {
-        for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+        stage_fragments<NET>(M, wl);
         __syncthreads();
       }
     }
@@ -494,7 +528,7 @@ __global__ __launch_bounds__(RENDER_THREADS, GEN ? 2 : 4) void render_kernel(con
 
     if (S > 0) {
       // ---- network on the S queued samples (sample-major MFMA tiles)
-      network_dispatch<GEN>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
+      network_dispatch<NET>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
       wave_sync();
     }
     NRF_STAMP(t2);
@@ -734,7 +768,7 @@ __global__ __launch_bounds__(256) void gen_mlp_forward_kernel(const DevModel M, 
   const GenModel& G = *M.gen;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id(), g = lane >> 4, c = lane & 15;
-  const LdsMap lm = lds_map<true>(smem, M, wave, 4);
+  const LdsMap lm = lds_map<NET_GENERIC>(smem, M, wave, 4);
   const uint32_t wave_global = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
   const uint32_t n_chunks = (n + GEN_SAMPLES - 1) / GEN_SAMPLES;
   for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
@@ -765,18 +799,18 @@ __global__ __launch_bounds__(256) void gen_mlp_forward_kernel(const DevModel M, 
 
 // Whole network on raw march output through the SAME code path as render_kernel.
 // DENSITY_ONLY (generic or hot): sigma only, rgb untouched (density-grid generation evaluates positions without directions).
-template <bool GEN>
+template <int NET>
 __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const float* __restrict__ xyz,
                                                       const float* __restrict__ dir, uint32_t n, float* __restrict__ sigma,
                                                       float* __restrict__ rgb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool GEN = NET == NET_GENERIC;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const LdsMap lm = lds_map<GEN>(smem, M, wave, 4);
+  const LdsMap lm = lds_map<NET>(smem, M, wave, 4);
   uint4* wl = lm.wl;
   LevelParams* lvs = lm.lvs;
-  if constexpr (!GEN)
-    for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
+  if constexpr (!GEN) stage_fragments<NET>(M, wl);
   if (threadIdx.x < 16) lvs[threadIdx.x] = M.lv[threadIdx.x];
   __syncthreads();
   WaveLds* W = lm.W;
@@ -806,10 +840,15 @@ __global__ __launch_bounds__(256, 2) void network_kernel(const DevModel M, const
           h.y = e[2 * j + 1];
           W->dirf[lane][j] = h2_bits(h);
         }
+        if constexpr (NET == NET_WIDE) {
+          lm.gen.rayd[3 * lane] = u0;
+          lm.gen.rayd[3 * lane + 1] = u1;
+          lm.gen.rayd[3 * lane + 2] = u2;
+        }
       }
     }
     wave_sync();
-    network_dispatch<GEN>(M, wl, lvs, W, lm.gen, S, lane, 1.0f);
+    network_dispatch<NET>(M, wl, lvs, W, lm.gen, S, lane, 1.0f);
     wave_sync();
     if (i < n) {
       const float4 so = W->out[lane];
@@ -1006,8 +1045,10 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
-  const int lds = (M.generic ? gen_lds_bytes(M, RENDER_WAVES) : LDS_FIXED_BYTES) +
-                  (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
+  const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
+                              : (M.wide ? LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES
+                                        : LDS_FIXED_BYTES);
+  const int lds = fixed + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
 #define NRF_LAUNCH_RENDER(G, C, U)                                                                                       \
   do {                                                                                                                   \
     hipError_t e_ = allow_lds(render_kernel<G, C, U>, lds);                                                              \
@@ -1023,12 +1064,17 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   const bool pow2_bound = M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
   const bool pow2 = lds_tab && pow2_h && M.cascade > 1 && pow2_bound;
   if (M.generic) {
-    if (lds_tab) NRF_LAUNCH_RENDER(true, true, MARCH_GENERIC); else NRF_LAUNCH_RENDER(true, false, MARCH_GENERIC);
+    if (lds_tab) NRF_LAUNCH_RENDER(NET_GENERIC, true, MARCH_GENERIC); else NRF_LAUNCH_RENDER(NET_GENERIC, false, MARCH_GENERIC);
+  } else if (M.wide) {
+    if (unit) NRF_LAUNCH_RENDER(NET_WIDE, true, MARCH_UNIT);
+    else if (pow2) NRF_LAUNCH_RENDER(NET_WIDE, true, MARCH_POW2);
+    else if (lds_tab) NRF_LAUNCH_RENDER(NET_WIDE, true, MARCH_GENERIC);
+    else NRF_LAUNCH_RENDER(NET_WIDE, false, MARCH_GENERIC);
   } else {
-    if (unit) NRF_LAUNCH_RENDER(false, true, MARCH_UNIT);
-    else if (pow2) NRF_LAUNCH_RENDER(false, true, MARCH_POW2);
-    else if (lds_tab) NRF_LAUNCH_RENDER(false, true, MARCH_GENERIC);
-    else NRF_LAUNCH_RENDER(false, false, MARCH_GENERIC);
+    if (unit) NRF_LAUNCH_RENDER(NET_HOT, true, MARCH_UNIT);
+    else if (pow2) NRF_LAUNCH_RENDER(NET_HOT, true, MARCH_POW2);
+    else if (lds_tab) NRF_LAUNCH_RENDER(NET_HOT, true, MARCH_GENERIC);
+    else NRF_LAUNCH_RENDER(NET_HOT, false, MARCH_GENERIC);
   }
 #undef NRF_LAUNCH_RENDER
   return hipGetLastError();
@@ -1081,12 +1127,16 @@ hipError_t launch_network(const DevModel& M, const void* xyz, const void* dir, u
   const uint64_t chunks = ((uint64_t)n + 63) / 64;
   if (M.generic) {
     const int lds = gen_lds_bytes(M, 4);
-    hipError_t e = allow_lds(network_kernel<true>, lds);
+    hipError_t e = allow_lds(network_kernel<NET_GENERIC>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(network_kernel<true>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), lds, st, M,
+    hipLaunchKernelGGL(network_kernel<NET_GENERIC>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), lds, st, M,
+                       (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
+  } else if (M.wide) {
+    const int lds = LDS_TOTAL_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + 4 * LDS_RAYD_BYTES;
+    hipLaunchKernelGGL(network_kernel<NET_WIDE>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), lds, st, M,
                        (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
   } else {
-    hipLaunchKernelGGL(network_kernel<false>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
+    hipLaunchKernelGGL(network_kernel<NET_HOT>, dim3(grid_for(chunks, 4, 256 * 4)), dim3(256), LDS_TOTAL_BYTES, st, M,
                        (const float*)xyz, (const float*)dir, n, (float*)sigma, (float*)rgb);
   }
   return hipGetLastError();
@@ -1163,6 +1213,7 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
 }
 
 int render_lds_bytes() { return LDS_FIXED_BYTES; }
+int render_wide_lds_fixed_bytes() { return LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
 int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes) { return LDS_LEVEL_BYTES + RENDER_WAVES * ((int)sizeof(WaveLds) + (int)gen_wave_bytes); }
 
