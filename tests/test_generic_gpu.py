@@ -263,3 +263,57 @@ def test_instant_ngp_geometry_runs_in_the_register_resident_instance(ctx):
         assert ctx.stats().n_samples > 0
         assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0
         assert rgba[..., :3].max() <= 1.0 + 1e-3  # logistic colours + white background stay in range
+
+
+@pytest.mark.parametrize("kw", [dict(dir_otype="Frequency", n_frequencies=12), dict(n_neurons=32, n_features_per_level=4, n_levels=8)])
+def test_wide_and_generic_instances_shard_batch_and_group_like_the_hot_one(ctx, kw):
+    """The other kernel instances behind the same launch machinery: batched views, 3-way strip shards + untile and a
+    two-member device group must all reproduce the single renders bit for bit (wide: Frequency-12; generic: a 32-neuron
+    F = 4 model), at a resolution with ragged strips."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=14, H=64, **kw)
+    W, H, n = 200, 104, 3
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    poses = np.stack([syn.orbit_pose(40.0 + 100.0 * i, 20.0) for i in range(n)])
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    singles = []
+    for i in range(n):
+        ctx.render(cams[i], poses[i])
+        singles.append(ctx.read_f32())
+    assert ctx.stats().n_samples > 0
+    ctx.set_max_views(n)
+    ctx.render_views(cams, poses)
+    for i in range(n):
+        rgba, depth = ctx.read_view_f32(i)
+        np.testing.assert_array_equal(rgba, singles[i][0])
+        np.testing.assert_array_equal(depth, singles[i][1])
+    ctx.set_max_views(1)
+    # strip shards of view 0, untiled on the host
+    world = 3
+    tps = nh.tiles_per_shard(W, H, world)
+    gathered = np.zeros((world, tps * 64, 4), np.float32)
+    for r in range(world):
+        o = nh.default_options()
+        o.shard_index, o.shard_count = r, world
+        ctx.set_options(o)
+        ctx.set_resolution(W, H)
+        f = ctx.render(cams[0], poses[0])
+        part = np.empty((f.n_tiles * 64, 4), np.float32)  # the last shards may hold one strip less than tiles_per_shard
+        dpart = np.empty(f.n_tiles * 64, np.float32)
+        nh._check(ctx.lib.nrf_read_shard_f32(ctx.h, part.ctypes.data, dpart.ctypes.data))
+        shard = np.zeros((tps * 64, 4), np.float32)
+        shard[:f.n_tiles * 64] = part
+        gathered[r] = shard
+    np.testing.assert_array_equal(nh.untile_numpy(gathered, W, H), singles[0][0])
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    # the one-process device group (both members on this box's one device)
+    g = nh.NerfGroup([0, 0])
+    g.load_model(desc)
+    g.set_resolution(W, H)
+    g.render_views(cams, poses)
+    for i in range(n):
+        rgba, depth = g.read_view_f32(i)
+        np.testing.assert_array_equal(rgba, singles[i][0])
+    g.close()
