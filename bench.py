@@ -461,9 +461,10 @@ def mlp_microbench(ctx, torch, dev):
     ms = e0.elapsed_time(e1) / reps
     tflops = n * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12
     gbs = n * (64 + 32 + 8) / (ms * 1e-3) / 1e9
-    # the same kernel with every chunk evaluated 16 times from registers: the MFMA chain (with its fp32 -> fp16
-    # re-packing between layers) without the HBM stream that caps the figure above at ~0.5 of peak
-    rep = 16
+    # the same kernel with every chunk evaluated 64 times from registers: the MFMA chain (with its fp32 -> fp16
+    # re-packing between layers) without the HBM stream that caps the figure above at ~0.5 of peak (at 16 repeats the
+    # stream's fixed cost, 0.1-0.3 ms per launch, is still a fifth of the time: 0.46 instead of 0.57)
+    rep = 64
     ctx.mlp_forward_repeat(feat.data_ptr(), dirf.data_ptr(), n, out.data_ptr(), rep, stream=st.cuda_stream)
     e0.record(st)
     for _ in range(4):

@@ -803,6 +803,8 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
   }
   if (rgb_sigmoid) {
+    asm volatile("" ::: "memory");  // keeps this a (wave-uniform) branch: without it the compiler evaluates the six
+                                    // logistic functions speculatively and selects -- 130 VALU instructions per pass
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
