@@ -45,5 +45,31 @@ def main():
     print("wrote tiny_scene.npz:", st.n_samples, "samples")
 
 
+# A second fixture for the shapes outside base.json (round 2): a Frequency-4 / Smoothstep / F = 4 x 8 levels / 32-neuron
+# model with 2 + 1 hidden layers -- pins the oracle's generalised encoders and MLP, and through it the generic instance.
+GENERIC_KW = dict(dir_otype="Frequency", n_frequencies=4, interpolation="Smoothstep", n_features_per_level=4, n_levels=8,
+                  n_neurons=32, density_hidden_layers=2, rgb_hidden_layers=1)
+
+
+def main_generic():
+    desc, keep, cfg = models.build_model(log2_hashmap_size=LOG2T, H=H, seed=2025, **GENERIC_KW)
+    o = op.Oracle(desc)
+    rng = np.random.default_rng(98)
+    pos01 = np.concatenate([rng.random((90, 3), dtype=np.float32), np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.25]], np.float32)])
+    d = rng.normal(size=(len(pos01), 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d01 = (np.float32(0.5) * d + np.float32(0.5)).astype(np.float32)
+    feat, dirf = o.encode_grid(pos01), o.encode_dir(d01)
+    out4 = o.mlp_forward(feat, dirf)
+    cam, pose = syn.default_camera(W, HH), syn.orbit_pose(130, 20)
+    rgba, depth, st = o.render(cam, pose, W, HH, schedule=op.SCHED_PER_RAY)
+    np.savez_compressed(Path(__file__).with_name("generic_scene.npz"),
+                        params=keep[0], density_grid=keep[1].astype(np.uint8), pos01=pos01, dir=d, feat=feat, dirf=dirf,
+                        out4=out4, cam=cam, pose=pose, rgba=rgba, depth=depth, n_samples=np.int64(st.n_samples),
+                        meta=np.array([LOG2T, H, W, HH, 2025], np.int64))
+    print("wrote generic_scene.npz:", st.n_samples, "samples, widths", o.feat_width, o.dir_width)
+
+
 if __name__ == "__main__":
     main()
+    main_generic()

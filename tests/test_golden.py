@@ -110,3 +110,51 @@ def test_frame_fingerprints_unchanged():
         assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
         assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, row
     c.close()
+
+
+# ---- second fixture: a shape outside base.json (tests/golden/generic_scene.npz, make_golden.py main_generic) ----
+GG = np.load(Path(__file__).parent / "golden" / "generic_scene.npz")
+GENERIC_KW = dict(dir_otype="Frequency", n_frequencies=4, interpolation="Smoothstep", n_features_per_level=4, n_levels=8,
+                  n_neurons=32, density_hidden_layers=2, rgb_hidden_layers=1)
+
+
+def _generic_model():
+    log2t, h, w, hh, seed = [int(v) for v in GG["meta"]]
+    desc, keep, cfg = models.build_model(log2_hashmap_size=log2t, H=h, seed=seed, **GENERIC_KW)
+    np.testing.assert_array_equal(keep[0], GG["params"])  # the generator is reproducible
+    desc, keep = nh.desc_from_config(cfg, GG["params"], GG["density_grid"].astype(np.float32))
+    return desc, keep, w, hh
+
+
+def test_oracle_reproduces_generic_golden():
+    desc, keep, w, hh = _generic_model()
+    o = op.Oracle(desc)
+    assert (o.feat_width, o.dir_width) == (32, 32)
+    d01 = (np.float32(0.5) * GG["dir"] + np.float32(0.5)).astype(np.float32)
+    np.testing.assert_array_equal(o.encode_grid(GG["pos01"]), GG["feat"])
+    np.testing.assert_array_equal(o.encode_dir(d01), GG["dirf"])
+    np.testing.assert_array_equal(o.mlp_forward(GG["feat"], GG["dirf"]), GG["out4"])
+    rgba, depth, st = o.render(GG["cam"], GG["pose"], w, hh, schedule=op.SCHED_PER_RAY)
+    np.testing.assert_array_equal(rgba, GG["rgba"])
+    np.testing.assert_array_equal(depth, GG["depth"])
+    assert st.n_samples == int(GG["n_samples"]) > 0
+
+
+@pytest.mark.gpu
+def test_hip_generic_instance_matches_generic_golden():
+    torch = pytest.importorskip("torch")
+    desc, keep, w, hh = _generic_model()
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    n = len(GG["pos01"])
+    pos = torch.from_numpy(GG["pos01"]).cuda()
+    out = torch.empty((n, 32), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_grid(pos.data_ptr(), n, out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), GG["feat"])  # bit-exact (Smoothstep, F = 4)
+    ctx.set_resolution(w, hh)
+    ctx.render(GG["cam"], GG["pose"])
+    rgba, depth = ctx.read_f32()
+    assert np.abs(rgba - GG["rgba"]).max() <= 2.0 / 255.0 and models.psnr(rgba, GG["rgba"]) >= 45.0
+    assert np.abs(depth - GG["depth"]).max() <= 2.0 / 255.0
+    ctx.close()
