@@ -13,14 +13,18 @@ idle (one frame alone: 1.0 ms; in a batch: 0.83 ms per frame).
 
 Multi-GPU (one process per GPU, RCCL):
   --config 3 (default for N > 1; BASELINE.json configs[2]): every frame's tile
-      strips are dealt round-robin to the ranks (strong scaling of the same
-      frames), two steps are in flight, every rank quantises its shard to the
-      reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only
+      strips are dealt round-robin to the ranks (tile-parallel: every rank renders
+      1/N of EVERY frame), two steps are in flight, every rank quantises its shard
+      to the reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only
       exchange is one RCCL gather of the batch's shards to rank 0, followed by an
       untile kernel there (--gather-format f32 ships float RGBA instead).
+      --scaling weak (default): a step is 16 x N frames, so every rank renders 16
+      frames' worth of tiles per step whatever N is; --scaling strong: a step is
+      the same 16 frames at every N (1/N-th of the work per rank and step).
   --config 5 (BASELINE.json configs[4]): 64 camera requests of 800x800 per step,
       replica-parallel: rank r renders whole frames of requests r*64/N .. and the
-      8-bit images are gathered on rank 0 (no untile: frames are whole).
+      8-bit images are gathered on rank 0 (no untile: frames are whole).  Strong
+      scaling by definition (64 requests per step); --scaling weak: 8 x N requests.
 
 `python bench.py --gpus N` WITHOUT a launcher starts the N ranks itself (fresh
 `torch.distributed.run` children, started before this process touches a GPU)
@@ -97,6 +101,9 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="steps in flight; 0 = default (1 at N = 1, else 2)")
     ap.add_argument("--views-per-step", type=int, default=0,
                     help="camera views rendered by ONE launch per step (nrf_render_views); 0 = default")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: weak = the step grows with N (16 x N frames tile-sharded over the ranks; config 5: 8 x N "
+                         "requests), strong = the same step at every N.  Default: weak for configs 2/3, strong for config 5")
     ap.add_argument("--gather-format", choices=("rgbd8", "f32"), default="rgbd8",
                     help="N > 1: what the ranks send to rank 0 -- the reference's 8-bit image (r,g,b,depth: 4 B/px, "
                          "quantised on the rendering GPU) or the float RGBA plane (16 B/px)")
@@ -171,15 +178,21 @@ def main():
     # batch (a few long-lived tiles) overlaps the head of the next.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
     depth = args.frames_in_flight or (DEFAULT_DEPTH if world == 1 else 2)
+    scaling = args.scaling or ("strong" if replica else "weak")
     if replica:
-        # 64 requests per step, rank r takes the contiguous block r*64/N ..: whole frames, shard_count 1
-        V_step = args.views_per_step or CONFIG5_REQUESTS
-        assert V_step % world == 0, "config 5: the requests of a step must divide over the ranks"
-        V = V_step // world
+        # rank r takes the contiguous block r*V .. of the step's requests: whole frames, shard_count 1
+        if scaling == "strong":  # BASELINE's form: 64 requests per step whatever N is
+            V_step = args.views_per_step or CONFIG5_REQUESTS
+            assert V_step % world == 0, "config 5: the requests of a step must divide over the ranks"
+            V = V_step // world
+        else:                    # 8 requests per rank and step (= the 8-GPU share of BASELINE's 64)
+            V = args.views_per_step or CONFIG5_REQUESTS // 8
+            V_step = V * world
         shard_index, shard_count = 0, 1
     else:
-        V = V_step = args.views_per_step or DEFAULT_VIEWS
-        assert 1 <= V <= nh.NRF_MAX_VIEWS, "one launch per step: at most NRF_MAX_VIEWS views"
+        # tile-parallel: every rank renders its strips of ALL V_step frames (launches of up to NRF_MAX_VIEWS views)
+        base = args.views_per_step or DEFAULT_VIEWS
+        V = V_step = base * world if scaling == "weak" else base
         shard_index, shard_count = rank, world
     opts = nh.default_options()
     opts.shard_index, opts.shard_count = shard_index, shard_count
@@ -323,7 +336,9 @@ def main():
             solo.load_model(desc)
             solo.set_resolution(W, H)
             # tile-sharded: view 0 of the step; replica: the first view of every rank's block
-            pairs = ([(r * V, r * V_step // world) for r in range(world)] if replica else [(0, step_poses(0)[0])])
+            # (a step of more than NRF_MAX_VIEWS views is several launches: the last view covers the last of them)
+            pairs = ([(r * V, r * V_step // world) for r in range(world)] if replica else
+                     sorted({(0, step_poses(0)[0]), (V - 1, step_poses(0)[V - 1])}))
             check = True
             for fi, pj in pairs:
                 frame = slots[0].frame[fi]
@@ -380,7 +395,7 @@ def main():
         "single_view_ms": round(single_view_ms, 4),
         "frames_per_s_single": round(1e3 / single_view_ms, 2),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
@@ -389,6 +404,8 @@ def main():
                                + (f"{CONFIG5_REQUESTS} camera requests per step" if replica else "8 orbit cameras"),
                    "samples_per_frame": None,
                    "parallelism": (f"replica{world}" if replica else f"tile{world}"), "views_per_step": V_step,
+                   "step": (f"{V_step} frames per step, each tile-sharded over the {world} rank(s)" if not replica else
+                            f"{V_step} requests per step, {V} whole frames per rank"),
                    "views_per_rank_and_step": V, "steps_in_flight": depth,
                    "gather": (args.gather_format if world > 1 else None)},
         "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
@@ -414,6 +431,8 @@ def main():
             "algorithmic_bytes_per_launch": int(mean_samples_launch * BYTES_PER_SAMPLE),
             "kernel_ms": round(mean_kern_s * 1e3, 4),
             "samples_per_launch": int(mean_samples_launch),
+            # a step of more than NRF_MAX_VIEWS views per rank is several back-to-back launches, timed as one
+            "launches_per_step": -(-V // nh.NRF_MAX_VIEWS),
             # `achieved` is per launch while ~launches_in_flight launches share the chip; the chip-level figures:
             "launches_in_flight": round(in_flight, 2),
             "aggregate_achieved": round(gather_gbs * in_flight, 2),

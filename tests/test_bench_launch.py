@@ -75,6 +75,20 @@ def test_self_launched_two_rank_rehearsal_tile_sharded():
     assert out["distributed"]["launcher"] == "bench.py self-launch" and len(out["distributed"]["devices"]) == 2
     assert out["sharded_frame_equals_unsharded"] is True
     assert out["config"]["parallelism"] == "tile2" and out["value"] > 0
+    # weak scaling is the default: the step grows with the ranks (2 frames per rank's worth of tiles -> 4 frames)
+    assert out["scaling"] == "weak" and out["config"]["views_per_step"] == 4
+
+
+@pytest.mark.gpu
+def test_self_launched_two_rank_rehearsal_strong_and_multi_launch_steps():
+    out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "2", "--warmup", "1",
+                       "--views-per-step", "3", "--scaling", "strong"])
+    assert out["scaling"] == "strong" and out["config"]["views_per_step"] == 3 and out["sharded_frame_equals_unsharded"] is True
+    # 20 x 2 = 40 frames per step = two launches per rank and step (NRF_MAX_VIEWS = 32), at a smaller resolution
+    out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "1", "--warmup", "1",
+                       "--views-per-step", "20", "--width", "640", "--height", "360"])
+    assert out["config"]["views_per_step"] == 40 and out["roofline"]["launches_per_step"] == 2
+    assert out["sharded_frame_equals_unsharded"] is True
 
 
 @pytest.mark.gpu
@@ -84,3 +98,4 @@ def test_self_launched_two_rank_rehearsal_config5_replicas():
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "replica2"
     assert out["config"]["views_per_step"] == 8 and out["config"]["views_per_rank_and_step"] == 4
     assert out["sharded_frame_equals_unsharded"] is True and "800x800" in out["config"]["workload"]
+    assert out["scaling"] == "strong"
