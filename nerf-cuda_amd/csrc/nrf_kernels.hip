@@ -351,6 +351,15 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   unsigned n_lane_trips = 0, n_wave_iters = 0;
 #endif
   NRF_STAMP(t_begin);
+#ifdef NRF_PHASE_TIMING
+  __shared__ unsigned long long wg_first, wg_last;
+  __shared__ unsigned wg_done;
+  if (threadIdx.x == 0) {  // ordered before their use by the barrier of step (1)
+    wg_first = ~0ull;
+    wg_last = 0ull;
+    wg_done = 0u;
+  }
+#endif
   // ---- ray generation + aabb
   const float o[3] = {V.org[0], V.org[1], V.org[2]};
   float d[3];
@@ -587,6 +596,16 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 #ifdef NRF_PHASE_TIMING
   if (lane == 0) {
     NRF_STAMP(t_end);
+    // wave slots a workgroup holds until its slowest tile is done: RENDER_WAVES x (last end - first begin) against
+    // the sum of the waves' own spans (counters[5])
+    atomicMin(&wg_first, t_begin);
+    atomicMax(&wg_last, t_end);
+    __threadfence_block();
+    const unsigned valid_waves = min((unsigned)RENDER_WAVES, (unsigned)(P.n_local_tiles - swz * RENDER_WAVES));
+    if (atomicAdd(&wg_done, 1u) + 1u == valid_waves) {
+      atomicAdd(&counters[12], (unsigned long long)valid_waves * (wg_last - wg_first));
+      atomicAdd(&counters[13], 1ull);
+    }
     atomicAdd(&counters[2], c_march);
     atomicAdd(&counters[3], c_net);
     atomicAdd(&counters[4], c_comp);

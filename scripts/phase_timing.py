@@ -31,3 +31,7 @@ for az in (0, 45, 90):
     print(f"   setup (raygen, SH, box clip, coarse DDA) {100*int(out[10])/tot:.1f}% of wave cycles = {int(out[10])/waves:.0f} cycles/wave")
     print(f"   MFMA tile slots evaluated {slots} = {100*s/max(slots,1):.1f}% filled")
     print(f"   per round: march {m/r:.0f}  network {n/r:.0f}  composite {c/r:.0f} cycles")
+    if int(out[13]):
+        held = int(out[12])
+        print(f"   workgroup hold: {int(out[13])} workgroups held their wave slots for {held/tot:.3f} x the waves' own spans "
+              f"({100*(1-tot/held):.1f}% of the held slot time is a finished wave waiting for the slowest tile of its strip)")
