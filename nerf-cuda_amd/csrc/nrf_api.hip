@@ -176,6 +176,10 @@ struct nrf_context {
   GenModel gen{};  // host copy of the generic instance's description (valid when dm.generic)
   std::vector<float> host_grid;  // the float density grid the march tables were built from
   bool grid_missing = false;     // loaded without a density grid and none generated yet
+  bool allow_persistent = true;  // NRF_PERSISTENT=0 keeps the one-workgroup-per-strip render_kernel (A/B runs)
+  bool centre_out = true;        // NRF_CENTRE_OUT=0: the persistent kernel's queue in row order
+  int block_tiles = 0;           // persistent kernel: tiles per queue entry (NRF_BLOCK_TILES=4|16; 0: per launch)
+  int n_cus = 256;
   nrf_options opt{};
   int W = 0, H = 0;
   int n_local_tiles = 0;
@@ -276,6 +280,8 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.density_scale = c->opt.density_scale;
   P.max_steps = c->opt.max_steps;
   P.march_budget = c->march_budget;
+  P.block_tiles = c->block_tiles;  // 0: the default (launch_render)
+  P.centre_out = c->centre_out ? 1 : 0;
   return NRF_OK;
 }
 
@@ -492,6 +498,18 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   }
   M.dilated_level_words = dilated_level_words;
   if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
+  // The persistent form of the render kernel (one workgroup per CU, waves pull tiles from a queue) keeps every march
+  // table in LDS for the whole launch: hot instance, tables that fit beside its 16 waves' blocks.
+  M.persistent = 0;
+  M.n_cus = (uint32_t)c->n_cus;
+  M.lds_grid_bytes = M.lds_grid_levels = 0;
+  if (c->allow_persistent && !M.generic && !M.wide && M.lds_coarse_words > 0) {
+    const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
+    if ((size_t)render_persistent_lds_fixed_bytes() + tables <= 160u * 1024u) {
+      M.persistent = 1;
+      M.lds_dilated_words = (uint32_t)dilated.size();
+    }
+  }
   c->desc.mean_density = mean_density;
   c->host_grid.assign(density_grid, density_grid + cells);
   return NRF_OK;
@@ -567,11 +585,15 @@ int nrf_create(int device, nrf_context** out) {
     const int b = std::atoi(e);
     if (b >= 1 && b <= 4096) c->march_budget = b;
   }
+  if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_BLOCK_TILES")) c->block_tiles = std::atoi(e);
+  if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES));
+  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES + 128 + 65536));  // + the persistent kernel's work-queue counter (+ the diagnostic build's per-wave stamps)
   HIP_TRY(hipMemset(c->d_counters, 0, COUNTER_BYTES));
   *out = c;
   return NRF_OK;
@@ -963,8 +985,16 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
   HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) {
     out[i] = 0;
-    for (int sl = 0; sl < COUNTER_SLOTS; ++sl) out[i] += raw[sl * 16 + i];
+    for (int sl = 0; sl < COUNTER_SLOTS; ++sl) out[i] = i == 14 ? std::max(out[i], raw[sl * 16 + i]) : out[i] + raw[sl * 16 + i];  // 14: a maximum
   }
+  return NRF_OK;
+}
+
+// Diagnostic build: entry / exit stamps (s_memtime) of the persistent kernel's waves, 2 x n values.
+extern "C" int nrf_debug_wave_times(nrf_context* c, unsigned long long* out, int n_waves) {
+  if (!c || !out || n_waves < 1 || n_waves > 4096) return fail(NRF_E_INVALID, "bad argument");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipMemcpy(out, (char*)c->d_counters + COUNTER_BYTES + 128, (size_t)n_waves * 16, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
 

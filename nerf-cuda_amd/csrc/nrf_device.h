@@ -114,6 +114,10 @@ struct DevModel {
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
   uint32_t lds_dilated_words;  // words of occ_dilated that fit the (not yet used) weight area of LDS during ray setup (0: global)
+  uint32_t persistent;      // 1: render_persistent_kernel may render this model (hot instance, every march table in LDS)
+  uint32_t n_cus;           // compute units of the device: workgroups of the persistent kernel
+  uint32_t lds_grid_bytes;  // persistent kernel: leading bytes of the hash table kept in LDS (levels 0 .. lds_grid_levels - 1)
+  uint32_t lds_grid_levels;
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.
@@ -123,6 +127,10 @@ struct ViewParams {
   float cam[4];  // fl_x, fl_y, cx, cy
   int roi[4];    // x0, y0, x1, y1 (pixels, inclusive): no ray outside this rectangle enters the box of occupied
                  // cells (host: conservative projection of its corners, nrf_api.hip view_roi); x1 < x0: empty
+  // persistent kernel: the local tiles [k_lo, k_hi) (multiples of 4 = whole strips) cover every strip row the
+  // rectangle touches; they are dealt to the waves through the work queue, positions [q_begin, q_begin + k_hi - k_lo)
+  // of it; the view's other tiles are background and are filled without the queue
+  int k_lo, k_hi, q_begin;
 };
 // Statistics counters: COUNTER_SLOTS copies of 16 x u64 (one 128-byte line each); a workgroup adds to copy
 // blockIdx % COUNTER_SLOTS.  Device-scope atomics on ONE address serialise at ~12 ns each across the 8 XCDs:
@@ -134,6 +142,7 @@ struct ViewBatch {
   ViewParams v[MAX_VIEWS];
   int n_views;
   int blocks_per_view;                 // workgroups per view: block b renders view b / blocks_per_view
+  int q_total;                         // persistent kernel: entries of the work queue (sum over views of k_hi - k_lo)
   unsigned long long view_stride_px;   // pixels between consecutive views in the output planes
 };
 
@@ -149,6 +158,8 @@ struct FrameParams {
   float bg_color, min_near, dt_gamma, density_scale;
   int max_steps;
   int march_budget;  // cell trips a lane may spend per round (tuning knob, default 256)
+  int block_tiles;  // persistent kernel: tiles per queue entry, 4 (one strip) or 16 (4 x 4 tiles)
+  int centre_out;   // persistent kernel: a view's strip rows are queued from the middle of its region of interest outwards
 };
 
 // ------------------------------------------------------------------ misc ----

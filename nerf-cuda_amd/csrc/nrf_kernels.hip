@@ -24,6 +24,9 @@ namespace nrf {
 #ifndef NRF_SLOTS
 #define NRF_SLOTS 64
 #endif
+#ifndef NRF_PRIO_ROUNDS
+#define NRF_PRIO_ROUNDS 16
+#endif
 constexpr int SLOTS = NRF_SLOTS;  // sample slots a wave fills per round
 struct WaveLds {
   union {
@@ -274,6 +277,149 @@ __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
     for (int i = threadIdx.x; i < 4 * (RK_WIDE - 1) * 64; i += blockDim.x) wl[N_FRAGS * 64 + i] = M.wfrag[FRAG_R0X * 64 + i];
 }
 
+// What a ray has composited so far, and a wave's statistics (both live in registers).
+struct TileAcc {
+  float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+};
+struct TileStats {
+  unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;  // slots: 16-sample MFMA tiles evaluated x 16 (padding included)
+#ifdef NRF_PHASE_TIMING
+  unsigned long long c_march = 0, c_net = 0, c_comp = 0;
+  unsigned n_lane_trips = 0, n_wave_iters = 0;
+#endif
+};
+
+constexpr unsigned PRIO_ROUNDS = NRF_PRIO_ROUNDS;
+// The rounds of one 8x8 tile (one wave, no workgroup barrier inside): march -> network -> compositing until no ray
+// of the tile is alive.  t / tc / alive: the rays' state after ray generation and the visibility walk.
+template <int NET, bool COARSE_LDS, int MARCH, bool PRIORITY = false>
+__device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams& P, const MarchConst& mc, const LdsMap& lm,
+                                            const uint32_t* coarse_lds, const float* ctab_lds, int lane, const float (&o)[3],
+                                            const float (&d)[3], float rdx, float rdy, float rdz, int sx, int sy, int sz,
+                                            float far_m, float t_skip, float t, float tc, bool alive, TileAcc& acc,
+                                            TileStats& ts) {
+  const uint4* wl = lm.wl;
+  const LevelParams* lvs = lm.lvs;
+  WaveLds* W = lm.W;
+  float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  int n_ray_samples = 0;
+#ifdef NRF_PHASE_TIMING
+  unsigned long long c_march = 0, c_net = 0, c_comp = 0;
+  unsigned n_lane_trips = 0, n_wave_iters = 0;
+#endif
+  unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;
+
+  while (true) {
+    if (__ballot(alive) == 0ull) break;
+    NRF_STAMP(t0);
+    // ---- march: ballot/mbcnt compaction of the found samples, k-major, into the wave's LDS slots
+    unsigned long long slots = 0ull;
+    int cnt = 0, S = 0;
+    int budget = P.march_budget;
+    bool marching = alive;
+    bool ended = false;  // t >= far or sample cap: the ray dies after compositing this round's samples
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long mm = __ballot(marching);
+      if (mm == 0ull || S + __popcll(mm) > SLOTS) break;
+      float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
+      bool found = false;
+#ifdef NRF_PHASE_TIMING
+      const int budget_before = budget;
+#endif
+      if (marching) {
+        const int r = COARSE_LDS ? march_next<true, MARCH>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                                    rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt)
+                                 : march_next<false, MARCH_GENERIC>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
+                                                     rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt);
+        found = r == MARCH_FOUND;
+        marching = found;
+        ended = ended || r == MARCH_EXHAUSTED;
+      }
+#ifdef NRF_PHASE_TIMING
+      {
+        int used = budget_before - budget;
+        n_lane_trips += (unsigned)used;
+        for (int o = 32; o; o >>= 1) used = max(used, __shfl_xor(used, o));
+        n_wave_iters += (unsigned)used;
+      }
+#endif
+      const unsigned long long fm = __ballot(found);
+      if (found) {
+        const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        const float tn = t + dt;        // march: t += dt
+        const float delta = tn - tc;    // deltas[1] = t - last_t (last_t == composited t)
+        tc = tc + delta;                // composite: t += deltas[1]
+        t = tc;                         // next march starts from rays_t
+        W->pos[slot] = make_float4(x, y, z, __builtin_bit_cast(float, lane));
+        W->aux[slot] = make_float2(dt, tc);
+        slots |= (unsigned long long)slot << (8 * k);
+        cnt++;
+        if (n_ray_samples + cnt >= P.max_steps) { marching = false; ended = true; }
+      }
+      S += __popcll(fm);
+    }
+    wave_sync();
+    NRF_STAMP(t1);
+
+    if (S > 0) {
+      // ---- network on the S queued samples (sample-major MFMA tiles)
+      network_dispatch<NET>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
+      wave_sync();
+    }
+    NRF_STAMP(t2);
+
+    // ---- alpha compositing, R/include/nerf-cuda/render_utils.h:699-743
+    if (alive) {
+      bool terminated = false;
+      for (int k = 0; k < 8; ++k) {
+        if (k >= cnt) break;
+        const int slot = (int)((slots >> (8 * k)) & 0xffull);
+        const float4 so = W->out[slot];
+        const float2 dtc = W->aux[slot];
+        const float alpha = 1.0f - __expf(-so.w * dtc.x);
+        const float T = 1 - ws;
+        const float wgt = alpha * T;
+        ws += wgt;
+        dep += wgt * dtc.y;  // depth += weight * t, t = composited t of this sample
+        cr += wgt * so.x;
+        cg += wgt * so.y;
+        cb += wgt * so.z;
+        // `T < 1e-4` against a double literal: true exactly for T <= 9.99999974737875e-05f
+        if (T <= 9.99999974737875e-05f) { terminated = true; break; }
+      }
+      n_ray_samples += cnt;
+      alive = !(terminated || ended);
+    }
+    wave_sync();
+    NRF_STAMP(t3);
+    NRF_ACC(c_march, t0, t1);
+    NRF_ACC(c_net, t1, t2);
+    NRF_ACC(c_comp, t2, t3);
+    n_samples += (unsigned)S;
+    n_rounds++;
+    n_tile_slots += (unsigned)((S + 15) & ~15);
+    if constexpr (PRIORITY) {
+      // Long tiles first: among the waves of a SIMD the arbiter prefers the higher s_setprio level and, within a level,
+      // the OLDEST wave -- in a persistent workgroup that is always the same one (measured: the four youngest waves of
+      // a workgroup needed 920 cycles per sample, the four oldest 610).  A tile that has been running for many rounds
+      // is the one a frame ends up waiting for: it climbs a level every PRIO_ROUNDS rounds.
+      if (n_rounds == PRIO_ROUNDS) __builtin_amdgcn_s_setprio(1);
+      else if (n_rounds == 2 * PRIO_ROUNDS) __builtin_amdgcn_s_setprio(2);
+      else if (n_rounds == 3 * PRIO_ROUNDS) __builtin_amdgcn_s_setprio(3);
+    }
+  }
+  if constexpr (PRIORITY) __builtin_amdgcn_s_setprio(0);
+
+  acc.ws = ws; acc.dep = dep; acc.cr = cr; acc.cg = cg; acc.cb = cb;
+  ts.n_samples += n_samples;
+  ts.n_rounds += n_rounds;
+  ts.n_tile_slots += n_tile_slots;
+#ifdef NRF_PHASE_TIMING
+  ts.c_march += c_march; ts.c_net += c_net; ts.c_comp += c_comp;
+  ts.n_lane_trips += n_lane_trips; ts.n_wave_iters += n_wave_iters;
+#endif
+}
+
 // ------------------------------------------------------- the render kernel ----
 // 256 threads, >= 4 waves per SIMD (four workgroups per CU, 39.9 KB of LDS each): caps the kernel at
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
@@ -319,11 +465,11 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   rgba += (size_t)view * VB.view_stride_px;
   depth += (size_t)view * VB.view_stride_px;
   const int swz = (int)blockIdx.x - view * VB.blocks_per_view;
+  const int strips_x = (P.tiles_x + 3) >> 2;
   const int k_local = swz * RENDER_WAVES + wave;
   const bool valid_tile = k_local < P.n_local_tiles;  // wave-uniform; padding waves still take the barriers below
   // partition unit = a strip of 4 horizontally adjacent tiles (one workgroup): strip s belongs to
   // rank s % shard_count, local strip index s / shard_count (nerfhip.h nrf_options)
-  const int strips_x = (P.tiles_x + 3) >> 2;
   const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
   const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
   const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
@@ -346,10 +492,6 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
     }
   }
 
-#ifdef NRF_PHASE_TIMING
-  unsigned long long c_march = 0, c_net = 0, c_comp = 0;
-  unsigned n_lane_trips = 0, n_wave_iters = 0;
-#endif
   NRF_STAMP(t_begin);
 #ifdef NRF_PHASE_TIMING
   __shared__ unsigned long long wg_first, wg_last;
@@ -479,100 +621,16 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   }
   if (!valid_tile) return;  // no barrier after this point
   NRF_STAMP(t_setup_done);
-  float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-  int n_ray_samples = 0;
-  unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;  // slots: 16-sample MFMA tiles evaluated x 16 (padding included)
-
-  while (true) {
-    if (__ballot(alive) == 0ull) break;
-    NRF_STAMP(t0);
-    // ---- march: ballot/mbcnt compaction of the found samples, k-major, into the wave's LDS slots
-    unsigned long long slots = 0ull;
-    int cnt = 0, S = 0;
-    int budget = P.march_budget;
-    bool marching = alive;
-    bool ended = false;  // t >= far or sample cap: the ray dies after compositing this round's samples
-    for (int k = 0; k < 8; ++k) {
-      const unsigned long long mm = __ballot(marching);
-      if (mm == 0ull || S + __popcll(mm) > SLOTS) break;
-      float x = 0.f, y = 0.f, z = 0.f, dt = 0.f;
-      bool found = false;
+  TileAcc acc;
+  TileStats ts;
+  tile_rounds<NET, COARSE_LDS, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+                                      alive, acc, ts);
+  const float ws = acc.ws, dep = acc.dep, cr = acc.cr, cg = acc.cg, cb = acc.cb;
+  const unsigned n_samples = ts.n_samples, n_rounds = ts.n_rounds, n_tile_slots = ts.n_tile_slots;
 #ifdef NRF_PHASE_TIMING
-      const int budget_before = budget;
+  const unsigned long long c_march = ts.c_march, c_net = ts.c_net, c_comp = ts.c_comp;
+  const unsigned n_lane_trips = ts.n_lane_trips, n_wave_iters = ts.n_wave_iters;
 #endif
-      if (marching) {
-        const int r = COARSE_LDS ? march_next<true, MARCH>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                    rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt)
-                                 : march_next<false, MARCH_GENERIC>(mc, M.occ_bits, nullptr, M.cell_bound, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
-                                                     rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt);
-        found = r == MARCH_FOUND;
-        marching = found;
-        ended = ended || r == MARCH_EXHAUSTED;
-      }
-#ifdef NRF_PHASE_TIMING
-      {
-        int used = budget_before - budget;
-        n_lane_trips += (unsigned)used;
-        for (int o = 32; o; o >>= 1) used = max(used, __shfl_xor(used, o));
-        n_wave_iters += (unsigned)used;
-      }
-#endif
-      const unsigned long long fm = __ballot(found);
-      if (found) {
-        const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
-        const float tn = t + dt;        // march: t += dt
-        const float delta = tn - tc;    // deltas[1] = t - last_t (last_t == composited t)
-        tc = tc + delta;                // composite: t += deltas[1]
-        t = tc;                         // next march starts from rays_t
-        W->pos[slot] = make_float4(x, y, z, __builtin_bit_cast(float, lane));
-        W->aux[slot] = make_float2(dt, tc);
-        slots |= (unsigned long long)slot << (8 * k);
-        cnt++;
-        if (n_ray_samples + cnt >= P.max_steps) { marching = false; ended = true; }
-      }
-      S += __popcll(fm);
-    }
-    wave_sync();
-    NRF_STAMP(t1);
-
-    if (S > 0) {
-      // ---- network on the S queued samples (sample-major MFMA tiles)
-      network_dispatch<NET>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
-      wave_sync();
-    }
-    NRF_STAMP(t2);
-
-    // ---- alpha compositing, R/include/nerf-cuda/render_utils.h:699-743
-    if (alive) {
-      bool terminated = false;
-      for (int k = 0; k < 8; ++k) {
-        if (k >= cnt) break;
-        const int slot = (int)((slots >> (8 * k)) & 0xffull);
-        const float4 so = W->out[slot];
-        const float2 dtc = W->aux[slot];
-        const float alpha = 1.0f - __expf(-so.w * dtc.x);
-        const float T = 1 - ws;
-        const float wgt = alpha * T;
-        ws += wgt;
-        dep += wgt * dtc.y;  // depth += weight * t, t = composited t of this sample
-        cr += wgt * so.x;
-        cg += wgt * so.y;
-        cb += wgt * so.z;
-        // `T < 1e-4` against a double literal: true exactly for T <= 9.99999974737875e-05f
-        if (T <= 9.99999974737875e-05f) { terminated = true; break; }
-      }
-      n_ray_samples += cnt;
-      alive = !(terminated || ended);
-    }
-    wave_sync();
-    NRF_STAMP(t3);
-    NRF_ACC(c_march, t0, t1);
-    NRF_ACC(c_net, t1, t2);
-    NRF_ACC(c_comp, t2, t3);
-    n_samples += (unsigned)S;
-    n_rounds++;
-    n_tile_slots += (unsigned)((S + 15) & ~15);
-  }
 
   // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
   if (in_img) {
@@ -601,7 +659,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
     atomicMin(&wg_first, t_begin);
     atomicMax(&wg_last, t_end);
     __threadfence_block();
-    const unsigned valid_waves = min((unsigned)RENDER_WAVES, (unsigned)(P.n_local_tiles - swz * RENDER_WAVES));
+    const unsigned valid_waves = min((unsigned)RENDER_WAVES, (unsigned)(P.n_local_tiles - (k_local - wave)));
     if (atomicAdd(&wg_done, 1u) + 1u == valid_waves) {
       atomicAdd(&counters[12], (unsigned long long)valid_waves * (wg_last - wg_first));
       atomicAdd(&counters[13], 1ull);
@@ -618,6 +676,312 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 #ifdef NRF_PHASE_TIMING
   {
     unsigned lt = n_lane_trips;
+    for (int o = 32; o; o >>= 1) lt += __shfl_xor(lt, o);
+    if (lane == 0) atomicAdd(&counters[8], (unsigned long long)lt);
+  }
+#endif
+}
+
+// ---------------------------------------------------- the persistent form ----
+// The same tile program as render_kernel, hot instance only, with the scheduling turned inside out: ONE workgroup of
+// PERSIST_WAVES waves per CU stays for the whole launch, stages the weight fragments, the level table and every march
+// table (coarse + dilated occupancy, cell boundaries) into LDS once, and then every WAVE on its own pulls 8x8 tiles from
+// a work queue (one device-scope atomic per tile, issued one tile ahead) until the queue is empty.  Against
+// render_kernel this removes (a) the wave slots a 4-tile workgroup holds until its slowest tile is done (7-8 % of the
+// slot time, profiles/r02/phase_timing_wg_hold.txt), (b) the per-strip staging of ~29 KB and its three barriers, and
+// (c) the borrowing of the weight area by the dilated table.  The queue only holds the strip rows a view's region of
+// interest touches; the rest of the frame is background and is filled by a static sweep once a wave finds the queue
+// empty (no atomics: same-address device atomics cost ~12 ns each, see COUNTER_SLOTS).
+// Exit: every wave leaves its loop when its fetched queue position is >= the total, which every fetch sequence
+// reaches (the counter only grows); no wave waits for another one after the staging barrier.
+constexpr int PERSIST_WAVES = 16;
+constexpr int PERSIST_THREADS = 64 * PERSIST_WAVES;
+constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4;  // q_begin of every view + the total; the workgroup's block counter
+
+__device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, float* depth, int k_local, int lane, int px, int py,
+                                            bool in_img, float4 color, float dn) {
+  if (in_img) {
+    const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
+    rgba[idx] = color;
+    depth[idx] = dn;
+  } else if (P.tile_major) {  // padding pixels of a shard's tile-major buffer
+    const size_t idx = (size_t)k_local * 64 + lane;
+    rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    depth[idx] = 0.f;
+  }
+}
+
+// The kernel's by-value arguments as they lie in the kernarg segment (the tile loop re-reads them per tile through a
+// pointer the compiler cannot see through: otherwise every field of the three structs is hoisted out of the loop and
+// kept in -- that is: spilled from -- SGPRs for the whole launch, 177 v_readlane in the march and network loops).
+struct PersistArgs {
+  DevModel M;
+  FrameParams P;
+  ViewBatch VB;
+};
+
+template <int MARCH>
+__global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
+                                                                              float4* __restrict__ rgba0, float* __restrict__ depth0,
+                                                                              unsigned long long* __restrict__ counters,
+                                                                              unsigned* __restrict__ queue) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  typedef const PersistArgs __attribute__((address_space(4))) * KArgPtr;
+  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevModel& M = M0;
+  const FrameParams& P = P0;
+  const ViewBatch& VB = VB0;
+  const LdsMap lm = lds_map<NET_HOT>(smem, M, wave, PERSIST_WAVES);
+  uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(lm.tables);
+  float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
+  uint32_t* dil_lds = reinterpret_cast<uint32_t*>(ctab_lds + M.lds_ctab_floats);
+  int* q_lds = reinterpret_cast<int*>(dil_lds + M.lds_dilated_words);
+  unsigned* sched = reinterpret_cast<unsigned*>(q_lds + MAX_VIEWS + 1);
+  // ---- staged once per workgroup (= once per CU and launch)
+  stage_fragments<NET_HOT>(M, lm.wl);
+  for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
+  for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
+  for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
+  if (threadIdx.x < 16) lm.lvs[threadIdx.x] = M.lv[threadIdx.x];
+  if (threadIdx.x <= MAX_VIEWS) {
+    const int v = (int)threadIdx.x;
+    q_lds[v] = v < VB.n_views ? VB.v[v].q_begin : VB.q_total;
+  }
+  if (threadIdx.x == 0) *sched = (unsigned)blockIdx.x << 5;  // the first block needs no atomic: the queue starts at gridDim.x
+  __syncthreads();
+
+  const MarchConst mc = march_const(M, P.dt_gamma);
+  TileStats ts;
+  const unsigned q_total = (unsigned)VB0.q_total;
+  NRF_STAMP(t_loop_begin);
+#ifdef NRF_PHASE_TIMING
+  unsigned long long c_sched = 0;
+#endif
+  while (true) {
+    NRF_STAMP(t_sched0);
+    // ---- next tile: the workgroup's current block (16 tiles) is dealt through an LDS counter; the wave that finds it
+    // used up fetches the next block from the global queue (one device-scope atomic per 16 tiles) and publishes it.
+    // sched = block << 5 | tiles taken; a block number >= q_total ends every wave's loop.
+    unsigned blk, bt;
+    const unsigned B = (unsigned)P0.block_tiles;
+    while (true) {
+      unsigned old = 0u;
+      if (lane == 0) old = atomicAdd(sched, 1u);
+      old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+      blk = old >> 5;
+      bt = old & 31u;
+      if (blk >= q_total || bt < B) break;
+      if (bt == B) {  // this wave refills: tile 0 of the new block is its own
+        unsigned nb = 0u;
+        if (lane == 0) nb = atomicAdd(queue, 1u);
+        nb = (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
+        if (lane == 0) __hip_atomic_store(sched, (nb << 5) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        blk = nb;
+        bt = 0u;
+        break;
+      }
+      // another wave is refilling: wait until the block number changes, then try again
+      while ((__hip_atomic_load(sched, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 5) == blk) __builtin_amdgcn_s_sleep(2);
+    }
+    NRF_STAMP(t_sched1);
+    NRF_ACC(c_sched, t_sched0, t_sched1);
+    if (blk >= q_total) break;
+    asm volatile("" : "+s"(ka));  // this tile's argument loads are this tile's (see PersistArgs)
+    const DevModel& M = *(const DevModel*)&ka->M;
+    const FrameParams& P = *(const FrameParams*)&ka->P;
+    const ViewBatch& VB = *(const ViewBatch*)&ka->VB;
+    // block -> (view, local tile)
+    const int qb = q_lds[lane < MAX_VIEWS ? lane : MAX_VIEWS];
+    const int view = __popcll(__ballot(lane < VB.n_views && (int)blk >= qb)) - 1;  // wave-uniform
+    const ViewParams& V = VB.v[view];
+    const int bl = (int)blk - V.q_begin;
+    // Centre-out: the queue visits a view's block rows (sharded: its blocks) in the order c, c + 1, c - 1, c + 2, ...
+    // from the middle of the region of interest, where the rays cross the most of the object, so that a view's last
+    // tiles are its lightest ones (in row order a heavy tile picked up late was a 30-40 % tail on a single frame).
+    const bool co = P.centre_out != 0;
+    auto centre_out = [co](int j, int n) { const int off = (j + 1) >> 1; return co ? (n - 1) / 2 + ((j & 1) ? off : -off) : j; };
+    int k_local;
+    if (P.shard_count == 1 && P.block_tiles == 16) {  // a block = 4 x 4 tiles (32 x 32 pixels): the strips of one column in 4 consecutive rows
+      const int sxn = (P.tiles_x + 3) >> 2;
+      const int n_rows = (V.k_hi - V.k_lo + 16 * sxn - 1) / (16 * sxn);
+      const int row = V.k_lo / (4 * sxn) + centre_out(bl / sxn, n_rows) * 4 + (int)(bt >> 2);
+      k_local = (row * sxn + bl % sxn) * 4 + (int)(bt & 3u);
+    } else if (P.shard_count == 1) {  // a block = one strip (small launches: finer balance between the CUs)
+      const int sxn = (P.tiles_x + 3) >> 2;
+      const int n_rows = (V.k_hi - V.k_lo) / (4 * sxn);
+      const int row = V.k_lo / (4 * sxn) + centre_out(bl / sxn, n_rows);
+      k_local = (row * sxn + bl % sxn) * 4 + (int)bt;
+    } else {                   // a block = 4 (or 1) consecutive local strips
+      k_local = V.k_lo + centre_out(bl, (V.k_hi - V.k_lo + P.block_tiles - 1) / P.block_tiles) * P.block_tiles + (int)bt;
+    }
+    if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last block (row)
+    float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
+    float* depth = depth0 + (size_t)view * VB.view_stride_px;
+    const int strips_x = (P.tiles_x + 3) >> 2;
+    const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
+    const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
+    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const bool in_img = px < P.W && py < P.H;
+    const float4 background = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
+    // the tile's own 8x8 pixels against the region of interest (render_kernel tests the strip's 32x8)
+    if (tx * 8 > V.roi[2] || tx * 8 + 7 < V.roi[0] || ty * 8 > V.roi[3] || ty * 8 + 7 < V.roi[1]) {
+      store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, background, 0.f);
+      continue;
+    }
+    NRF_STAMP(t_begin);
+#ifdef NRF_PHASE_TIMING
+    const unsigned samples_before = ts.n_samples;
+#endif
+    // ---- ray generation + aabb (as render_kernel)
+    const float o[3] = {V.org[0], V.org[1], V.org[2]};
+    float d[3];
+    ray_dir(V.R, V.cam, px, py, d);
+    float near, far;
+    near_far(M.aabb, o, d, P.min_near, near, far);
+    const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+    const int sx = __builtin_signbitf(d[0]) ? 0 : 1;
+    const int sy = __builtin_signbitf(d[1]) ? 0 : 1;
+    const int sz = __builtin_signbitf(d[2]) ? 0 : 1;
+    float t = near, tc = near;
+    bool alive = in_img && (near < far);
+    float far_m = far, t_skip = near, t_in, t_out;
+    box_interval(M.occ_box, o, rdx, rdy, rdz, t_in, t_out);
+    const bool nan = !(t_in == t_in) || !(t_out == t_out);
+    {
+      const bool hits = (M.occ_box[0] <= M.occ_box[3]) && (t_in <= t_out) && (t_out > near);
+      if (t_out < far_m) far_m = t_out;
+      if (nan) far_m = far;
+      alive = alive && (hits || nan);
+    }
+    if (M.occ_dilated != nullptr && alive && !nan) {  // the visibility walk, on this workgroup's own copy of the table
+      const int Hc = (int)(M.H >> 2);
+      const float t_box0 = fmaxf(t_in, near);
+      bool any = false;
+      float first = far_m, last = t_box0;
+      const uint32_t n_casc = MARCH == MARCH_UNIT ? 1u : M.cascade;
+      for (uint32_t k = 0; k < n_casc; ++k) {
+        const float mb = (n_casc > 1) ? fminf(ldexpf(1.0f, (int)k), M.bound) : fminf(1.0f, M.bound);
+        float c_in = t_box0, c_out = far_m;
+        if (n_casc > 1) {
+          const float cube[6] = {-mb, -mb, -mb, mb, mb, mb};
+          float a, b;
+          box_interval(cube, o, rdx, rdy, rdz, a, b);
+          if (a == a && b == b) {
+            c_in = fmaxf(c_in, a);
+            c_out = fminf(c_out, b);
+          }
+        }
+        if (!(c_in < c_out)) continue;
+        float t_last, t_first;
+        if (coarse_visibility(dil_lds + (size_t)k * M.dilated_level_words, Hc, mb, o, d, rdx, rdy, rdz, c_in, c_out, t_first, t_last)) {
+          any = true;
+          first = fminf(first, t_first);
+          last = fmaxf(last, t_last);
+        }
+      }
+      alive = any;
+      if (last < far_m) far_m = last;
+      if (any) t_skip = first;
+    }
+    TileAcc acc;
+    if (__ballot(alive) != 0ull) {
+      if (alive) {  // direction encoding of the rays that will evaluate the network
+        float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
+        float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
+        float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
+        half_t e[16];
+        encode_dir16(M, u0, u1, u2, e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          half2_t h;
+          h.x = e[2 * j];
+          h.y = e[2 * j + 1];
+          lm.W->dirf[lane][j] = h2_bits(h);
+        }
+      }
+      wave_sync();
+      NRF_STAMP(t_setup_done);
+      tile_rounds<NET_HOT, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+                                        alive, acc, ts);
+#ifdef NRF_PHASE_TIMING
+      if (lane == 0) {
+        NRF_STAMP(t_end);
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SLOTS) * 16 + 5], t_end - t_begin);
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SLOTS) * 16 + 6], 1ull);
+        atomicAdd(&counters[(blockIdx.x % COUNTER_SLOTS) * 16 + 10], t_setup_done - t_begin);
+      }
+#endif
+    }
+    // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264
+    const float bgw = (1 - acc.ws) * P.bg_color;
+    const float span = far - near;
+    float dn = span > 0.0f ? fmaxf(acc.dep - near, 0.0f) / span : 0.0f;
+#ifdef NRF_PHASE_TIMING
+    if (P.march_budget == 4095) {  // diagnostic: the depth plane carries the tile's cost (cycles / 1e6) and start time instead
+      NRF_STAMP(t_tile_end);
+      const unsigned hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all 32 bits
+      dn = (lane & 7) == 1 ? (float)(t_tile_end - t_begin) * 1e-6f
+         : (lane & 7) == 2 ? (float)(ts.n_samples - samples_before) * 1e-3f
+         : (lane & 7) == 3 ? (float)bt
+         : (lane & 7) == 4 ? (float)((hw_id >> 4) & 3u)   // SIMD_ID
+         : (lane & 7) == 5 ? (float)wave
+         : (lane & 7) == 6 ? (float)(hw_id & 15u)          // WAVE_ID (slot)
+         : (float)(t_begin - t_loop_begin) * 1e-6f;
+    }
+#endif
+    store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
+  }
+
+#ifdef NRF_PHASE_TIMING
+  if (lane == 0) {  // how long this wave was in the tile loop (sum, count, maximum) and how much of it waiting for a tile
+    NRF_STAMP(t_loop_end);
+    unsigned long long* cs = counters + (blockIdx.x % COUNTER_SLOTS) * 16;
+    atomicAdd(&cs[12], t_loop_end - t_loop_begin);
+    atomicAdd(&cs[13], 1ull);
+    atomicMax(&cs[14], t_loop_end - t_loop_begin);
+    atomicAdd(&cs[15], c_sched);
+    // absolute entry / exit stamps of every wave (nrf_debug_wave_times)
+    unsigned long long* wt = counters + COUNTER_SLOTS * 16 + 16 + 2 * ((size_t)blockIdx.x * PERSIST_WAVES + wave);
+    wt[0] = t_loop_begin;
+    wt[1] = t_loop_end;
+  }
+#endif
+  // ---- the tiles the queue does not hold are background: a static sweep, one tile per wave and step
+  {
+    const float4 background = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
+    const int n_waves = (int)gridDim.x * PERSIST_WAVES;
+    const int strips_x = (P.tiles_x + 3) >> 2;
+    for (int view = 0; view < VB.n_views; ++view) {
+      const ViewParams& V = VB.v[view];
+      float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
+      float* depth = depth0 + (size_t)view * VB.view_stride_px;
+      const int outside = P.n_local_tiles - (min(V.k_hi, P.n_local_tiles) - V.k_lo);  // tiles before k_lo and from k_hi on
+      for (int i = (int)blockIdx.x * PERSIST_WAVES + wave; i < outside; i += n_waves) {
+        const int k_local = i < V.k_lo ? i : i + (min(V.k_hi, P.n_local_tiles) - V.k_lo);
+        const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
+        const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
+        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+        store_pixel(P, rgba, depth, k_local, lane, px, py, px < P.W && py < P.H, background, 0.f);
+      }
+    }
+  }
+  counters += (blockIdx.x % COUNTER_SLOTS) * 16;
+  if (lane == 0 && ts.n_rounds != 0) {
+    atomicAdd(&counters[0], (unsigned long long)ts.n_samples);
+    atomicAdd(&counters[1], (unsigned long long)ts.n_rounds);
+    atomicAdd(&counters[11], (unsigned long long)ts.n_tile_slots);
+#ifdef NRF_PHASE_TIMING
+    atomicAdd(&counters[2], ts.c_march);
+    atomicAdd(&counters[3], ts.c_net);
+    atomicAdd(&counters[4], ts.c_comp);
+    atomicAdd(&counters[9], (unsigned long long)ts.n_wave_iters);
+#endif
+  }
+#ifdef NRF_PHASE_TIMING
+  {
+    unsigned lt = ts.n_lane_trips;
     for (int o = 32; o; o >>= 1) lt += __shfl_xor(lt, o);
     if (lane == 0) atomicAdd(&counters[8], (unsigned long long)lt);
   }
@@ -1056,14 +1420,68 @@ static hipError_t allow_lds(K kernel, int bytes) {
 }
 static int gen_lds_bytes(const DevModel& M, int waves) { return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)M.gen_wave_bytes); }
 
-hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
+hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
                          hipStream_t st) {
   ViewBatch VB = VBin;
+  FrameParams P = Pin;
+  // persistent kernel: a queue entry is one strip (4 tiles).  Blocks of 4 x 4 tiles (NRF_BLOCK_TILES=16) were measured 2 %
+  // slower in 16-view launches and 13 % slower for one view alone: the 16 tiles of a block at the object's centre are half of
+  // a CU's share of a 1080p frame, and the extra L1 sharing between its strips is worth less than the finer balance.
+  if (P.block_tiles != 4 && P.block_tiles != 16) P.block_tiles = 4;
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
-  if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return hipSuccess;
-  if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
+  if (M.persistent && !M.generic && !M.wide && lds_tab) {
+    // work queue: per view the local strips of every strip row its region of interest touches
+    const int strips_x = (P.tiles_x + 3) >> 2, N = P.shard_count, idx = P.shard_index;
+    const int k_end = (P.n_local_tiles + 3) & ~3;
+    int q = 0;
+    for (int v = 0; v < VB.n_views; ++v) {
+      ViewParams& V = VB.v[v];
+      V.k_lo = V.k_hi = 0;
+      int block_rows = 0;
+      if (V.roi[2] >= V.roi[0] && V.roi[3] >= V.roi[1]) {
+        const int ty0 = std::max(V.roi[1] >> 3, 0), ty1 = std::min(V.roi[3] >> 3, P.tiles_y - 1);
+        if (ty1 >= ty0) {
+          const int s0 = ty0 * strips_x, s1 = (ty1 + 1) * strips_x;  // global strips [s0, s1)
+          const int ls0 = s0 > idx ? (s0 - idx + N - 1) / N : 0, ls1 = s1 > idx ? (s1 - idx + N - 1) / N : 0;
+          V.k_lo = std::min(4 * ls0, k_end);
+          V.k_hi = std::min(4 * ls1, k_end);
+          if (N == 1 && P.block_tiles == 16) {  // whole block rows (the last one may reach below the image: those tiles are skipped)
+            block_rows = (ty1 - ty0 + 4) / 4;
+            V.k_hi = std::min((ty0 + 4 * block_rows) * strips_x * 4, k_end);
+          }
+        }
+      }
+      V.q_begin = q;
+      // queue entries are blocks of 16 tiles: unsharded 4 x 4 tiles (strip column x 4 rows), else 4 consecutive local strips
+      q += (N == 1 && P.block_tiles == 16) ? block_rows * strips_x : (V.k_hi - V.k_lo + P.block_tiles - 1) / P.block_tiles;
+    }
+    VB.q_total = q;
+    const int lds = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) +
+                    4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) + LDS_QUEUE_BYTES;
+    const long long tiles = (long long)P.n_local_tiles * VB.n_views;
+    const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + PERSIST_WAVES - 1) / PERSIST_WAVES));
+    unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue, wgs, 1, st);  // every workgroup's first block is its own index
+    if (e != hipSuccess) return e;
+    const bool pow2_h = (M.H & (M.H - 1)) == 0;
+    int eb = 0;
+    const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
+    const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+#define NRF_LAUNCH_PERSISTENT(U)                                                                                          \
+  do {                                                                                                                   \
+    e = allow_lds(render_persistent_kernel<U>, lds);                                                                     \
+    if (e != hipSuccess) return e;                                                                                       \
+    hipLaunchKernelGGL((render_persistent_kernel<U>), dim3(wgs), dim3(PERSIST_THREADS), lds, st, M, P, VB, (float4*)rgba, \
+                       (float*)depth, (unsigned long long*)counters, queue);                                             \
+  } while (0)
+    if (unit) NRF_LAUNCH_PERSISTENT(MARCH_UNIT);
+    else if (pow2) NRF_LAUNCH_PERSISTENT(MARCH_POW2);
+    else NRF_LAUNCH_PERSISTENT(MARCH_GENERIC);
+#undef NRF_LAUNCH_PERSISTENT
+    return hipGetLastError();
+  }
   const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
                               : (M.wide ? LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES
                                         : LDS_FIXED_BYTES);
@@ -1232,6 +1650,7 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
 }
 
 int render_lds_bytes() { return LDS_FIXED_BYTES; }
+int render_persistent_lds_fixed_bytes() { return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES; }
 int render_wide_lds_fixed_bytes() { return LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
 int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes) { return LDS_LEVEL_BYTES + RENDER_WAVES * ((int)sizeof(WaveLds) + (int)gen_wave_bytes); }

@@ -31,7 +31,11 @@ for az in (0, 45, 90):
     print(f"   setup (raygen, SH, box clip, coarse DDA) {100*int(out[10])/tot:.1f}% of wave cycles = {int(out[10])/waves:.0f} cycles/wave")
     print(f"   MFMA tile slots evaluated {slots} = {100*s/max(slots,1):.1f}% filled")
     print(f"   per round: march {m/r:.0f}  network {n/r:.0f}  composite {c/r:.0f} cycles")
-    if int(out[13]):
+    if int(out[13]) and int(out[14]):  # persistent kernel: the waves' time in the tile loop
+        n, total, longest, sched = int(out[13]), int(out[12]), int(out[14]), int(out[15])
+        print(f"   tile loop: {n} waves, mean {total/n:.0f} cycles, longest {longest} -> the mean wave is in the loop for {100*total/n/longest:.1f}% "
+              f"of the longest one's time; waiting for a tile: {100*sched/total:.2f}% of the loop time; in tiles with live rays: {100*tot/total:.1f}%")
+    elif int(out[13]):
         held = int(out[12])
         print(f"   workgroup hold: {int(out[13])} workgroups held their wave slots for {held/tot:.3f} x the waves' own spans "
               f"({100*(1-tot/held):.1f}% of the held slot time is a finished wave waiting for the slowest tile of its strip)")

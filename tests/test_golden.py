@@ -83,6 +83,7 @@ def test_frame_fingerprints_unchanged():
     import models
     import nerfhip as nh
     import synthetic as syn
+    torch = pytest.importorskip("torch")
 
     want = [ln.split() for ln in (Path(__file__).parent / "golden" / "frame_hashes.txt").read_text().splitlines() if ln.strip()]
     desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
@@ -103,8 +104,14 @@ def test_frame_fingerprints_unchanged():
             loaded = config4
         W, H = int(W), int(H)
         c.set_resolution(W, H)
+        # into poisoned caller-owned planes: a pixel the kernel leaves unwritten cannot hide behind the previous frame
+        t_rgba = torch.full((H, W, 4), 7.0, device="cuda")
+        t_depth = torch.full((H, W), 7.0, device="cuda")
+        torch.cuda.synchronize()
+        c.bind_output(t_rgba.data_ptr(), t_depth.data_ptr())
         c.render(syn.default_camera(W, H), syn.orbit_pose(float(az), float(el), radius=float(radius)))
-        rgba, depth = c.read_f32()
+        c.bind_output(0, 0)
+        rgba, depth = t_rgba.cpu().numpy(), t_depth.cpu().numpy()
         # the count of evaluated samples depends on the batching (speculation past a ray's end), the picture does not
         assert abs(c.stats().n_samples - int(n_samples)) <= 0.02 * int(n_samples) + 64, row
         assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
