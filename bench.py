@@ -32,7 +32,7 @@ and relays rank 0's line; under a launcher WORLD_SIZE must equal --gpus, or the
 run fails.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (render_kernel); the contract's figure: algorithmic
+  roofline      dominant kernel (render_persistent_kernel); the contract's figure: algorithmic
                 gather bytes (512 B/sample = 16 levels x 8 corners x half2) over the
                 kernel's mean duration measured with HIP events on its stream,
                 against the HBM peak -- plus what the counters say really binds it
@@ -414,7 +414,7 @@ def main():
                                      ("external" if world > 1 else None)),
                         "devices": devices},
         "roofline": {
-            "kernel": "render_kernel",
+            "kernel": "render_persistent_kernel",
             # the contract's figure: ALGORITHMIC gather bytes / kernel time against the HBM peak.  The table
             # (24 MB) is served from L2 / Infinity Cache, so this is a cache-gather rate: see hbm_gbs_measured and limiter
             "bound": "hbm",

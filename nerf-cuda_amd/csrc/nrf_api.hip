@@ -178,7 +178,7 @@ struct nrf_context {
   bool grid_missing = false;     // loaded without a density grid and none generated yet
   bool allow_persistent = true;  // NRF_PERSISTENT=0 keeps the one-workgroup-per-strip render_kernel (A/B runs)
   bool centre_out = true;        // NRF_CENTRE_OUT=0: the persistent kernel's queue in row order
-  int block_tiles = 0;           // persistent kernel: tiles per queue entry (NRF_BLOCK_TILES=4|16; 0: per launch)
+  int queue_classes = 0;         // NRF_QUEUE_CLASSES=1..8: work queues of the persistent kernel (default: one per XCD)
   int n_cus = 256;
   nrf_options opt{};
   int W = 0, H = 0;
@@ -280,8 +280,8 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.density_scale = c->opt.density_scale;
   P.max_steps = c->opt.max_steps;
   P.march_budget = c->march_budget;
-  P.block_tiles = c->block_tiles;  // 0: the default (launch_render)
   P.centre_out = c->centre_out ? 1 : 0;
+  P.queue_classes = c->queue_classes;
   return NRF_OK;
 }
 
@@ -502,7 +502,6 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   // table in LDS for the whole launch: hot instance, tables that fit beside its 16 waves' blocks.
   M.persistent = 0;
   M.n_cus = (uint32_t)c->n_cus;
-  M.lds_grid_bytes = M.lds_grid_levels = 0;
   if (c->allow_persistent && !M.generic && !M.wide && M.lds_coarse_words > 0) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
     if ((size_t)render_persistent_lds_fixed_bytes() + tables <= 160u * 1024u) {
@@ -586,8 +585,8 @@ int nrf_create(int device, nrf_context** out) {
     if (b >= 1 && b <= 4096) c->march_budget = b;
   }
   if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
-  if (const char* e = std::getenv("NRF_BLOCK_TILES")) c->block_tiles = std::atoi(e);
   if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_QUEUE_CLASSES")) c->queue_classes = std::atoi(e);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

@@ -116,8 +116,6 @@ struct DevModel {
   uint32_t lds_dilated_words;  // words of occ_dilated that fit the (not yet used) weight area of LDS during ray setup (0: global)
   uint32_t persistent;      // 1: render_persistent_kernel may render this model (hot instance, every march table in LDS)
   uint32_t n_cus;           // compute units of the device: workgroups of the persistent kernel
-  uint32_t lds_grid_bytes;  // persistent kernel: leading bytes of the hash table kept in LDS (levels 0 .. lds_grid_levels - 1)
-  uint32_t lds_grid_levels;
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.
@@ -142,7 +140,8 @@ struct ViewBatch {
   ViewParams v[MAX_VIEWS];
   int n_views;
   int blocks_per_view;                 // workgroups per view: block b renders view b / blocks_per_view
-  int q_total;                         // persistent kernel: entries of the work queue (sum over views of k_hi - k_lo)
+  int q_total;                         // persistent kernel: units of the launch (strip rows; sharded: local strips), all views
+  int n_classes, class_cols;           // its work queues: class c holds, for every unit, the columns c, c + n_classes, ... < class_cols
   unsigned long long view_stride_px;   // pixels between consecutive views in the output planes
 };
 
@@ -158,7 +157,7 @@ struct FrameParams {
   float bg_color, min_near, dt_gamma, density_scale;
   int max_steps;
   int march_budget;  // cell trips a lane may spend per round (tuning knob, default 256)
-  int block_tiles;  // persistent kernel: tiles per queue entry, 4 (one strip) or 16 (4 x 4 tiles)
+  int queue_classes;  // persistent kernel, unsharded frames: work queues (8: one per XCD; 1: a single queue); 0: default
   int centre_out;   // persistent kernel: a view's strip rows are queued from the middle of its region of interest outwards
 };
 

@@ -24,9 +24,6 @@ namespace nrf {
 #ifndef NRF_SLOTS
 #define NRF_SLOTS 64
 #endif
-#ifndef NRF_PRIO_ROUNDS
-#define NRF_PRIO_ROUNDS 16
-#endif
 constexpr int SLOTS = NRF_SLOTS;  // sample slots a wave fills per round
 struct WaveLds {
   union {
@@ -289,10 +286,9 @@ struct TileStats {
 #endif
 };
 
-constexpr unsigned PRIO_ROUNDS = NRF_PRIO_ROUNDS;
 // The rounds of one 8x8 tile (one wave, no workgroup barrier inside): march -> network -> compositing until no ray
 // of the tile is alive.  t / tc / alive: the rays' state after ray generation and the visibility walk.
-template <int NET, bool COARSE_LDS, int MARCH, bool PRIORITY = false>
+template <int NET, bool COARSE_LDS, int MARCH>
 __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams& P, const MarchConst& mc, const LdsMap& lm,
                                             const uint32_t* coarse_lds, const float* ctab_lds, int lane, const float (&o)[3],
                                             const float (&d)[3], float rdx, float rdy, float rdz, int sx, int sy, int sz,
@@ -398,17 +394,7 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
     n_samples += (unsigned)S;
     n_rounds++;
     n_tile_slots += (unsigned)((S + 15) & ~15);
-    if constexpr (PRIORITY) {
-      // Long tiles first: among the waves of a SIMD the arbiter prefers the higher s_setprio level and, within a level,
-      // the OLDEST wave -- in a persistent workgroup that is always the same one (measured: the four youngest waves of
-      // a workgroup needed 920 cycles per sample, the four oldest 610).  A tile that has been running for many rounds
-      // is the one a frame ends up waiting for: it climbs a level every PRIO_ROUNDS rounds.
-      if (n_rounds == PRIO_ROUNDS) __builtin_amdgcn_s_setprio(1);
-      else if (n_rounds == 2 * PRIO_ROUNDS) __builtin_amdgcn_s_setprio(2);
-      else if (n_rounds == 3 * PRIO_ROUNDS) __builtin_amdgcn_s_setprio(3);
-    }
   }
-  if constexpr (PRIORITY) __builtin_amdgcn_s_setprio(0);
 
   acc.ws = ws; acc.dep = dep; acc.cr = cr; acc.cg = cg; acc.cb = cb;
   ts.n_samples += n_samples;
@@ -749,74 +735,85 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
     const int v = (int)threadIdx.x;
     q_lds[v] = v < VB.n_views ? VB.v[v].q_begin : VB.q_total;
   }
-  if (threadIdx.x == 0) *sched = (unsigned)blockIdx.x << 5;  // the first block needs no atomic: the queue starts at gridDim.x
+  if (threadIdx.x == 0) *sched = (0xfffffeu << 5) | 4u;  // no strip yet: the first wave to ask fetches one
   __syncthreads();
 
   const MarchConst mc = march_const(M, P.dt_gamma);
   TileStats ts;
-  const unsigned q_total = (unsigned)VB0.q_total;
+  // ---- the work queues.  Unsharded frames: one queue per XCD class -- class c owns the strip columns c, c + 8, ...
+  // of every view, so that the strips an XCD's L2 serves are vertical neighbours (16 KB of L1 per CU and 4 MB of L2 per
+  // XCD are where the table lives; with ONE queue, strips landed on random XCDs and the L2 missed twice as often as
+  // under render_kernel's static strip -> XCD mapping).  A workgroup starts with the class of its own XCD and moves on
+  // to the next class when a queue runs dry, so the XCDs balance at the end.  Sharded frames (a rank's strips are
+  // every N-th one): one queue.  A queue entry is one strip (4 tiles); 4 x 4-tile blocks were 2 % slower in 16-view
+  // launches and 13 % slower for one view (the 16 tiles of a block at the object's centre are half of a CU's share);
+  // groups of 2 or 4 adjacent columns per class measured like single columns, groups of 8 were 2 % slower.
+  //   sched (LDS, one word per workgroup) = classes moved past << 29 | queue position << 5 | tiles taken
+  const unsigned n_cls = (unsigned)VB0.n_classes, cls_cols = (unsigned)VB0.class_cols, n_units = (unsigned)VB0.q_total;
+  const unsigned cls0 = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) % n_cls;  // HW_REG_XCC_ID[3:0]
+  constexpr unsigned POS_DONE = 0xffffffu;
   NRF_STAMP(t_loop_begin);
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_sched = 0;
 #endif
   while (true) {
     NRF_STAMP(t_sched0);
-    // ---- next tile: the workgroup's current block (16 tiles) is dealt through an LDS counter; the wave that finds it
-    // used up fetches the next block from the global queue (one device-scope atomic per 16 tiles) and publishes it.
-    // sched = block << 5 | tiles taken; a block number >= q_total ends every wave's loop.
-    unsigned blk, bt;
-    const unsigned B = (unsigned)P0.block_tiles;
+    unsigned pos, bt, moved;
     while (true) {
       unsigned old = 0u;
       if (lane == 0) old = atomicAdd(sched, 1u);
       old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-      blk = old >> 5;
+      moved = old >> 29;
+      pos = (old >> 5) & POS_DONE;
       bt = old & 31u;
-      if (blk >= q_total || bt < B) break;
-      if (bt == B) {  // this wave refills: tile 0 of the new block is its own
-        unsigned nb = 0u;
-        if (lane == 0) nb = atomicAdd(queue, 1u);
-        nb = (unsigned)__builtin_amdgcn_readfirstlane((int)nb);
-        if (lane == 0) __hip_atomic_store(sched, (nb << 5) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        blk = nb;
+      if (pos == POS_DONE || bt < 4u) break;
+      if (bt == 4u) {  // this wave refills: tile 0 of the new strip is its own
+        unsigned nb = POS_DONE;
+        for (; moved < n_cls; ++moved) {
+          const unsigned cls = (cls0 + moved) % n_cls;
+          const unsigned total = n_units * ((cls_cols - cls + n_cls - 1u) / n_cls);
+          unsigned got = 0u;
+          if (lane == 0) got = atomicAdd(queue + cls, 1u);
+          got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+          if (got < total) { nb = got; break; }
+        }
+        if (nb == POS_DONE) moved = 0u;
+        if (lane == 0) __hip_atomic_store(sched, (moved << 29) | (nb << 5) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pos = nb;
         bt = 0u;
         break;
       }
-      // another wave is refilling: wait until the block number changes, then try again
-      while ((__hip_atomic_load(sched, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 5) == blk) __builtin_amdgcn_s_sleep(2);
+      // another wave is refilling: wait until the strip changes, then try again
+      while ((__hip_atomic_load(sched, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 5) == (old >> 5)) __builtin_amdgcn_s_sleep(2);
     }
     NRF_STAMP(t_sched1);
     NRF_ACC(c_sched, t_sched0, t_sched1);
-    if (blk >= q_total) break;
+    if (pos == POS_DONE) break;
     asm volatile("" : "+s"(ka));  // this tile's argument loads are this tile's (see PersistArgs)
     const DevModel& M = *(const DevModel*)&ka->M;
     const FrameParams& P = *(const FrameParams*)&ka->P;
     const ViewBatch& VB = *(const ViewBatch*)&ka->VB;
-    // block -> (view, local tile)
+    // queue position -> (unit, column), unit -> view.  A unit is a strip row of a view's region of interest (sharded: a
+    // local strip); the views' units are numbered one after the other.
+    const unsigned cls = (cls0 + moved) % n_cls, ncols = (cls_cols - cls + n_cls - 1u) / n_cls;
+    const int u = (int)(pos / ncols), j = (int)(pos - (unsigned)u * ncols);
     const int qb = q_lds[lane < MAX_VIEWS ? lane : MAX_VIEWS];
-    const int view = __popcll(__ballot(lane < VB.n_views && (int)blk >= qb)) - 1;  // wave-uniform
+    const int view = __popcll(__ballot(lane < VB.n_views && u >= qb)) - 1;  // wave-uniform
     const ViewParams& V = VB.v[view];
-    const int bl = (int)blk - V.q_begin;
-    // Centre-out: the queue visits a view's block rows (sharded: its blocks) in the order c, c + 1, c - 1, c + 2, ...
-    // from the middle of the region of interest, where the rays cross the most of the object, so that a view's last
-    // tiles are its lightest ones (in row order a heavy tile picked up late was a 30-40 % tail on a single frame).
+    const int ul = u - V.q_begin;
+    // Centre-out: a view's units are visited in the order c, c + 1, c - 1, c + 2, ... from the middle of the region of
+    // interest, where the rays cross the most of the object, so that a view's last tiles tend to be light ones.
     const bool co = P.centre_out != 0;
-    auto centre_out = [co](int j, int n) { const int off = (j + 1) >> 1; return co ? (n - 1) / 2 + ((j & 1) ? off : -off) : j; };
+    auto centre_out = [co](int i, int n) { const int off = (i + 1) >> 1; return co ? (n - 1) / 2 + ((i & 1) ? off : -off) : i; };
     int k_local;
-    if (P.shard_count == 1 && P.block_tiles == 16) {  // a block = 4 x 4 tiles (32 x 32 pixels): the strips of one column in 4 consecutive rows
+    if (P.shard_count == 1) {
       const int sxn = (P.tiles_x + 3) >> 2;
-      const int n_rows = (V.k_hi - V.k_lo + 16 * sxn - 1) / (16 * sxn);
-      const int row = V.k_lo / (4 * sxn) + centre_out(bl / sxn, n_rows) * 4 + (int)(bt >> 2);
-      k_local = (row * sxn + bl % sxn) * 4 + (int)(bt & 3u);
-    } else if (P.shard_count == 1) {  // a block = one strip (small launches: finer balance between the CUs)
-      const int sxn = (P.tiles_x + 3) >> 2;
-      const int n_rows = (V.k_hi - V.k_lo) / (4 * sxn);
-      const int row = V.k_lo / (4 * sxn) + centre_out(bl / sxn, n_rows);
-      k_local = (row * sxn + bl % sxn) * 4 + (int)bt;
-    } else {                   // a block = 4 (or 1) consecutive local strips
-      k_local = V.k_lo + centre_out(bl, (V.k_hi - V.k_lo + P.block_tiles - 1) / P.block_tiles) * P.block_tiles + (int)bt;
+      const int row = V.k_lo / (4 * sxn) + centre_out(ul, (V.k_hi - V.k_lo) / (4 * sxn));
+      k_local = (row * sxn + (int)cls + (int)n_cls * j) * 4 + (int)bt;
+    } else {
+      k_local = V.k_lo + centre_out(ul, (V.k_hi - V.k_lo) >> 2) * 4 + (int)bt;
     }
-    if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last block (row)
+    if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last strip
     float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
     float* depth = depth0 + (size_t)view * VB.view_stride_px;
     const int strips_x = (P.tiles_x + 3) >> 2;
@@ -903,7 +900,7 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
       }
       wave_sync();
       NRF_STAMP(t_setup_done);
-      tile_rounds<NET_HOT, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+      tile_rounds<NET_HOT, true, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
                                         alive, acc, ts);
 #ifdef NRF_PHASE_TIMING
       if (lane == 0) {
@@ -1420,26 +1417,20 @@ static hipError_t allow_lds(K kernel, int bytes) {
 }
 static int gen_lds_bytes(const DevModel& M, int waves) { return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)M.gen_wave_bytes); }
 
-hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
+hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
                          hipStream_t st) {
   ViewBatch VB = VBin;
-  FrameParams P = Pin;
-  // persistent kernel: a queue entry is one strip (4 tiles).  Blocks of 4 x 4 tiles (NRF_BLOCK_TILES=16) were measured 2 %
-  // slower in 16-view launches and 13 % slower for one view alone: the 16 tiles of a block at the object's centre are half of
-  // a CU's share of a 1080p frame, and the extra L1 sharing between its strips is worth less than the finer balance.
-  if (P.block_tiles != 4 && P.block_tiles != 16) P.block_tiles = 4;
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
   if (M.persistent && !M.generic && !M.wide && lds_tab) {
-    // work queue: per view the local strips of every strip row its region of interest touches
+    // work queues: per view the strip rows its region of interest touches (sharded: the local strips of those rows)
     const int strips_x = (P.tiles_x + 3) >> 2, N = P.shard_count, idx = P.shard_index;
     const int k_end = (P.n_local_tiles + 3) & ~3;
     int q = 0;
     for (int v = 0; v < VB.n_views; ++v) {
       ViewParams& V = VB.v[v];
       V.k_lo = V.k_hi = 0;
-      int block_rows = 0;
       if (V.roi[2] >= V.roi[0] && V.roi[3] >= V.roi[1]) {
         const int ty0 = std::max(V.roi[1] >> 3, 0), ty1 = std::min(V.roi[3] >> 3, P.tiles_y - 1);
         if (ty1 >= ty0) {
@@ -1447,23 +1438,21 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
           const int ls0 = s0 > idx ? (s0 - idx + N - 1) / N : 0, ls1 = s1 > idx ? (s1 - idx + N - 1) / N : 0;
           V.k_lo = std::min(4 * ls0, k_end);
           V.k_hi = std::min(4 * ls1, k_end);
-          if (N == 1 && P.block_tiles == 16) {  // whole block rows (the last one may reach below the image: those tiles are skipped)
-            block_rows = (ty1 - ty0 + 4) / 4;
-            V.k_hi = std::min((ty0 + 4 * block_rows) * strips_x * 4, k_end);
-          }
         }
       }
       V.q_begin = q;
-      // queue entries are blocks of 16 tiles: unsharded 4 x 4 tiles (strip column x 4 rows), else 4 consecutive local strips
-      q += (N == 1 && P.block_tiles == 16) ? block_rows * strips_x : (V.k_hi - V.k_lo + P.block_tiles - 1) / P.block_tiles;
+      q += N == 1 ? (V.k_hi - V.k_lo) / (4 * strips_x) : (V.k_hi - V.k_lo) / 4;  // units: strip rows / local strips
     }
     VB.q_total = q;
+    VB.n_classes = N == 1 ? (P.queue_classes >= 1 && P.queue_classes <= 8 ? P.queue_classes : 8) : 1;
+    VB.class_cols = N == 1 ? strips_x : 1;
+    if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int lds = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) +
                     4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) + LDS_QUEUE_BYTES;
     const long long tiles = (long long)P.n_local_tiles * VB.n_views;
     const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + PERSIST_WAVES - 1) / PERSIST_WAVES));
     unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue, wgs, 1, st);  // every workgroup's first block is its own index
+    hipError_t e = hipMemsetAsync(queue, 0, 8 * sizeof(unsigned), st);
     if (e != hipSuccess) return e;
     const bool pow2_h = (M.H & (M.H - 1)) == 0;
     int eb = 0;

@@ -9,7 +9,7 @@ import sys
 
 path, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 views = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-rows = [r for r in csv.DictReader(open(path)) if "render_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(path)) if "render_kernel" in r["Kernel_Name"] or "render_persistent_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 timed, single, iso = dur[warmup:warmup + steps], dur[warmup + steps:warmup + steps + 8], dur[warmup + steps + 8:]
