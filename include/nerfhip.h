@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define NRF_ABI_VERSION 3
-#define NRF_MAX_VIEWS 32 /* cameras one launch of the fused kernel takes (nrf_render_views) */
+#define NRF_MAX_VIEWS 128 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
 enum {

@@ -125,17 +125,18 @@ struct ViewParams {
   float cam[4];  // fl_x, fl_y, cx, cy
   int roi[4];    // x0, y0, x1, y1 (pixels, inclusive): no ray outside this rectangle enters the box of occupied
                  // cells (host: conservative projection of its corners, nrf_api.hip view_roi); x1 < x0: empty
-  // persistent kernel: the local tiles [k_lo, k_hi) (multiples of 4 = whole strips) cover every strip row the
-  // rectangle touches; they are dealt to the waves through the work queue, positions [q_begin, q_begin + k_hi - k_lo)
-  // of it; the view's other tiles are background and are filled without the queue
-  int k_lo, k_hi, q_begin;
+  // persistent kernel: the local tiles [k_lo, k_hi) (multiples of 4 = whole strips) cover the q_rows strip rows (from row q_row0) the
+  // rectangle touches; those rows are units [q_begin, q_begin + q_rows) of the launch's work queues; the view's other
+  // tiles are background and are filled without the queues
+  int k_lo, k_hi, q_begin, q_rows, q_row0;
 };
 // Statistics counters: COUNTER_SLOTS copies of 16 x u64 (one 128-byte line each); a workgroup adds to copy
 // blockIdx % COUNTER_SLOTS.  Device-scope atomics on ONE address serialise at ~12 ns each across the 8 XCDs:
 // two of them per wave made an all-background 1080p frame cost 0.79 ms.
 constexpr int COUNTER_SLOTS = 64;
 constexpr int COUNTER_BYTES = COUNTER_SLOTS * 16 * 8;
-constexpr int MAX_VIEWS = 32; // == NRF_MAX_VIEWS: views of one render_kernel launch (by-value kernel argument)
+constexpr int MAX_VIEWS = 128; // == NRF_MAX_VIEWS: views of one render launch (by-value kernel argument: 12.8 KB; the kernarg
+                               // segment takes it -- a 16 KB by-value struct was tried on gfx950)
 struct ViewBatch {
   ViewParams v[MAX_VIEWS];
   int n_views;

@@ -745,7 +745,9 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
   // XCD are where the table lives; with ONE queue, strips landed on random XCDs and the L2 missed twice as often as
   // under render_kernel's static strip -> XCD mapping).  A workgroup starts with the class of its own XCD and moves on
   // to the next class when a queue runs dry, so the XCDs balance at the end.  Sharded frames (a rank's strips are
-  // every N-th one): one queue.  A queue entry is one strip (4 tiles); 4 x 4-tile blocks were 2 % slower in 16-view
+  // every N-th one): the same with the rank's own strips of a row -- its j-th strip of every row belongs to class
+  // j % 8, and the strips of a column are N apart in the rank's numbering whatever the row.
+  // A queue entry is one strip (4 tiles); 4 x 4-tile blocks were 2 % slower in 16-view
   // launches and 13 % slower for one view (the 16 tiles of a block at the object's centre are half of a CU's share);
   // groups of 2 or 4 adjacent columns per class measured like single columns, groups of 8 were 2 % slower.
   //   sched (LDS, one word per workgroup) = classes moved past << 29 | queue position << 5 | tiles taken
@@ -797,22 +799,23 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
     // local strip); the views' units are numbered one after the other.
     const unsigned cls = (cls0 + moved) % n_cls, ncols = (cls_cols - cls + n_cls - 1u) / n_cls;
     const int u = (int)(pos / ncols), j = (int)(pos - (unsigned)u * ncols);
-    const int qb = q_lds[lane < MAX_VIEWS ? lane : MAX_VIEWS];
-    const int view = __popcll(__ballot(lane < VB.n_views && u >= qb)) - 1;  // wave-uniform
+    static_assert(MAX_VIEWS == 128, "two ballots cover the views");
+    const int view = __popcll(__ballot(lane < VB.n_views && u >= q_lds[lane])) +
+                     __popcll(__ballot(lane + 64 < VB.n_views && u >= q_lds[lane + 64])) - 1;  // wave-uniform
     const ViewParams& V = VB.v[view];
     const int ul = u - V.q_begin;
     // Centre-out: a view's units are visited in the order c, c + 1, c - 1, c + 2, ... from the middle of the region of
     // interest, where the rays cross the most of the object, so that a view's last tiles tend to be light ones.
     const bool co = P.centre_out != 0;
     auto centre_out = [co](int i, int n) { const int off = (i + 1) >> 1; return co ? (n - 1) / 2 + ((i & 1) ? off : -off) : i; };
-    int k_local;
-    if (P.shard_count == 1) {
-      const int sxn = (P.tiles_x + 3) >> 2;
-      const int row = V.k_lo / (4 * sxn) + centre_out(ul, (V.k_hi - V.k_lo) / (4 * sxn));
-      k_local = (row * sxn + (int)cls + (int)n_cls * j) * 4 + (int)bt;
-    } else {
-      k_local = V.k_lo + centre_out(ul, (V.k_hi - V.k_lo) >> 2) * 4 + (int)bt;
-    }
+    // unit -> strip row of the frame; entry j of the class -> the (cls + n_cls * j)-th of this rank's strips in that row
+    const int sxn = (P.tiles_x + 3) >> 2, N = P.shard_count;
+    const int row = V.q_row0 + centre_out(ul, V.q_rows);
+    const int s_row = row * sxn;                                    // global strips [s_row, s_row + sxn) form the row
+    const int ls_first = s_row > P.shard_index ? (s_row - P.shard_index + N - 1) / N : 0;
+    const int ls = ls_first + (int)cls + (int)n_cls * j;
+    if (ls * N + P.shard_index >= s_row + sxn) continue;            // this row holds fewer of the rank's strips
+    const int k_local = ls * 4 + (int)bt;
     if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last strip
     float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
     float* depth = depth0 + (size_t)view * VB.view_stride_px;
@@ -1431,9 +1434,12 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     for (int v = 0; v < VB.n_views; ++v) {
       ViewParams& V = VB.v[v];
       V.k_lo = V.k_hi = 0;
+      int rows = 0, row0 = 0;
       if (V.roi[2] >= V.roi[0] && V.roi[3] >= V.roi[1]) {
         const int ty0 = std::max(V.roi[1] >> 3, 0), ty1 = std::min(V.roi[3] >> 3, P.tiles_y - 1);
         if (ty1 >= ty0) {
+          rows = ty1 - ty0 + 1;
+          row0 = ty0;
           const int s0 = ty0 * strips_x, s1 = (ty1 + 1) * strips_x;  // global strips [s0, s1)
           const int ls0 = s0 > idx ? (s0 - idx + N - 1) / N : 0, ls1 = s1 > idx ? (s1 - idx + N - 1) / N : 0;
           V.k_lo = std::min(4 * ls0, k_end);
@@ -1441,11 +1447,13 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
         }
       }
       V.q_begin = q;
-      q += N == 1 ? (V.k_hi - V.k_lo) / (4 * strips_x) : (V.k_hi - V.k_lo) / 4;  // units: strip rows / local strips
+      V.q_rows = rows;
+      V.q_row0 = row0;
+      q += rows;  // units: the strip rows the region of interest touches
     }
     VB.q_total = q;
-    VB.n_classes = N == 1 ? (P.queue_classes >= 1 && P.queue_classes <= 8 ? P.queue_classes : 8) : 1;
-    VB.class_cols = N == 1 ? strips_x : 1;
+    VB.n_classes = P.queue_classes >= 1 && P.queue_classes <= 8 ? P.queue_classes : 8;
+    VB.class_cols = (strips_x + N - 1) / N;  // a row holds at most this many of the rank's strips
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int lds = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) +
                     4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) + LDS_QUEUE_BYTES;

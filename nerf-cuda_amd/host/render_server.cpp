@@ -5,7 +5,7 @@
 //
 // Unlike the reference (one client at a time, one render_frame per request) any number of clients
 // may be connected: each connection has a reader thread that queues its pose, and ONE render
-// thread takes everything that is queued -- up to NRF_MAX_VIEWS poses -- into a single
+// thread takes everything that is queued -- up to SERVER_BATCH_VIEWS (32) poses -- into a single
 // render_frames call (one launch of the fused kernel).  Requests that arrive while a batch renders
 // form the next batch, so batching needs no timer and a lone client sees no added latency
 // (BASELINE config 5: many concurrent camera requests).
@@ -15,7 +15,7 @@
 // Robustness (the reference relies on sockpp::socket_initializer for the first point and has none of the others):
 //   * a client that disconnects mid-reply must not take the server down: SIGPIPE is ignored and every send uses
 //     MSG_NOSIGNAL;
-//   * an extended request of n views is served in chunks of NRF_MAX_VIEWS (one launch each): at most that many
+//   * an extended request of n views is served in chunks of SERVER_BATCH_VIEWS (one launch each): at most that many
 //     frames are held per connection, whatever n (<= NRF1_MAX_VIEWS_PER_REQUEST) says;
 //   * client threads are detached and counted, nothing grows with the number of connections served;
 //   * NRF_SERVER_BIND=<ipv4> restricts the listening address (default: any, like the reference's acceptor);
@@ -88,6 +88,8 @@ struct Batcher {
   bool test_hooks = false;  // NRF_SERVER_TEST_HOOKS=1
 };
 constexpr uint32_t NRF1_MAX_VIEWS_PER_REQUEST = 4096;
+constexpr uint32_t SERVER_BATCH_VIEWS = 32;  // frames one launch of the server renders and holds (<= NRF_MAX_VIEWS)
+static_assert(SERVER_BATCH_VIEWS <= NRF_MAX_VIEWS, "a batch is one launch");
 
 // the one thread that owns the renderer
 void render_loop(NerfRender& render, const size_t frame_bytes, Batcher& b) {
@@ -97,7 +99,7 @@ void render_loop(NerfRender& render, const size_t frame_bytes, Batcher& b) {
       std::unique_lock<std::mutex> lk(b.m);
       b.cv.wait(lk, [&] { return b.stop.load() || !b.queue.empty(); });
       if (b.stop.load() && b.queue.empty()) return;
-      while (!b.queue.empty() && batch.size() < (size_t)NRF_MAX_VIEWS) {
+      while (!b.queue.empty() && batch.size() < (size_t)SERVER_BATCH_VIEWS) {
         batch.push_back(b.queue.front());
         b.queue.pop_front();
       }
@@ -168,11 +170,11 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, co
       std::memcpy(body.data(), (const char*)nerf_pos + 8, have < need ? have : need);
       if (need > have && !read_n(sock, (char*)body.data() + have, need - have)) break;
       bool ok = true;
-      // chunks of NRF_MAX_VIEWS: every chunk is queued before its first wait (one launch), sent, and freed before
-      // the next one is queued -- a connection never holds more than NRF_MAX_VIEWS rendered frames
-      for (uint32_t first = 0; ok && first < n; first += NRF_MAX_VIEWS) {
+      // chunks of SERVER_BATCH_VIEWS: every chunk is queued before its first wait (one launch), sent, and freed before
+      // the next one is queued -- a connection never holds more than SERVER_BATCH_VIEWS rendered frames
+      for (uint32_t first = 0; ok && first < n; first += SERVER_BATCH_VIEWS) {
         std::vector<std::shared_ptr<Request>> reqs;
-        for (uint32_t v = first; v < n && v < first + NRF_MAX_VIEWS; ++v) {
+        for (uint32_t v = first; v < n && v < first + SERVER_BATCH_VIEWS; ++v) {
           const float* r = body.data() + (size_t)v * 20;
           reqs.push_back(submit(b, Camera{r[0], r[1], r[2], r[3]}, r + 4));
         }

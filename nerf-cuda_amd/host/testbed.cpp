@@ -3,7 +3,7 @@
 // and pose, print "Process time", write image.png / deep.png.
 //   usage: testbed [snapshot.msgpack] [width height] [out_prefix] [transforms.json]
 // With a transforms.json (NeRF-synthetic / instant-ngp camera path) every frame of the path is rendered as well, in
-// batches of NRF_MAX_VIEWS views per launch, and written to <out_prefix>path_NNNN.rgb.
+// batches of 32 views per launch, and written to <out_prefix>path_NNNN.rgb.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -14,6 +14,8 @@
 #include "nerf_render.h"
 #include "png_lite.h"
 #include "render_buffer.h"
+
+constexpr size_t PATH_BATCH_VIEWS = 32;  // frames of a camera path rendered (and held) per launch
 
 using namespace ngp;
 
@@ -67,8 +69,8 @@ int main(int argc, char** argv) {
       load_camera_path(argv[5], W, H, cams, poses);
       const auto p0 = std::chrono::steady_clock::now();
       size_t done = 0;
-      for (size_t first = 0; first < cams.size(); first += NRF_MAX_VIEWS) {
-        const size_t n = std::min(cams.size() - first, (size_t)NRF_MAX_VIEWS);
+      for (size_t first = 0; first < cams.size(); first += PATH_BATCH_VIEWS) {
+        const size_t n = std::min(cams.size() - first, PATH_BATCH_VIEWS);
         const std::vector<Image> imgs = render->render_frames(std::vector<Camera>(cams.begin() + first, cams.begin() + first + n),
                                                               std::vector<Matrix4f>(poses.begin() + first, poses.begin() + first + n));
         for (size_t i = 0; i < n; ++i, ++done) {

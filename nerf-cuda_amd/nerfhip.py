@@ -24,7 +24,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
 NRF_ABI_VERSION = 3
-NRF_MAX_VIEWS = 32
+NRF_MAX_VIEWS = 128
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
 
 ACT = {"none": 0, "relu": 1, "exponential": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5, "sine": 6}

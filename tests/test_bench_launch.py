@@ -84,10 +84,10 @@ def test_self_launched_two_rank_rehearsal_strong_and_multi_launch_steps():
     out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "2", "--warmup", "1",
                        "--views-per-step", "3", "--scaling", "strong"])
     assert out["scaling"] == "strong" and out["config"]["views_per_step"] == 3 and out["sharded_frame_equals_unsharded"] is True
-    # 20 x 2 = 40 frames per step = two launches per rank and step (NRF_MAX_VIEWS = 32), at a smaller resolution
+    # 70 x 2 = 140 frames per step = two launches per rank and step (NRF_MAX_VIEWS = 128), at a smaller resolution
     out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "1", "--warmup", "1",
-                       "--views-per-step", "20", "--width", "640", "--height", "360"])
-    assert out["config"]["views_per_step"] == 40 and out["roofline"]["launches_per_step"] == 2
+                       "--views-per-step", "70", "--width", "320", "--height", "184"])
+    assert out["config"]["views_per_step"] == 140 and out["roofline"]["launches_per_step"] == 2
     assert out["sharded_frame_equals_unsharded"] is True
 
 

@@ -365,7 +365,7 @@ def test_render_server_survives_rude_clients(snapshot):
         s.sendall(quit_msg.tobytes())              # without the hook: a pose like any other -> one frame comes back
         _recv_exact(s, 3 * W * H)
         assert srv.poll() is None
-        # 40 views in one extended request = two launches (NRF_MAX_VIEWS = 32), answers in request order
+        # 40 views in one extended request = two launches (the server renders 32 views per launch), answers in request order
         cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
         views = [syn.orbit_pose(9.0 * i, 25.0) for i in range(40)]
         msg = b"NRF1" + np.uint32(len(views)).tobytes()
