@@ -16,8 +16,9 @@ Multi-GPU (one process per GPU, RCCL):
       strips are dealt round-robin to the ranks (tile-parallel: every rank renders
       1/N of EVERY frame), two steps are in flight, every rank quantises its shard
       to the reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only
-      exchange is one RCCL gather of the batch's shards to rank 0, followed by an
-      untile kernel there (--gather-format f32 ships float RGBA instead).
+      exchange is one RCCL gather of the batch's shards to the step's sink rank
+      (step % N by default, --gather-root 0: always rank 0), followed by an untile
+      kernel there (--gather-format f32 ships float RGBA instead).
       --scaling weak (default): a step is 16 x N frames, so every rank renders 16
       frames' worth of tiles per step whatever N is; --scaling strong: a step is
       the same 16 frames at every N (1/N-th of the work per rank and step).
@@ -107,6 +108,9 @@ def parse_args():
     ap.add_argument("--gather-format", choices=("rgbd8", "f32"), default="rgbd8",
                     help="N > 1: what the ranks send to rank 0 -- the reference's 8-bit image (r,g,b,depth: 4 B/px, "
                          "quantised on the rendering GPU) or the float RGBA plane (16 B/px)")
+    ap.add_argument("--gather-root", choices=("rotate", "0"), default="rotate",
+                    help="N > 1: the rank that assembles a step's frames -- step %% N (default: every rank is the sink of every "
+                         "N-th step, so no GPU carries the receive + untile of all frames) or always rank 0")
     ap.add_argument("--lib", default=None, help="another build of libnerfhip.so (A/B comparisons on one box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -227,17 +231,18 @@ def main():
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
         if world > 1:
+            is_sink = rank == 0 or args.gather_root == "rotate"  # this rank assembles (some of) the steps' frames
             if args.gather_format == "rgbd8":  # 4-byte pixels: one int32 "channel"
                 sl.send = torch.zeros((V, n_px), dtype=torch.int32, device=dev)
-                sl.all = torch.empty((world, V, n_px), dtype=torch.int32, device=dev) if rank == 0 else None
+                sl.all = torch.empty((world, V, n_px), dtype=torch.int32, device=dev) if is_sink else None
                 sl.frame = (sl.all.view(world * V, H, W) if replica else
-                            torch.empty((V, H, W), dtype=torch.int32, device=dev)) if rank == 0 else None
+                            torch.empty((V, H, W), dtype=torch.int32, device=dev)) if is_sink else None
             else:
                 sl.send = sl.rgba
-                sl.all = torch.empty((world, V, n_px, 4), device=dev) if rank == 0 else None
+                sl.all = torch.empty((world, V, n_px, 4), device=dev) if is_sink else None
                 sl.frame = (sl.all.view(world * V, H, W, 4) if replica else
-                            torch.empty((V, H, W, 4), device=dev)) if rank == 0 else None
-            sl.parts = [sl.all[r] for r in range(world)] if rank == 0 else None
+                            torch.empty((V, H, W, 4), device=dev)) if is_sink else None
+            sl.parts = [sl.all[r] for r in range(world)] if is_sink else None
         slots.append(sl)
     ctx = slots[0].ctx
     comm = torch.cuda.Stream(dev)
@@ -258,16 +263,20 @@ def main():
             e1.record(sl.stream)
             launch_events.append((e0, e1))
         if world > 1:
-            # the one exchange of the path: every rank's shard / frames -> rank 0 (direct xGMI sends: xGMI is
-            # point-to-point, so a gather moves 1/N-th of what an all-gather would), untile on rank 0
+            # the one exchange of the path: every rank's shard / frames -> the step's sink rank (direct xGMI sends: xGMI
+            # is point-to-point, so a gather moves 1/N-th of what an all-gather would), untile there
             if args.gather_format == "rgbd8":  # nerf_render.cu:345-359 on the rendering GPU, 4 B/px on the wire
                 sl.ctx.quantize_rgbd8(sl.rgba.data_ptr(), sl.depth.data_ptr(), V * n_px, sl.send.data_ptr(),
                                       stream=sl.stream.cuda_stream)
             sl.rendered.record(sl.stream)
+            # the rank that assembles this step's frames: step % N -- the receive of N - 1 shards (link-bound: 930 MB over
+            # seven xGMI links at N = 8) and the untile of the step's frames are then every rank's duty once in N steps
+            # instead of rank 0's in every step (scripts/overlap_test.py: 14.4 -> 13.5 ms per step on the sink)
+            root = i % world if args.gather_root == "rotate" else 0
             with torch.cuda.stream(comm):
                 comm.wait_event(sl.rendered)
-                dist.gather(sl.send, sl.parts if rank == 0 else None, dst=0)
-                if rank == 0 and not replica:
+                dist.gather(sl.send, sl.parts if rank == root else None, dst=root)
+                if rank == root and not replica:
                     sl.ctx.untile_views(sl.all.data_ptr(), world, tps, 4 if args.gather_format == "f32" else 1, V,
                                         sl.frame.data_ptr(), stream=comm.cuda_stream)
                 sl.gathered.record(comm)
@@ -283,7 +292,8 @@ def main():
         # timed region never pays for connection set-up whatever --warmup is
         with torch.cuda.stream(comm):
             probe = torch.zeros((256,), dtype=torch.int32, device=dev)
-            dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+            for root in (range(world) if args.gather_root == "rotate" else (0,)):
+                dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == root else None, dst=root)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -407,7 +417,8 @@ def main():
                    "step": (f"{V_step} frames per step, each tile-sharded over the {world} rank(s)" if not replica else
                             f"{V_step} requests per step, {V} whole frames per rank"),
                    "views_per_rank_and_step": V, "steps_in_flight": depth,
-                   "gather": (args.gather_format if world > 1 else None)},
+                   "gather": (args.gather_format if world > 1 else None),
+                   "gather_root": (("step % N" if args.gather_root == "rotate" else "rank 0") if world > 1 else None)},
         "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
                         "backend": (dist.get_backend() if world > 1 else None),
                         "launcher": ("bench.py self-launch" if os.environ.get("NRF_BENCH_SELF_LAUNCHED") else

@@ -77,12 +77,14 @@ def test_self_launched_two_rank_rehearsal_tile_sharded():
     assert out["config"]["parallelism"] == "tile2" and out["value"] > 0
     # weak scaling is the default: the step grows with the ranks (2 frames per rank's worth of tiles -> 4 frames)
     assert out["scaling"] == "weak" and out["config"]["views_per_step"] == 4
+    assert out["config"]["gather_root"] == "step % N"  # the default: every rank assembles every N-th step's frames
 
 
 @pytest.mark.gpu
 def test_self_launched_two_rank_rehearsal_strong_and_multi_launch_steps():
     out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "2", "--warmup", "1",
-                       "--views-per-step", "3", "--scaling", "strong"])
+                       "--views-per-step", "3", "--scaling", "strong", "--gather-root", "0"])
+    assert out["config"]["gather_root"] == "rank 0"
     assert out["scaling"] == "strong" and out["config"]["views_per_step"] == 3 and out["sharded_frame_equals_unsharded"] is True
     # 70 x 2 = 140 frames per step = two launches per rank and step (NRF_MAX_VIEWS = 128), at a smaller resolution
     out = _bench_line(["--gpus", "2", "--backend", "gloo", "--single-device", "--check", "--steps", "1", "--warmup", "1",
