@@ -1,0 +1,133 @@
+"""The two schedulings of the fused kernel must produce the same frames bit for bit: `render_persistent_kernel` (one
+workgroup per CU, waves pull strips from per-XCD work queues; the default for the base.json shape) against
+`render_kernel` (one workgroup per strip; `NRF_PERSISTENT=0`).  Every render goes into poisoned caller-owned planes,
+so a pixel that neither the queues nor the background sweep of the persistent kernel covers shows up.  The cases are
+the ones its queue arithmetic has to get right: frames whose region of interest is the whole image, a strip of it,
+empty; images smaller than a workgroup's share; odd sizes; shards of 2 / 3 / 8 ranks; more views than one launch
+takes; several cascades; queue settings (one queue, row order).  Sizes are small: the point is coverage, the speed
+is bench.py's business."""
+import os
+
+import numpy as np
+import pytest
+
+import models
+import nerfhip as nh
+import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _poses(kind, n):
+    if kind == "orbit":
+        return [syn.orbit_pose(37.0 * i + 5.0, (25.0, -10.0, 60.0)[i % 3]) for i in range(n)]
+    if kind == "inside":      # camera inside the volume: the region of interest is the whole image
+        return [syn.orbit_pose(50.0 * i, 20.0, radius=0.4 / 0.33) for i in range(n)]
+    if kind == "away":        # looking away from the object: empty region of interest -> all background
+        out = []
+        for i in range(n):
+            m = syn.orbit_pose(40.0 * i, 15.0).copy()
+            m[:3, 0] *= -1.0  # turn the camera round (x and z axes flipped: still right-handed)
+            m[:3, 2] *= -1.0
+            out.append(m)
+        return out
+    if kind == "far":         # the object is a few pixels wide: a region of interest of one or two strips
+        return [syn.orbit_pose(70.0 * i, 35.0, radius=30.0 / 0.33) for i in range(n)]
+    raise ValueError(kind)
+
+
+def _render(desc, W, H, poses, env, shard=(0, 1), opts_kw=None):
+    """Frames of `poses` (one nrf_render_views call) with the environment `env` in force at context creation."""
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = nh.NerfHip(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ctx.load_model(desc)
+    o = nh.default_options()
+    o.shard_index, o.shard_count = shard
+    for k, v in (opts_kw or {}).items():
+        setattr(o, k, v)
+    ctx.set_options(o)
+    ctx.set_resolution(W, H)
+    n = len(poses)
+    n_px = nh.tiles_per_shard(W, H, shard[1]) * 64 if shard[1] > 1 else W * H
+    rgba = torch.full((n, n_px, 4), 7.0, device="cuda")
+    depth = torch.full((n, n_px), 7.0, device="cuda")
+    torch.cuda.synchronize()
+    ctx.bind_output(rgba.data_ptr(), depth.data_ptr())
+    ctx.render_views(np.stack([syn.default_camera(W, H)] * n), np.stack(poses))
+    st = ctx.stats()
+    out = rgba.cpu().numpy(), depth.cpu().numpy(), int(st.n_samples), int(st.n_rays)
+    ctx.close()
+    return out
+
+
+def _same(a, b, what):
+    assert a[2] == b[2] and a[3] == b[3], (what, a[2:], b[2:])          # samples, rays
+    assert not np.any(a[0] == 7.0) and not np.any(a[1] == 7.0), what    # every pixel of the planes was written
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), what
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), what
+
+
+STRIP = {"NRF_PERSISTENT": "0"}
+PERSISTENT = {"NRF_PERSISTENT": "1"}
+
+
+@pytest.fixture(scope="module")
+def model():
+    desc, keep, _ = models.build_model(log2_hashmap_size=15, H=64)
+    return desc, keep
+
+
+@pytest.mark.parametrize("W,H", [(333, 211), (64, 40), (8, 8), (1000, 24), (40, 600)])
+@pytest.mark.parametrize("kind", ["orbit", "inside", "away", "far"])
+def test_persistent_kernel_equals_strip_kernel(model, W, H, kind):
+    desc, _ = model
+    poses = _poses(kind, 5)
+    ref = _render(desc, W, H, poses, STRIP)
+    _same(_render(desc, W, H, poses, PERSISTENT), ref, (W, H, kind))
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+def test_persistent_kernel_shards(model, count):
+    desc, _ = model
+    W, H = 501, 283  # 63 x 36 tiles: 16 strip columns, the last one partly outside the image
+    poses = _poses("orbit", 3) + _poses("inside", 2) + _poses("far", 1)
+    for index in range(count):
+        ref = _render(desc, W, H, poses, STRIP, shard=(index, count))
+        _same(_render(desc, W, H, poses, PERSISTENT, shard=(index, count)), ref, (count, index))
+
+
+def test_more_views_than_one_launch_takes(model):
+    desc, _ = model
+    n = nh.NRF_MAX_VIEWS + 5
+    poses = _poses("orbit", n)
+    ref = _render(desc, 96, 64, poses, STRIP)
+    _same(_render(desc, 96, 64, poses, PERSISTENT), ref, "two launches")
+    _same(_render(desc, 96, 64, poses, PERSISTENT, shard=(1, 2)), _render(desc, 96, 64, poses, STRIP, shard=(1, 2)), "two launches, sharded")
+
+
+def test_queue_settings_do_not_change_the_picture(model):
+    desc, _ = model
+    poses = _poses("orbit", 4) + _poses("inside", 2)
+    ref = _render(desc, 400, 300, poses, STRIP)
+    for env in ({"NRF_QUEUE_CLASSES": "1"}, {"NRF_QUEUE_CLASSES": "3"}, {"NRF_CENTRE_OUT": "0"},
+                {"NRF_QUEUE_CLASSES": "8", "NRF_CENTRE_OUT": "0"}):
+        _same(_render(desc, 400, 300, poses, dict(PERSISTENT, **env)), ref, env)
+
+
+def test_persistent_kernel_with_cascades_and_sample_cap():
+    """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
+    dilated table, 44 KB of march tables in LDS) and a small max_steps."""
+    desc, keep, _ = models.build_model(log2_hashmap_size=15, H=64, cascade=5, bound=16.0)
+    poses = [syn.orbit_pose(30.0, 20.0), syn.orbit_pose(200.0, -15.0, radius=1.5 / 0.33), syn.orbit_pose(120.0, 70.0, radius=9.0 / 0.33)]
+    for kw in ({"max_steps": 1024}, {"max_steps": 7}):
+        ref = _render(desc, 320, 200, poses, STRIP, opts_kw=kw)
+        _same(_render(desc, 320, 200, poses, PERSISTENT, opts_kw=kw), ref, kw)
