@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
   const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t n_chunks = (n + CH - 1) / CH;
-  uint4 fv[T], fnext[T];
-  uint2 dv[T], dnext[T];
+  uint4 fv[T], fnext[T], fnext2[T];
+  uint2 dv[T], dnext[T], dnext2[T];
   auto load_chunk = [&](uint32_t chunk, uint4 (&f)[T], uint2 (&d)[T]) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -1097,8 +1097,9 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
     }
   };
   load_chunk(wave_global, fv, dv);
+  load_chunk(wave_global + n_waves, fnext, dnext);
   for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
-    load_chunk(chunk + n_waves, fnext, dnext);  // in flight during the MFMAs below
+    load_chunk(chunk + 2 * n_waves, fnext2, dnext2);  // two chunks ahead: in flight during the MFMAs of this one and the next
     half8_t f[T];
     half4_t df[T];
 #pragma unroll
@@ -1120,24 +1121,26 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
       }
       mlp_tiles<T, FRAG_D0_NATURAL>(RegFrags{wreg}, f, df, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
     }
-    if (g == 0) {  // (r, g, b): six bytes of the sample's eight
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const uint32_t s = chunk * CH + 16u * t + c;
-        if (s < n) {
-          *reinterpret_cast<uint32_t*>(out + 4 * (size_t)s) = o.rg[t];
-          out[4 * (size_t)s + 2] = bits_h2(o.bx[t]).x;
-        }
-      }
+    // One 8-byte store per sample: (r, g, b) of every tile are in lane row 0, sigma of tile g in lane row g -- move tile g's
+    // colours to lane row g as well (v_permlane16_swap) and let the first T lane rows write 128 contiguous bytes each
+    // (three partial stores of 4 + 2 + 2 bytes per sample before).
+    static_assert(T == 1 || T == 2, "lane rows that hold a tile's outputs");
+    uint32_t rg_row = o.rg[0], bx_row = o.bx[0];
+    if constexpr (T == 2) {
+      rg_row = __builtin_amdgcn_permlane16_swap(o.rg[0], o.rg[1], false, false)[0];
+      bx_row = __builtin_amdgcn_permlane16_swap(o.bx[0], o.bx[1], false, false)[0];
     }
-    if (g < T) {  // sigma of tile g lives in lane row g
+    if (g < T) {
       const uint32_t s = chunk * CH + 16u * g + c;
-      if (s < n) out[4 * (size_t)s + 3] = o.sigma;
+      const uint32_t sigma_bits = (uint32_t)__builtin_bit_cast(unsigned short, o.sigma);
+      if (s < n) *reinterpret_cast<uint2*>(out + 4 * (size_t)s) = make_uint2(rg_row, (bx_row & 0xffffu) | (sigma_bits << 16));
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       fv[t] = fnext[t];
       dv[t] = dnext[t];
+      fnext[t] = fnext2[t];
+      dnext[t] = dnext2[t];
     }
   }
 }
