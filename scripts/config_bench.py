@@ -29,7 +29,7 @@ def run(name, desc, W, H, n_views, radius, opts=None, reps=4):
 
 desc2, k2, _ = models.build_model(log2_hashmap_size=19, H=128)
 run("config 2 (bound 1, 1 cascade)", desc2, 1920, 1080, 16, 4.0311)
-run("config 5 (64 requests of 800x800, two launches of 32)", desc2, 800, 800, 64, 4.0311)
+run("config 5 (64 requests of 800x800, one launch)", desc2, 800, 800, 64, 4.0311)
 desc4, k4, _ = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)
 o4 = nh.default_options(); o4.max_steps = 1024
 # config 4 from a snapshot in instant-ngp's own layout (aabb_scale 32 = bound 16: Morton-ordered fp16 density grid of six
