@@ -498,15 +498,21 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   }
   M.dilated_level_words = dilated_level_words;
   if (!dilated.empty() && dilated.size() * 4 <= (size_t)N_FRAGS * 64 * 16) M.lds_dilated_words = (uint32_t)dilated.size();
-  // The persistent form of the render kernel (one workgroup per CU, waves pull tiles from a queue) keeps every march
-  // table in LDS for the whole launch: hot instance, tables that fit beside its 16 waves' blocks.
+  // The persistent form of the render kernel (one workgroup per CU, waves pull strips from work queues) keeps every march
+  // table in LDS for the whole launch: tables that fit beside the blocks of its waves (16 hot, 12 wide, 12 or 8 generic).
   M.persistent = 0;
+  M.persist_waves = 0;
   M.n_cus = (uint32_t)c->n_cus;
-  if (c->allow_persistent && !M.generic && !M.wide && M.lds_coarse_words > 0) {
+  if (c->allow_persistent && M.lds_coarse_words > 0) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
-    if ((size_t)render_persistent_lds_fixed_bytes() + tables <= 160u * 1024u) {
-      M.persistent = 1;
-      M.lds_dilated_words = (uint32_t)dilated.size();
+    for (int waves : {render_persistent_waves(M.generic, M.wide), 8}) {
+      if (waves == 8 && !M.generic) break;  // (only the generic instance has a second workgroup size)
+      if ((size_t)render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) + tables <= 160u * 1024u) {
+        M.persistent = 1;
+        M.persist_waves = (uint32_t)waves;
+        M.lds_dilated_words = (uint32_t)dilated.size();
+        break;
+      }
     }
   }
   c->desc.mean_density = mean_density;

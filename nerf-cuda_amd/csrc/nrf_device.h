@@ -114,7 +114,8 @@ struct DevModel {
   uint32_t lds_coarse_words;  // words of occ_coarse staged in LDS by render_kernel (0: read it from global)
   uint32_t lds_ctab_floats;   // floats of cell_bound staged in LDS (0: read it from global)
   uint32_t lds_dilated_words;  // words of occ_dilated that fit the (not yet used) weight area of LDS during ray setup (0: global)
-  uint32_t persistent;      // 1: render_persistent_kernel may render this model (hot instance, every march table in LDS)
+  uint32_t persistent;      // 1: render_persistent_kernel renders this model (every march table fits in LDS beside its waves)
+  uint32_t persist_waves;   // waves of its workgroup (16 hot, 12 wide, 12 or 8 generic)
   uint32_t n_cus;           // compute units of the device: workgroups of the persistent kernel
 };
 

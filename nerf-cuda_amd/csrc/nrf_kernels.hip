@@ -670,7 +670,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 
 // ---------------------------------------------------- the persistent form ----
 // The same tile program as render_kernel, hot instance only, with the scheduling turned inside out: ONE workgroup of
-// PERSIST_WAVES waves per CU stays for the whole launch, stages the weight fragments, the level table and every march
+// persist_waves(NET) waves per CU stays for the whole launch, stages the weight fragments, the level table and every march
 // table (coarse + dilated occupancy, cell boundaries) into LDS once, and then every WAVE on its own pulls 8x8 tiles from
 // a work queue (one device-scope atomic per tile, issued one tile ahead) until the queue is empty.  Against
 // render_kernel this removes (a) the wave slots a 4-tile workgroup holds until its slowest tile is done (7-8 % of the
@@ -680,8 +680,9 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 // empty (no atomics: same-address device atomics cost ~12 ns each, see COUNTER_SLOTS).
 // Exit: every wave leaves its loop when its fetched queue position is >= the total, which every fetch sequence
 // reaches (the counter only grows); no wave waits for another one after the staging barrier.
-constexpr int PERSIST_WAVES = 16;
-constexpr int PERSIST_THREADS = 64 * PERSIST_WAVES;
+// waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
+// SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
+__host__ __device__ constexpr int persist_waves(int net) { return net == NET_HOT ? 16 : 12; }
 constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4;  // q_begin of every view + the total; the workgroup's block counter
 
 __device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, float* depth, int k_local, int lane, int px, int py,
@@ -706,8 +707,8 @@ struct PersistArgs {
   ViewBatch VB;
 };
 
-template <int MARCH>
-__global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
+template <int NET, int MARCH, int WAVES = persist_waves(NET)>
+__global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
                                                                               float4* __restrict__ rgba0, float* __restrict__ depth0,
                                                                               unsigned long long* __restrict__ counters,
                                                                               unsigned* __restrict__ queue) {
@@ -719,14 +720,16 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
   const DevModel& M = M0;
   const FrameParams& P = P0;
   const ViewBatch& VB = VB0;
-  const LdsMap lm = lds_map<NET_HOT>(smem, M, wave, PERSIST_WAVES);
+  constexpr int PERSIST_WAVES = WAVES;
+  constexpr bool GEN = NET == NET_GENERIC;
+  const LdsMap lm = lds_map<NET>(smem, M, wave, PERSIST_WAVES);
   uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(lm.tables);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
   uint32_t* dil_lds = reinterpret_cast<uint32_t*>(ctab_lds + M.lds_ctab_floats);
   int* q_lds = reinterpret_cast<int*>(dil_lds + M.lds_dilated_words);
   unsigned* sched = reinterpret_cast<unsigned*>(q_lds + MAX_VIEWS + 1);
   // ---- staged once per workgroup (= once per CU and launch)
-  stage_fragments<NET_HOT>(M, lm.wl);
+  if constexpr (!GEN) stage_fragments<NET>(M, lm.wl);  // (the generic instance streams its weights from global memory)
   for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
   for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
   for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
@@ -891,19 +894,30 @@ __global__ __launch_bounds__(PERSIST_THREADS, 1) void render_persistent_kernel(c
         float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
         float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
         float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
-        half_t e[16];
-        encode_dir16(M, u0, u1, u2, e);
+        if constexpr (GEN) {
+          lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
+          lm.gen.rayd[3 * lane + 1] = u1;
+          lm.gen.rayd[3 * lane + 2] = u2;
+        } else {
+          half_t e[16];
+          encode_dir16(M, u0, u1, u2, e);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          half2_t h;
-          h.x = e[2 * j];
-          h.y = e[2 * j + 1];
-          lm.W->dirf[lane][j] = h2_bits(h);
+          for (int j = 0; j < 8; ++j) {
+            half2_t h;
+            h.x = e[2 * j];
+            h.y = e[2 * j + 1];
+            lm.W->dirf[lane][j] = h2_bits(h);
+          }
+          if constexpr (NET == NET_WIDE) {  // the entries beyond the first sixteen are evaluated per sample (dir_entries8)
+            lm.gen.rayd[3 * lane] = u0;
+            lm.gen.rayd[3 * lane + 1] = u1;
+            lm.gen.rayd[3 * lane + 2] = u2;
+          }
         }
       }
       wave_sync();
       NRF_STAMP(t_setup_done);
-      tile_rounds<NET_HOT, true, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+      tile_rounds<NET, true, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
                                         alive, acc, ts);
 #ifdef NRF_PHASE_TIMING
       if (lane == 0) {
@@ -1429,7 +1443,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
-  if (M.persistent && !M.generic && !M.wide && lds_tab) {
+  if (M.persistent && lds_tab) {
     // work queues: per view the strip rows its region of interest touches (sharded: the local strips of those rows)
     const int strips_x = (P.tiles_x + 3) >> 2, N = P.shard_count, idx = P.shard_index;
     const int k_end = (P.n_local_tiles + 3) & ~3;
@@ -1458,10 +1472,11 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     VB.n_classes = P.queue_classes >= 1 && P.queue_classes <= 8 ? P.queue_classes : 8;
     VB.class_cols = (strips_x + N - 1) / N;  // a row holds at most this many of the rank's strips
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
-    const int lds = LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) +
-                    4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) + LDS_QUEUE_BYTES;
+    const int waves = (int)M.persist_waves;
+    const int lds = render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) +
+                    4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words);
     const long long tiles = (long long)P.n_local_tiles * VB.n_views;
-    const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + PERSIST_WAVES - 1) / PERSIST_WAVES));
+    const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + waves - 1) / waves));
     unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
     hipError_t e = hipMemsetAsync(queue, 0, 8 * sizeof(unsigned), st);
     if (e != hipSuccess) return e;
@@ -1469,17 +1484,28 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     int eb = 0;
     const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
     const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
-#define NRF_LAUNCH_PERSISTENT(U)                                                                                          \
+#define NRF_LAUNCH_PERSISTENT_W(G, U, WV)                                                                                 \
   do {                                                                                                                   \
-    e = allow_lds(render_persistent_kernel<U>, lds);                                                                     \
+    e = allow_lds(render_persistent_kernel<G, U, WV>, lds);                                                              \
     if (e != hipSuccess) return e;                                                                                       \
-    hipLaunchKernelGGL((render_persistent_kernel<U>), dim3(wgs), dim3(PERSIST_THREADS), lds, st, M, P, VB, (float4*)rgba, \
-                       (float*)depth, (unsigned long long*)counters, queue);                                             \
+    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,                \
+                       (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
   } while (0)
-    if (unit) NRF_LAUNCH_PERSISTENT(MARCH_UNIT);
-    else if (pow2) NRF_LAUNCH_PERSISTENT(MARCH_POW2);
-    else NRF_LAUNCH_PERSISTENT(MARCH_GENERIC);
+#define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G))
+    if (M.generic) {  // (the generic instance has one march form)
+      if (waves == 12) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12);
+      else NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 8);
+    } else if (M.wide) {
+      if (unit) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_UNIT);
+      else if (pow2) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_POW2);
+      else NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_GENERIC);
+    } else {
+      if (unit) NRF_LAUNCH_PERSISTENT(NET_HOT, MARCH_UNIT);
+      else if (pow2) NRF_LAUNCH_PERSISTENT(NET_HOT, MARCH_POW2);
+      else NRF_LAUNCH_PERSISTENT(NET_HOT, MARCH_GENERIC);
+    }
 #undef NRF_LAUNCH_PERSISTENT
+#undef NRF_LAUNCH_PERSISTENT_W
     return hipGetLastError();
   }
   const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
@@ -1650,7 +1676,13 @@ hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb
 }
 
 int render_lds_bytes() { return LDS_FIXED_BYTES; }
-int render_persistent_lds_fixed_bytes() { return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + PERSIST_WAVES * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES; }
+// LDS of the persistent workgroup of `waves` waves without its march tables (lds_map<NET> + the queue words)
+int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t gen_wave_bytes, int waves) {
+  if (generic) return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)gen_wave_bytes) + LDS_QUEUE_BYTES;
+  if (wide) return LDS_WFRAG_WIDE_BYTES + LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + LDS_RAYD_BYTES) + LDS_QUEUE_BYTES;
+  return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + waves * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
+}
+int render_persistent_waves(uint32_t generic, uint32_t wide) { return persist_waves(generic ? NET_GENERIC : (wide ? NET_WIDE : NET_HOT)); }
 int render_wide_lds_fixed_bytes() { return LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
 int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes) { return LDS_LEVEL_BYTES + RENDER_WAVES * ((int)sizeof(WaveLds) + (int)gen_wave_bytes); }

@@ -29,7 +29,8 @@ hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_sh
 hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n, void* out, hipStream_t st);
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
 int render_lds_bytes();
-int render_persistent_lds_fixed_bytes();
+int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t gen_wave_bytes, int waves);
+int render_persistent_waves(uint32_t generic, uint32_t wide);
 int render_lds_table_max_bytes();
 int render_wide_lds_fixed_bytes();  // wide instance: LDS of render_kernel without the march tables
 int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes);  // generic instance: LDS of render_kernel without the march tables

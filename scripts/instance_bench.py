@@ -1,0 +1,38 @@
+"""Throughput of the three network instances (register-resident / wide / generic) in both schedulings of the render kernel:
+16 views of 1920x1080 per launch, persistent form against NRF_PERSISTENT=0 (one workgroup per strip), same process."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "nerf-cuda_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import models, nerfhip as nh, synthetic as syn
+
+W, H, V = 1920, 1080, 16
+cams = np.stack([syn.default_camera(W, H)] * V)
+poses = np.stack([syn.orbit_pose(45.0 * (i % 8), 30.0) for i in range(V)])
+SHAPES = [
+    ("base.json shape (register-resident)", {}),
+    ("Frequency-12 directions (wide)", dict(dir_otype="Frequency", n_frequencies=12)),
+    ("32 neurons (generic)", dict(n_neurons=32)),
+    ("128 neurons (generic)", dict(n_neurons=128)),
+    ("F = 4 x 8 levels, Smoothstep (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep")),
+    ("SH degree 6 (generic)", dict(sh_degree=6)),
+]
+for name, kw in SHAPES:
+    desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128, **kw)
+    res = []
+    for persistent in ("0", "1"):
+        os.environ["NRF_PERSISTENT"] = persistent
+        c = nh.NerfHip(0); c.load_model(desc); c.set_resolution(W, H); c.set_max_views(V)
+        s = torch.cuda.Stream()
+        c.render_views(cams, poses, stream=s.cuda_stream); torch.cuda.synchronize()
+        samples = c.stats().n_samples
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            c.render_views(cams, poses, stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res.append((dt / V * 1e3, samples / dt / 1e6))
+        c.close()
+    print(f"{name:44s} per strip {res[0][0]:7.3f} ms/view {res[0][1]:7.0f} Msamples/s | persistent {res[1][0]:7.3f} ms/view {res[1][1]:7.0f} Msamples/s "
+          f"({100 * (res[0][0] / res[1][0] - 1):+.0f} %)", flush=True)
