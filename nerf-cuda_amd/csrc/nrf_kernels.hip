@@ -1,16 +1,18 @@
 // nrf_kernels.hip -- gfx950 kernels of the render hot path and their launchers.
 //
-// render_kernel is the product: ONE launch per frame -- or per batch of up to
-// 32 camera views -- replaces the reference's host-driven loop of ~15 launches
-// + a blocking D2H copy per march iteration (R/src/nerf_render.cu:269-338).  One wavefront owns one 8x8 pixel tile (64
-// rays) for the tile's whole life:
+// The render kernel is the product: ONE launch per frame -- or per batch of up to 128 camera views -- replaces the
+// reference's host-driven loop of ~15 launches + a blocking D2H copy per march iteration
+// (R/src/nerf_render.cu:269-338).  One wavefront owns one 8x8 pixel tile (64 rays) for the tile's whole life:
 //     raygen -> near/far -> { march (ballot/mbcnt sample compaction into LDS)
 //                             -> hash-grid gather + SH -> both MLPs on MFMA
 //                             -> alpha compositing } until every ray is dead
 //     -> background blend -> RGBA / depth store.
-// Nothing but the final pixels ever goes to HBM; the only global reads are the
-// hash table, the occupancy bitfield and 20 KiB of weight fragments per
-// workgroup (kept in LDS).
+// Nothing but the final pixels ever goes to HBM; the only global reads are the hash table, the occupancy bitfield and
+// the weight fragments (kept in LDS).  Two schedulings of that tile program (tile_rounds is shared):
+//   render_persistent_kernel  one workgroup per CU for the whole launch, tables staged once, waves pull strips from
+//                             per-XCD work queues -- the default;
+//   render_kernel             one workgroup per strip of 4 tiles, scheduled by the dispatcher -- models whose march
+//                             tables do not fit beside the persistent workgroup, and NRF_PERSISTENT=0.
 // The stage kernels below it expose the same device functions one stage at a
 // time for the parity tests (include/nerfhip.h "stage entry points").
 
@@ -669,17 +671,18 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 }
 
 // ---------------------------------------------------- the persistent form ----
-// The same tile program as render_kernel, hot instance only, with the scheduling turned inside out: ONE workgroup of
-// persist_waves(NET) waves per CU stays for the whole launch, stages the weight fragments, the level table and every march
-// table (coarse + dilated occupancy, cell boundaries) into LDS once, and then every WAVE on its own pulls 8x8 tiles from
-// a work queue (one device-scope atomic per tile, issued one tile ahead) until the queue is empty.  Against
-// render_kernel this removes (a) the wave slots a 4-tile workgroup holds until its slowest tile is done (7-8 % of the
-// slot time, profiles/r02/phase_timing_wg_hold.txt), (b) the per-strip staging of ~29 KB and its three barriers, and
-// (c) the borrowing of the weight area by the dilated table.  The queue only holds the strip rows a view's region of
-// interest touches; the rest of the frame is background and is filled by a static sweep once a wave finds the queue
-// empty (no atomics: same-address device atomics cost ~12 ns each, see COUNTER_SLOTS).
-// Exit: every wave leaves its loop when its fetched queue position is >= the total, which every fetch sequence
-// reaches (the counter only grows); no wave waits for another one after the staging barrier.
+// The same tile program as render_kernel with the scheduling turned inside out: ONE workgroup of persist_waves waves per
+// CU stays for the whole launch, stages the weight fragments, the level table and every march table (coarse + dilated
+// occupancy, cell boundaries) into LDS once, and then every WAVE on its own pulls 8x8 tiles from the work queues
+// (below) until they are empty.  Against render_kernel this removes (a) the wave slots a 4-tile workgroup holds until
+// its slowest tile is done (7-8 % of the slot time, profiles/r02/phase_timing_wg_hold.txt), (b) the per-strip staging
+// of 29 KB (44 KB of tables alone with five cascades) and its three barriers, and (c) the borrowing of the weight area
+// by the dilated table.  The queues only hold the strip rows a view's region of interest touches; the rest of the
+// frame is background and is filled by a static sweep once a wave finds the queues empty (no atomics: same-address
+// device atomics cost ~12 ns each, see COUNTER_SLOTS).
+// Exit: a wave leaves its loop when every queue has handed out its last position (the counters only grow, and a
+// workgroup visits every class once); no wave waits for another one after the staging barrier, except -- for the
+// length of one device atomic -- for the wave of its workgroup that is fetching the next strip.
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
 __host__ __device__ constexpr int persist_waves(int net) { return net == NET_HOT ? 16 : 12; }
