@@ -244,6 +244,14 @@ int nrf_render_batch(nrf_context* ctx, int n_views, const float* cams, const flo
  * returns to the context's own buffers.  Replaces the host round trip
  * render_frame -> host_to_accumulate_buffer of main.cu:87-129.               */
 int nrf_bind_output(nrf_context* ctx, void* rgba, void* depth);
+/* Binds a caller-owned device buffer of packed 8-bit pixels -- the reference's output format
+ * (unsigned char)(255.0 * x) of r, g, b and depth (nerf_render.cu:352-359) as r | g << 8 | b << 16 | depth << 24,
+ * uint32 [n_views * view_stride_px], same pixel order as the float planes (tile-major for a shard) -- as the
+ * target of subsequent renders: the kernel writes these 4 bytes per pixel instead of the 20 of the float planes,
+ * bit-identical to nrf_quantize_rgbd8 of them.  The frame is then the caller's to read (nrf_read_* return
+ * NRF_E_STATE, nrf_frame::rgba / depth are NULL); NULL returns to the float planes.  What a rank of a multi-GPU
+ * step binds: its shard goes onto the wire as rendered.                                                    */
+int nrf_bind_output_rgbd8(nrf_context* ctx, void* rgbd8);
 /* nrf_render on the context's own stream WITHOUT waiting for it (the way the
  * reference overlaps its NGPU devices, nerf_render.cu:252-362); nrf_sync waits. */
 int nrf_render_async(nrf_context* ctx, const float cam[4], const float pose[16], nrf_frame* out);

@@ -194,6 +194,7 @@ struct nrf_context {
   void* d_depth8 = nullptr;
   void* bound_rgba = nullptr;  // caller-owned targets (nrf_bind_output)
   void* bound_depth = nullptr;
+  void* bound_rgbd8 = nullptr;  // caller-owned packed 8-bit target (nrf_bind_output_rgbd8)
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
   int march_budget = 256;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
@@ -281,6 +282,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.max_steps = c->opt.max_steps;
   P.march_budget = c->march_budget;
   P.centre_out = c->centre_out ? 1 : 0;
+  P.out_rgbd8 = c->bound_rgbd8 ? 1 : 0;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
 }
@@ -930,7 +932,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
   if (c->grid_missing)
     return fail(NRF_E_STATE, "the model was loaded without a density grid: call nrf_generate_density_grid first");
-  if (!c->bound_rgba && n_views > c->max_views)
+  if (!c->bound_rgba && !c->bound_rgbd8 && n_views > c->max_views)
     return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
   FrameParams P;
   fill_frame_params(c, cams, poses, P);
@@ -939,6 +941,10 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   HIP_TRY(hipEventRecord(c->ev0, st));
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
   void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
+  if (c->bound_rgbd8) {  // 4 bytes per pixel where the depth plane would be (store_pixel)
+    rgba = nullptr;
+    depth = c->bound_rgbd8;
+  }
   for (int first = 0; first < n_views; first += MAX_VIEWS) {
     ViewBatch VB;
     std::memset(&VB, 0, sizeof(VB));
@@ -949,11 +955,11 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
       for (int i = 0; i < 4; ++i) VB.v[v].cam[i] = cams[4 * (size_t)(first + v) + i];
       view_roi(VB.v[v].R, VB.v[v].org, VB.v[v].cam, c->dm.occ_box, c->W, c->H, VB.v[v].roi);
     }
-    HIP_TRY(launch_render(c->dm, P, VB, (char*)rgba + (size_t)first * c->n_out_px * 16, (char*)depth + (size_t)first * c->n_out_px * 4,
+    HIP_TRY(launch_render(c->dm, P, VB, rgba ? (char*)rgba + (size_t)first * c->n_out_px * 16 : nullptr, (char*)depth + (size_t)first * c->n_out_px * 4,
                           c->d_counters, st));
   }
   c->last_rgba = rgba;
-  c->last_depth = depth;
+  c->last_depth = rgba ? depth : nullptr;  // (a packed 8-bit frame is the caller's to read)
   c->last_views = n_views;
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->last_stream = st;
@@ -964,7 +970,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
     out->height = c->H;
     out->n_tiles = c->n_local_tiles;
     out->rgba = rgba;
-    out->depth = depth;
+    out->depth = rgba ? depth : nullptr;
     out->tile_major = P.tile_major;
     out->n_views = n_views;
     out->view_stride_px = (int64_t)c->n_out_px;
@@ -1022,6 +1028,14 @@ int nrf_bind_output(nrf_context* c, void* rgba, void* depth) {
   if ((rgba == nullptr) != (depth == nullptr)) return fail(NRF_E_INVALID, "bind both planes or neither");
   c->bound_rgba = rgba;
   c->bound_depth = depth;
+  c->bound_rgbd8 = nullptr;
+  return NRF_OK;
+}
+
+int nrf_bind_output_rgbd8(nrf_context* c, void* rgbd8) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  c->bound_rgbd8 = rgbd8;
+  if (rgbd8) c->bound_rgba = c->bound_depth = nullptr;
   return NRF_OK;
 }
 
@@ -1051,6 +1065,7 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
 int nrf_read_view_f32(nrf_context* c, int view, float* rgba, float* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  if (!c->last_rgba) return fail(NRF_E_STATE, "the last render went to a packed 8-bit buffer (nrf_bind_output_rgbd8): it is the caller's to read");
   if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_f32 needs a single-shard (row-major) frame");
   if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);
@@ -1067,6 +1082,7 @@ int nrf_read_f32(nrf_context* c, float* rgba, float* depth) { return nrf_read_vi
 int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  if (!c->last_rgba) return fail(NRF_E_STATE, "the last render went to a packed 8-bit buffer (nrf_bind_output_rgbd8): it is the caller's to read");
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->last_stream));
@@ -1079,6 +1095,7 @@ int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
 int nrf_read_view_u8(nrf_context* c, int view, uint8_t* rgb, uint8_t* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
+  if (!c->last_rgba) return fail(NRF_E_STATE, "the last render went to a packed 8-bit buffer (nrf_bind_output_rgbd8): it is the caller's to read");
   if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_u8 needs a single-shard (row-major) frame");
   if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);

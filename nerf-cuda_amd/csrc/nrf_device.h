@@ -160,6 +160,7 @@ struct FrameParams {
   int max_steps;
   int march_budget;  // cell trips a lane may spend per round (tuning knob, default 256)
   int queue_classes;  // persistent kernel, unsharded frames: work queues (8: one per XCD; 1: a single queue); 0: default
+  int out_rgbd8;    // the frame goes to a packed 8-bit buffer (r | g << 8 | b << 16 | depth << 24) passed as the depth plane
   int centre_out;   // persistent kernel: a view's strip rows are queued from the middle of its region of interest outwards
 };
 

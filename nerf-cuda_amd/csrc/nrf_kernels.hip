@@ -276,6 +276,33 @@ __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
     for (int i = threadIdx.x; i < 4 * (RK_WIDE - 1) * 64; i += blockDim.x) wl[N_FRAGS * 64 + i] = M.wfrag[FRAG_R0X * 64 + i];
 }
 
+// (unsigned char)(255.0 * x), saturating, NaN -> 0 (R/src/nerf_render.cu:352-359, deviation D-2)
+__device__ __forceinline__ unsigned char quant_u8(float v) {
+  const double s = 255.0 * (double)v;
+  if (!(s > 0.0)) return 0;
+  if (s >= 255.0) return 255;
+  return (unsigned char)s;
+}
+
+// One pixel of a frame.  Float planes (rgba [px][4], depth [px]) -- or, when the caller bound a packed 8-bit target
+// (nrf_bind_output_rgbd8: FrameParams::out_rgbd8), the reference's output format r | g << 8 | b << 16 | depth << 24
+// written where the depth plane would be (4 bytes per pixel either way, so the per-view offsets are the same);
+// padding pixels of a shard's tile-major buffer are zero in both forms.
+__device__ __forceinline__ uint32_t pack_rgbd8(float4 c, float d) {
+  return (uint32_t)quant_u8(c.x) | ((uint32_t)quant_u8(c.y) << 8) | ((uint32_t)quant_u8(c.z) << 16) | ((uint32_t)quant_u8(d) << 24);
+}
+__device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, float* depth, int k_local, int lane, int px, int py,
+                                            bool in_img, float4 color, float dn) {
+  if (!in_img && !P.tile_major) return;
+  const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
+  if (P.out_rgbd8) {
+    reinterpret_cast<uint32_t*>(depth)[idx] = in_img ? pack_rgbd8(color, dn) : 0u;
+  } else {
+    rgba[idx] = in_img ? color : make_float4(0.f, 0.f, 0.f, 0.f);
+    depth[idx] = in_img ? dn : 0.f;
+  }
+}
+
 // What a ray has composited so far, and a wave's statistics (both live in registers).
 struct TileAcc {
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
@@ -468,14 +495,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
     // waves of the workgroup take this exit together, before any barrier)
     const int sx0 = (strip % strips_x) * 32, sy0 = ty * 8;
     if (sx0 > V.roi[2] || sx0 + 31 < V.roi[0] || sy0 > V.roi[3] || sy0 + 7 < V.roi[1]) {
-      const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
-      if (in_img) {
-        rgba[idx] = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
-        depth[idx] = 0.f;
-      } else if (P.tile_major && valid_tile) {
-        rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        depth[idx] = 0.f;
-      }
+      if (valid_tile) store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f), 0.f);
       return;
     }
   }
@@ -621,17 +641,11 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 #endif
 
   // ---- get_image_and_depth, R/include/nerf-cuda/render_utils.h:257-264 (depth 0 when the ray missed the aabb)
-  if (in_img) {
+  {
     const float bgw = (1 - ws) * P.bg_color;
     const float span = far - near;
     const float dn = span > 0.0f ? fmaxf(dep - near, 0.0f) / span : 0.0f;
-    const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
-    rgba[idx] = make_float4(cr + bgw, cg + bgw, cb + bgw, ws);
-    depth[idx] = dn;
-  } else if (P.tile_major) {
-    const size_t idx = (size_t)k_local * 64 + lane;
-    rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    depth[idx] = 0.f;
+    store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(cr + bgw, cg + bgw, cb + bgw, ws), dn);
   }
   counters += (blockIdx.x % COUNTER_SLOTS) * 16;  // see COUNTER_SLOTS
   if (lane == 0 && n_rounds != 0) {           // waves that never sampled (background) add nothing
@@ -687,19 +701,6 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
 __host__ __device__ constexpr int persist_waves(int net) { return net == NET_HOT ? 16 : 12; }
 constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4;  // q_begin of every view + the total; the workgroup's block counter
-
-__device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, float* depth, int k_local, int lane, int px, int py,
-                                            bool in_img, float4 color, float dn) {
-  if (in_img) {
-    const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
-    rgba[idx] = color;
-    depth[idx] = dn;
-  } else if (P.tile_major) {  // padding pixels of a shard's tile-major buffer
-    const size_t idx = (size_t)k_local * 64 + lane;
-    rgba[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    depth[idx] = 0.f;
-  }
-}
 
 // The kernel's by-value arguments as they lie in the kernarg segment (the tile loop re-reads them per tile through a
 // pointer the compiler cannot see through: otherwise every field of the three structs is hoisted out of the loop and
@@ -1402,14 +1403,6 @@ __global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ g
     const float* src = gathered + ((((size_t)shard * n_views + view) * tiles_per_shard + k) * 64 + l) * C;
     for (int ch = 0; ch < C; ++ch) out[i * C + ch] = src[ch];
   }
-}
-
-// (unsigned char)(255.0 * x), saturating, NaN -> 0 (R/src/nerf_render.cu:352-359, deviation D-2)
-__device__ __forceinline__ unsigned char quant_u8(float v) {
-  const double s = 255.0 * (double)v;
-  if (!(s > 0.0)) return 0;
-  if (s >= 255.0) return 255;
-  return (unsigned char)s;
 }
 
 __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ rgba, const float* __restrict__ depth, int n,

@@ -152,6 +152,7 @@ _SIGS = {
     "nrf_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_bind_output_rgbd8": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nrf_render_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
     "nrf_sync": (C.c_int, [C.c_void_p]),
     "nrf_generate_rays_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
@@ -569,6 +570,10 @@ class NerfHip:
 
     def bind_output(self, rgba_ptr, depth_ptr):
         _check(self.lib.nrf_bind_output(self.h, C.c_void_p(rgba_ptr or 0), C.c_void_p(depth_ptr or 0)))
+
+    def bind_output_rgbd8(self, rgbd8_ptr):
+        """Packed 8-bit target (r | g << 8 | b << 16 | depth << 24 per pixel) of subsequent renders; 0: back to the float planes."""
+        _check(self.lib.nrf_bind_output_rgbd8(self.h, C.c_void_p(rgbd8_ptr or 0)))
 
     def read_f32(self):
         rgba = np.empty((self.height, self.width, 4), np.float32)

@@ -149,3 +149,52 @@ def test_persistent_kernel_other_instances(kw):
     for shard in ((0, 1), (2, 3)):
         ref = _render(desc, 300, 180, poses, STRIP, shard=shard)
         _same(_render(desc, 300, 180, poses, PERSISTENT, shard=shard), ref, (kw, shard))
+
+
+@pytest.mark.parametrize("env", [STRIP, PERSISTENT], ids=["per-strip", "persistent"])
+@pytest.mark.parametrize("shard", [(0, 1), (1, 3)])
+def test_packed_8bit_output_equals_quantised_float_planes(model, env, shard):
+    """nrf_bind_output_rgbd8: the kernel writes the reference's 8-bit pixels itself; bit-identical to nrf_quantize_rgbd8 of
+    the float planes, for whole frames and for a shard's tile-major buffer (padding pixels zero), in both schedulings."""
+    desc, _ = model
+    W, H = 333, 211
+    poses = _poses("orbit", 3) + _poses("inside", 1) + _poses("away", 1)
+    n = len(poses)
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = nh.NerfHip(0)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    ctx.load_model(desc)
+    o = nh.default_options()
+    o.shard_index, o.shard_count = shard
+    ctx.set_options(o)
+    ctx.set_resolution(W, H)
+    n_px = nh.tiles_per_shard(W, H, shard[1]) * 64 if shard[1] > 1 else W * H
+    rgba = torch.zeros((n, n_px, 4), device="cuda")
+    depth = torch.zeros((n, n_px), device="cuda")
+    want = torch.zeros((n, n_px), dtype=torch.int32, device="cuda")
+    got = torch.full((n, n_px), 0x07070707, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.bind_output(rgba.data_ptr(), depth.data_ptr())
+    ctx.render_views(cams, np.stack(poses))
+    ctx.quantize_rgbd8(rgba.data_ptr(), depth.data_ptr(), n * n_px, want.data_ptr())
+    ctx.bind_output_rgbd8(got.data_ptr())
+    f = ctx.render_views(cams, np.stack(poses))
+    torch.cuda.synchronize()
+    assert not f.rgba and not f.depth  # the packed frame is the caller's
+    with pytest.raises(nh.NerfHipError):
+        ctx.read_f32()
+    g, w = got.cpu().numpy(), want.cpu().numpy()
+    if shard[1] > 1:  # padding tiles at the end of an uneven shard's buffer are nobody's pixels
+        written = g != 0x07070707
+        assert written.mean() > 0.97 and np.array_equal(g[written], w[written])
+    else:
+        assert np.array_equal(g, w)
+    ctx.bind_output_rgbd8(0)      # back to the context's own float planes
+    ctx.set_max_views(n)
+    ctx.render_views(cams, np.stack(poses))
+    ctx.close()
