@@ -14,8 +14,9 @@ idle (one frame alone: 1.0 ms; in a batch: 0.83 ms per frame).
 Multi-GPU (one process per GPU, RCCL):
   --config 3 (default for N > 1; BASELINE.json configs[2]): every frame's tile
       strips are dealt round-robin to the ranks (tile-parallel: every rank renders
-      1/N of EVERY frame), two steps are in flight, every rank quantises its shard
-      to the reference's 8-bit image format (r, g, b, depth: 4 B/px) and the only
+      1/N of EVERY frame), two steps are in flight, every rank renders its shard
+      straight into the reference's 8-bit image format (r, g, b, depth: 4 B/px;
+      nrf_bind_output_rgbd8), all renders of a rank go to one stream, and the only
       exchange is one RCCL gather of the batch's shards to the step's sink rank
       (step % N by default, --gather-root 0: always rank 0), followed by an untile
       kernel there (--gather-format f32 ships float RGBA instead).
@@ -217,6 +218,13 @@ def main():
     class Slot:
         pass
 
+    # N > 1: the renders of all slots go to ONE stream.  The persistent render kernel owns every compute unit it runs on, so
+    # a kernel of another stream gets a wave slot only if it becomes eligible together with a render: the exchange of step i
+    # waits for render i's event and render i + 1 for render i on its stream -- both start when render i ends, RCCL's few
+    # workgroups take their slots and the render the rest.  With a stream per slot render i + 1 is resident before render i
+    # has ended, and the exchange of step i waits for the next gap (scripts/overlap_test.py: 17.2 against 14.2 ms per step).
+    render_stream = torch.cuda.Stream(dev) if world > 1 else None
+    packed = world > 1 and args.gather_format == "rgbd8"
     slots = []
     for _ in range(depth):
         sl = Slot()
@@ -224,16 +232,22 @@ def main():
         sl.ctx.load_model(desc)
         sl.ctx.set_options(opts)
         sl.ctx.set_resolution(W, H)
-        sl.stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: NULL would make the ABI synchronise per call
-        sl.rgba = torch.zeros((V, n_px, 4), device=dev)
-        sl.depth = torch.zeros((V, n_px), device=dev)
-        sl.ctx.bind_output(sl.rgba.data_ptr(), sl.depth.data_ptr())
+        # a real (non-NULL) stream: NULL would make the ABI synchronise per call
+        sl.stream = render_stream if render_stream is not None else torch.cuda.Stream(dev)
+        if packed:
+            # the kernel writes the reference's 8-bit pixels (r, g, b, depth: nerf_render.cu:345-359) itself: the shard goes
+            # onto the wire as rendered, 4 B/px instead of 20 B/px of float planes and no quantise pass
+            sl.send = torch.zeros((V, n_px), dtype=torch.int32, device=dev)
+            sl.ctx.bind_output_rgbd8(sl.send.data_ptr())
+        else:
+            sl.rgba = torch.zeros((V, n_px, 4), device=dev)
+            sl.depth = torch.zeros((V, n_px), device=dev)
+            sl.ctx.bind_output(sl.rgba.data_ptr(), sl.depth.data_ptr())
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
         if world > 1:
             is_sink = rank == 0 or args.gather_root == "rotate"  # this rank assembles (some of) the steps' frames
-            if args.gather_format == "rgbd8":  # 4-byte pixels: one int32 "channel"
-                sl.send = torch.zeros((V, n_px), dtype=torch.int32, device=dev)
+            if packed:  # 4-byte pixels: one int32 "channel"
                 sl.all = torch.empty((world, V, n_px), dtype=torch.int32, device=dev) if is_sink else None
                 sl.frame = (sl.all.view(world * V, H, W) if replica else
                             torch.empty((V, H, W), dtype=torch.int32, device=dev)) if is_sink else None
@@ -265,9 +279,6 @@ def main():
         if world > 1:
             # the one exchange of the path: every rank's shard / frames -> the step's sink rank (direct xGMI sends: xGMI
             # is point-to-point, so a gather moves 1/N-th of what an all-gather would), untile there
-            if args.gather_format == "rgbd8":  # nerf_render.cu:345-359 on the rendering GPU, 4 B/px on the wire
-                sl.ctx.quantize_rgbd8(sl.rgba.data_ptr(), sl.depth.data_ptr(), V * n_px, sl.send.data_ptr(),
-                                      stream=sl.stream.cuda_stream)
             sl.rendered.record(sl.stream)
             # the rank that assembles this step's frames: step % N -- the receive of N - 1 shards (link-bound: 930 MB over
             # seven xGMI links at N = 8) and the untile of the step's frames are then every rank's duty once in N steps
