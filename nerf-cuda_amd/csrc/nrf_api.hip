@@ -945,10 +945,17 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
     rgba = nullptr;
     depth = c->bound_rgbd8;
   }
-  for (int first = 0; first < n_views; first += MAX_VIEWS) {
+  // views per launch: NRF_MAX_VIEWS, fewer when the frames are so large that the persistent kernel's 24-bit queue positions
+  // (strip rows of all views x strips per row) would not hold the launch (8K frames: 64 views)
+  int per_launch = MAX_VIEWS;
+  {
+    const long long per_view = (long long)P.tiles_y * ((P.tiles_x + 3) / 4);
+    if (per_view * per_launch >= 0xffffff) per_launch = (int)std::max(1LL, 0xfffffeLL / std::max(per_view, 1LL));
+  }
+  for (int first = 0; first < n_views; first += per_launch) {
     ViewBatch VB;
     std::memset(&VB, 0, sizeof(VB));
-    VB.n_views = n_views - first < MAX_VIEWS ? n_views - first : MAX_VIEWS;
+    VB.n_views = n_views - first < per_launch ? n_views - first : per_launch;
     VB.view_stride_px = c->n_out_px;
     for (int v = 0; v < VB.n_views; ++v) {
       nerf_matrix_to_ngp(poses + 16 * (size_t)(first + v), c->desc.scale, VB.v[v].R, VB.v[v].org);
