@@ -937,7 +937,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   FrameParams P;
   fill_frame_params(c, cams, poses, P);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, COUNTER_BYTES, st));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, COUNTER_BYTES + RENDER_QUEUE_BYTES, st));  // statistics + the first launch's work queues
   HIP_TRY(hipEventRecord(c->ev0, st));
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
   void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
@@ -963,7 +963,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
       view_roi(VB.v[v].R, VB.v[v].org, VB.v[v].cam, c->dm.occ_box, c->W, c->H, VB.v[v].roi);
     }
     HIP_TRY(launch_render(c->dm, P, VB, rgba ? (char*)rgba + (size_t)first * c->n_out_px * 16 : nullptr, (char*)depth + (size_t)first * c->n_out_px * 4,
-                          c->d_counters, st));
+                          c->d_counters, st, first == 0));
   }
   c->last_rgba = rgba;
   c->last_depth = rgba ? depth : nullptr;  // (a packed 8-bit frame is the caller's to read)

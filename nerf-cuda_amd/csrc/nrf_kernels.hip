@@ -1434,7 +1434,7 @@ static hipError_t allow_lds(K kernel, int bytes) {
 static int gen_lds_bytes(const DevModel& M, int waves) { return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)M.gen_wave_bytes); }
 
 hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
-                         hipStream_t st) {
+                         hipStream_t st, bool queues_are_zero) {
   ViewBatch VB = VBin;
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
   const int blocks = VB.blocks_per_view * VB.n_views;
@@ -1474,7 +1474,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     const long long tiles = (long long)P.n_local_tiles * VB.n_views;
     const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + waves - 1) / waves));
     unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
-    hipError_t e = hipMemsetAsync(queue, 0, 8 * sizeof(unsigned), st);
+    hipError_t e = hipSuccess;
+    if (!queues_are_zero) e = hipMemsetAsync(queue, 0, RENDER_QUEUE_BYTES, st);  // (the caller's statistics memset covered them)
     if (e != hipSuccess) return e;
     const bool pow2_h = (M.H & (M.H - 1)) == 0;
     int eb = 0;
