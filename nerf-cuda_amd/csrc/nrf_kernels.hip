@@ -754,9 +754,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   // to the next class when a queue runs dry, so the XCDs balance at the end.  Sharded frames (a rank's strips are
   // every N-th one): the same with the rank's own strips of a row -- its j-th strip of every row belongs to class
   // j % 8, and the strips of a column are N apart in the rank's numbering whatever the row.
-  // A queue entry is one strip (4 tiles); 4 x 4-tile blocks were 2 % slower in 16-view
-  // launches and 13 % slower for one view (the 16 tiles of a block at the object's centre are half of a CU's share);
-  // groups of 2 or 4 adjacent columns per class measured like single columns, groups of 8 were 2 % slower.
+  // A queue entry is one strip (4 tiles); 4 x 4-tile blocks were 2 % slower in 16-view launches and 13 % slower for one
+  // view (the 16 tiles of a block at the object's centre are half of a CU's share); groups of 2 or 4 adjacent columns
+  // per class measured like single columns, groups of 8 were 2 % slower.
   //   sched (LDS, one word per workgroup) = classes moved past << 29 | queue position << 5 | tiles taken
   const unsigned n_cls = (unsigned)VB0.n_classes, cls_cols = (unsigned)VB0.class_cols, n_units = (unsigned)VB0.q_total;
   const unsigned cls0 = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) % n_cls;  // HW_REG_XCC_ID[3:0]
@@ -802,8 +802,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     const DevModel& M = *(const DevModel*)&ka->M;
     const FrameParams& P = *(const FrameParams*)&ka->P;
     const ViewBatch& VB = *(const ViewBatch*)&ka->VB;
-    // queue position -> (unit, column), unit -> view.  A unit is a strip row of a view's region of interest (sharded: a
-    // local strip); the views' units are numbered one after the other.
+    // queue position -> (unit, column), unit -> view.  A unit is a strip row of a view's region of interest; the views'
+    // units are numbered one after the other.
     const unsigned cls = (cls0 + moved) % n_cls, ncols = (cls_cols - cls + n_cls - 1u) / n_cls;
     const int u = (int)(pos / ncols), j = (int)(pos - (unsigned)u * ncols);
     static_assert(MAX_VIEWS == 128, "two ballots cover the views");
