@@ -85,7 +85,8 @@ doc = {
                 "transcendentals in 8, an MFMA holds the issue port for 8 (scripts/issue_rate/issue_rate.hip, "
                 "profiles/r02/issue_rate.txt).  The busiest unit is the texture addresser: every 64-lane gather of "
                 "4-byte table entries occupies it for ~17 cycles (4 addresses per clock), 128 such gathers per 16 samples.  "
-                "HBM is not the limiter: hbm_bytes_per_launch / kernel time is ~1 TB/s (the table lives in L2 / Infinity Cache).",
+                f"HBM is not the limiter: hbm_bytes_per_launch / kernel time is {(g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / (statistics.mean(agg[grid]['_ms']) * 1e-3) / 1e12:.1f} TB/s "
+                "(the table lives in L2 / Infinity Cache).",
     },
 }
 Path(out).write_text(json.dumps(doc, indent=1) + "\n")
