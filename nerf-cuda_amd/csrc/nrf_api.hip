@@ -507,14 +507,24 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   M.n_cus = (uint32_t)c->n_cus;
   if (c->allow_persistent && M.lds_coarse_words > 0) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
+    // generic instance: 12 waves with the weight fragments in LDS, 12 waves without, 8 with, 8 without -- the first that fits
+    // (NRF_GEN_WLDS=0: never stage the fragments)
+    const bool allow_wlds = !(std::getenv("NRF_GEN_WLDS") && std::atoi(std::getenv("NRF_GEN_WLDS")) == 0);
+    M.gen_weights_lds = 0;
     for (int waves : {render_persistent_waves(M.generic, M.wide), 8}) {
       if (waves == 8 && !M.generic) break;  // (only the generic instance has a second workgroup size)
-      if ((size_t)render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) + tables <= 160u * 1024u) {
-        M.persistent = 1;
-        M.persist_waves = (uint32_t)waves;
-        M.lds_dilated_words = (uint32_t)dilated.size();
-        break;
+      const size_t fixed = (size_t)render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) + tables;
+      for (int wlds : {1, 0}) {
+        if (wlds && (!M.generic || !allow_wlds)) continue;
+        if (fixed + (wlds ? 16u + M.gen_frag_bytes : 0u) <= 160u * 1024u) {
+          M.persistent = 1;
+          M.persist_waves = (uint32_t)waves;
+          M.gen_weights_lds = (uint32_t)wlds;
+          M.lds_dilated_words = (uint32_t)dilated.size();
+          break;
+        }
       }
+      if (M.persistent) break;
     }
   }
   c->desc.mean_density = mean_density;
@@ -824,6 +834,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.wide = (!generic && wide) ? 1u : 0u;
   M.gen = (const GenModel*)c->d_gen;
   M.gen_wave_bytes = gen_wave_bytes;
+  M.gen_frag_bytes = generic ? (uint32_t)(frags.size() * 2) : 0u;
   c->gen = G;
   // the density grid of the snapshot (nerf_render.cu:447-466) -- or none yet: nrf_generate_density_grid evaluates it
   // from the network (NerfRender::generate_density_grid); until then the model cannot be rendered

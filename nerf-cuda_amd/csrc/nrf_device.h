@@ -116,6 +116,8 @@ struct DevModel {
   uint32_t lds_dilated_words;  // words of occ_dilated that fit the (not yet used) weight area of LDS during ray setup (0: global)
   uint32_t persistent;      // 1: render_persistent_kernel renders this model (every march table fits in LDS beside its waves)
   uint32_t persist_waves;   // waves of its workgroup (16 hot, 12 wide, 12 or 8 generic)
+  uint32_t gen_frag_bytes;  // generic instance: bytes of its weight fragments
+  uint32_t gen_weights_lds; // generic instance, persistent kernel: the fragments are staged in LDS (they fit beside rows and tables)
   uint32_t n_cus;           // compute units of the device: workgroups of the persistent kernel
 };
 

@@ -65,6 +65,7 @@ struct GenLds {
   float* rayd;   // [64 rays][3]: 0.5 d + 0.5 of every ray (nerf_render.cu:313-314)
   half_t* X;     // [GEN_SAMPLES][act_stride]
   half_t* Y;
+  const uint4* wfrag;  // the layers' weight fragments: DevModel::wfrag (global memory) or the persistent kernel's LDS copy
 };
 
 // ---------------------------------------------------------------- hash grid ----
@@ -302,7 +303,7 @@ template <bool DENSITY_ONLY>
 __device__ __forceinline__ void gen_mlps(const DevModel& M, const GenModel& G, const GenLds& Lw, int lane, const int (&ray)[GEN_TILES],
                                          float4_t (&out)[GEN_TILES]) {
   const int g = lane >> 4, c = lane & 15;
-  const uint4* __restrict__ frags = M.wfrag;
+  const uint4* __restrict__ frags = Lw.wfrag;
   const uint32_t stride = G.act_stride;
   half_t* cur = Lw.X;
   half_t* nxt = Lw.Y;

@@ -254,6 +254,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.gen.dir = reinterpret_cast<half_t*>(dir + wave * gen_dir_bytes(G));
     m.gen.X = reinterpret_cast<half_t*>(act + wave * gen_act_bytes(G));
     m.gen.Y = m.gen.X + GEN_SAMPLES * G.act_stride;
+    m.gen.wfrag = M.wfrag;
     m.tables = act + n_waves * gen_act_bytes(G);
   } else {
     constexpr int WF = NET == NET_WIDE ? LDS_WFRAG_WIDE_BYTES : LDS_WFRAG_BYTES;
@@ -261,6 +262,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.lvs = reinterpret_cast<LevelParams*>(smem + WF);
     m.W = reinterpret_cast<WaveLds*>(smem + WF + LDS_LEVEL_BYTES) + wave;
     m.gen.dens = m.gen.dir = m.gen.X = m.gen.Y = nullptr;
+    m.gen.wfrag = nullptr;
     unsigned char* after = smem + WF + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
     m.gen.rayd = NET == NET_WIDE ? reinterpret_cast<float*>(after + wave * LDS_RAYD_BYTES) : nullptr;
     m.tables = after + (NET == NET_WIDE ? n_waves * LDS_RAYD_BYTES : 0);
@@ -711,7 +713,8 @@ struct PersistArgs {
   ViewBatch VB;
 };
 
-template <int NET, int MARCH, int WAVES = persist_waves(NET)>
+// WLDS (generic instance): the layers' weight fragments are staged in LDS as well, instead of streamed from L2 per pass.
+template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
                                                                               float4* __restrict__ rgba0, float* __restrict__ depth0,
                                                                               unsigned long long* __restrict__ counters,
@@ -726,14 +729,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   const ViewBatch& VB = VB0;
   constexpr int PERSIST_WAVES = WAVES;
   constexpr bool GEN = NET == NET_GENERIC;
-  const LdsMap lm = lds_map<NET>(smem, M, wave, PERSIST_WAVES);
+  LdsMap lm = lds_map<NET>(smem, M, wave, PERSIST_WAVES);
   uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(lm.tables);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
   uint32_t* dil_lds = reinterpret_cast<uint32_t*>(ctab_lds + M.lds_ctab_floats);
   int* q_lds = reinterpret_cast<int*>(dil_lds + M.lds_dilated_words);
   unsigned* sched = reinterpret_cast<unsigned*>(q_lds + MAX_VIEWS + 1);
   // ---- staged once per workgroup (= once per CU and launch)
-  if constexpr (!GEN) stage_fragments<NET>(M, lm.wl);  // (the generic instance streams its weights from global memory)
+  if constexpr (!GEN) stage_fragments<NET>(M, lm.wl);
+  if constexpr (GEN && WLDS) {  // the generic instance's fragments, behind everything else (16-byte aligned)
+    uint4* w_lds = reinterpret_cast<uint4*>(smem + ((reinterpret_cast<unsigned char*>(sched + 1) - smem + 15) & ~(size_t)15));
+    for (uint32_t i = threadIdx.x; i < M.gen_frag_bytes / 16u; i += blockDim.x) w_lds[i] = M.wfrag[i];
+    lm.gen.wfrag = w_lds;
+  }
   for (uint32_t i = threadIdx.x; i < M.lds_coarse_words; i += blockDim.x) coarse_lds[i] = M.occ_coarse[i];
   for (uint32_t i = threadIdx.x; i < M.lds_ctab_floats; i += blockDim.x) ctab_lds[i] = M.cell_bound[i];
   for (uint32_t i = threadIdx.x; i < M.lds_dilated_words; i += blockDim.x) dil_lds[i] = M.occ_dilated[i];
@@ -1470,7 +1478,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int waves = (int)M.persist_waves;
     const int lds = render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) +
-                    4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words);
+                    4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) +
+                    (M.gen_weights_lds ? 16 + (int)M.gen_frag_bytes : 0);
     const long long tiles = (long long)P.n_local_tiles * VB.n_views;
     const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + waves - 1) / waves));
     unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
@@ -1481,17 +1490,19 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     int eb = 0;
     const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
     const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
-#define NRF_LAUNCH_PERSISTENT_W(G, U, WV)                                                                                 \
+#define NRF_LAUNCH_PERSISTENT_W(G, U, WV, WL)                                                                             \
   do {                                                                                                                   \
-    e = allow_lds(render_persistent_kernel<G, U, WV>, lds);                                                              \
+    e = allow_lds(render_persistent_kernel<G, U, WV, WL>, lds);                                                          \
     if (e != hipSuccess) return e;                                                                                       \
-    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,                \
+    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,            \
                        (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
   } while (0)
-#define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G))
+#define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G), false)
     if (M.generic) {  // (the generic instance has one march form)
-      if (waves == 12) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12);
-      else NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 8);
+      if (waves == 12 && M.gen_weights_lds) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12, true);
+      else if (waves == 12) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12, false);
+      else if (M.gen_weights_lds) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 8, true);
+      else NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 8, false);
     } else if (M.wide) {
       if (unit) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_UNIT);
       else if (pow2) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_POW2);
