@@ -1445,6 +1445,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
                          hipStream_t st, bool queues_are_zero) {
   ViewBatch VB = VBin;
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
+  if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return hipSuccess;  // a shard without a strip (tiny frames, many ranks)
+  if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
   if (M.persistent && lds_tab) {

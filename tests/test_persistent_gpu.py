@@ -198,3 +198,11 @@ def test_packed_8bit_output_equals_quantised_float_planes(model, env, shard):
     ctx.set_max_views(n)
     ctx.render_views(cams, np.stack(poses))
     ctx.close()
+
+
+@pytest.mark.parametrize("env", [STRIP, PERSISTENT], ids=["per-strip", "persistent"])
+def test_shard_without_a_strip_renders_nothing(model, env):
+    """11 x 42 pixels are 6 strips: rank 7 of 8 owns none of them -- the launch is a no-op, not an error."""
+    desc, _ = model
+    out = _render(desc, 11, 42, _poses("orbit", 2), env, shard=(7, 8))
+    assert out[2] == 0 and np.all(out[0] == 7.0)  # no sample, no pixel touched
