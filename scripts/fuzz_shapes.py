@@ -1,0 +1,70 @@
+"""Random network shapes of the reference's JSON vocabulary (grid: levels / features / interpolation / table size; direction
+encoding: SH degree, Frequency, Identity; MLPs: width, depths, activations) against the oracle: hash-grid encoding bit-exact,
+SH / Identity direction encoding bit-exact, a 96x64 frame within the path's tolerance (max |d| <= 2/255, PSNR >= 45 dB), in
+both schedulings of the render kernel.  usage: scripts/fuzz_shapes.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "nerf-cuda_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import models, nerfhip as nh, oracle_py as op, synthetic as syn
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+W, H = 96, 64
+bad = 0
+for case in range(n_cases):
+    kw = dict(n_levels=int(rng.integers(1, 17)), n_features_per_level=int(rng.choice([1, 2, 2, 4, 8])),
+              interpolation=str(rng.choice(["Linear", "Linear", "Nearest", "Smoothstep"])),
+              n_neurons=int(rng.choice([16, 32, 64, 64, 128])), density_hidden_layers=int(rng.integers(1, 4)),
+              rgb_hidden_layers=int(rng.integers(1, 5)))
+    enc = rng.choice(["sh", "sh", "freq", "identity"])
+    if enc == "sh":
+        kw["sh_degree"] = int(rng.integers(1, 9))
+    elif enc == "freq":
+        kw.update(dir_otype="Frequency", n_frequencies=int(rng.integers(1, 13)))
+    else:
+        kw["dir_otype"] = "Identity"
+    if kw["n_levels"] * kw["n_features_per_level"] > 128:  # keep the feature row within what the generic instance's rows hold
+        kw["n_features_per_level"] = 2
+    if rng.random() < 0.3:
+        kw["rgb_output_activation"] = "Sigmoid"
+    geo = dict(H=int(rng.choice([16, 32, 33, 64])), log2_hashmap_size=int(rng.integers(8, 15)))
+    if rng.random() < 0.4:
+        geo.update(cascade=int(rng.integers(2, 5)), bound=float(rng.choice([2.0, 4.0, 3.0])))
+    try:
+        desc, keep, cfg = models.build_model(**geo, **kw)
+        o = op.Oracle(desc)
+        cam, pose = syn.default_camera(W, H), syn.orbit_pose(float(rng.uniform(0, 360)), float(rng.uniform(-30, 60)),
+                                                              radius=float(rng.choice([4.0311, 1.5 / 0.33, 2.5])))
+        want, wdepth, wst = o.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
+        p01 = rng.random((513, 3), dtype=np.float32)
+        feat = o.encode_grid(p01)
+        res = []
+        for persistent in ("1", "0"):
+            os.environ["NRF_PERSISTENT"] = persistent
+            c = nh.NerfHip(0); c.load_model(desc); c.set_resolution(W, H)
+            c.render(cam, pose)
+            got, gdepth = c.read_f32()
+            out = torch.empty((513, o.feat_width), dtype=torch.int16, device="cuda")
+            pd = torch.from_numpy(p01).cuda(); torch.cuda.synchronize()
+            c.encode_grid(pd.data_ptr(), 513, out.data_ptr())
+            enc_ok = np.array_equal(out.cpu().numpy().view(np.uint16), feat)
+            err = float(np.abs(got - want).max())
+            derr = float(np.abs(gdepth - wdepth).max())
+            ps = models.psnr(got, want)
+            res.append((got, gdepth))
+            ok = enc_ok and err <= 2.0 / 255.0 and derr <= 2.0 / 255.0 and ps >= 45.0 and c.stats().n_samples >= wst.n_samples
+            if not ok:
+                bad += 1
+                print("FAIL", "persistent" if persistent == "1" else "per-strip", geo, kw, f"encode bit-exact {enc_ok}, max|d| {err:.2e}, depth {derr:.2e}, psnr {ps:.1f}, "
+                      f"samples {c.stats().n_samples} (oracle {wst.n_samples})", flush=True)
+            c.close()
+        if not (np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32)) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))):
+            bad += 1
+            print("SCHEDULINGS DIFFER", geo, kw, flush=True)
+    except nh.NerfHipError as e:
+        print("refused", geo, kw, str(e)[:160], flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR", geo, kw, repr(e)[:300], flush=True)
+print(f"{n_cases} random shapes, {bad} failures", flush=True)
