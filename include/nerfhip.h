@@ -224,9 +224,12 @@ int nrf_set_options(nrf_context* ctx, const nrf_options* o);
 int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
                void* stream, nrf_frame* out);
 /* Batched multi-view render: n_views cameras (cams [n][4], poses [n][16], same
- * model / resolution / shard) in ONE launch per NRF_MAX_VIEWS views, view-major,
- * so the workgroups of view v+1 fill the wave slots the tail of view v leaves
- * idle.  This is the path for a render_server with many concurrent camera
+ * model / resolution / shard) in ONE launch per NRF_MAX_VIEWS views: the tiles
+ * of view v+1 take the wave slots the few long tiles at the end of view v leave
+ * idle (the kernel is persistent -- one workgroup per compute unit pulls tile
+ * strips of all views from work queues -- so every launch ends with the same
+ * short tail whatever its size, and nothing else runs on the device while it
+ * is resident: see INTEGRATION.md).  This is the path for a render_server with many concurrent camera
  * requests (the reference serves them one render_frame at a time,
  * render_server.cu:86-101) and for multi-GPU shards, which are too small to
  * fill a GPU alone.  Every view is bit-identical to an nrf_render of that
