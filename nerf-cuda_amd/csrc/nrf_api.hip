@@ -178,6 +178,7 @@ struct nrf_context {
   bool grid_missing = false;     // loaded without a density grid and none generated yet
   bool allow_persistent = true;  // NRF_PERSISTENT=0 keeps the one-workgroup-per-strip render_kernel (A/B runs)
   bool centre_out = true;        // NRF_CENTRE_OUT=0: the persistent kernel's queue in row order
+  bool allow_gen_wlds = true;    // NRF_GEN_WLDS=0: the generic instance's weight fragments are never staged in LDS
   int queue_classes = 0;         // NRF_QUEUE_CLASSES=1..8: work queues of the persistent kernel (default: one per XCD)
   int n_cus = 256;
   nrf_options opt{};
@@ -508,8 +509,8 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   if (c->allow_persistent && M.lds_coarse_words > 0) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
     // generic instance: 12 waves with the weight fragments in LDS, 12 waves without, 8 with, 8 without -- the first that fits
-    // (NRF_GEN_WLDS=0: never stage the fragments)
-    const bool allow_wlds = !(std::getenv("NRF_GEN_WLDS") && std::atoi(std::getenv("NRF_GEN_WLDS")) == 0);
+    // (NRF_GEN_WLDS=0 at nrf_create: never stage the fragments)
+    const bool allow_wlds = c->allow_gen_wlds;
     M.gen_weights_lds = 0;
     for (int waves : {render_persistent_waves(M.generic, M.wide), 8}) {
       if (waves == 8 && !M.generic) break;  // (only the generic instance has a second workgroup size)
@@ -604,6 +605,7 @@ int nrf_create(int device, nrf_context** out) {
   }
   if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_GEN_WLDS")) c->allow_gen_wlds = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_QUEUE_CLASSES")) c->queue_classes = std::atoi(e);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipSetDevice(device));

@@ -16,6 +16,8 @@
 // The stage kernels below it expose the same device functions one stage at a
 // time for the parity tests (include/nerfhip.h "stage entry points").
 
+#include <cstddef>
+
 #include "nrf_device.h"
 #include "nrf_generic.h"
 #include "nrf_launch.h"
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   // measured 2-10 % slower: the views then compete for L1/L2 with disjoint table regions.)
   const int view = (int)blockIdx.x / VB.blocks_per_view;  // wave-uniform (SALU)
   const ViewParams& V = VB.v[view];
-  rgba += (size_t)view * VB.view_stride_px;
+  if (rgba) rgba += (size_t)view * VB.view_stride_px;  // (NULL: packed 8-bit output, store_pixel)
   depth += (size_t)view * VB.view_stride_px;
   const int swz = (int)blockIdx.x - view * VB.blocks_per_view;
   const int strips_x = (P.tiles_x + 3) >> 2;
@@ -712,6 +714,10 @@ struct PersistArgs {
   FrameParams P;
   ViewBatch VB;
 };
+// (kernel arguments are placed like the members of a struct: each at the next multiple of its alignment)
+static_assert(offsetof(PersistArgs, P) == (sizeof(DevModel) + alignof(FrameParams) - 1) / alignof(FrameParams) * alignof(FrameParams) &&
+                  offsetof(PersistArgs, VB) % alignof(ViewBatch) == 0,
+              "PersistArgs mirrors the kernarg segment of render_persistent_kernel");
 
 // WLDS (generic instance): the layers' weight fragments are staged in LDS as well, instead of streamed from L2 per pass.
 template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false>
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     if (ls * N + P.shard_index >= s_row + sxn) continue;            // this row holds fewer of the rank's strips
     const int k_local = ls * 4 + (int)bt;
     if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last strip
-    float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
+    float4* rgba = rgba0 ? rgba0 + (size_t)view * VB.view_stride_px : nullptr;  // (NULL: packed 8-bit output, store_pixel)
     float* depth = depth0 + (size_t)view * VB.view_stride_px;
     const int strips_x = (P.tiles_x + 3) >> 2;
     const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     const int strips_x = (P.tiles_x + 3) >> 2;
     for (int view = 0; view < VB.n_views; ++view) {
       const ViewParams& V = VB.v[view];
-      float4* rgba = rgba0 + (size_t)view * VB.view_stride_px;
+      float4* rgba = rgba0 ? rgba0 + (size_t)view * VB.view_stride_px : nullptr;
       float* depth = depth0 + (size_t)view * VB.view_stride_px;
       const int outside = P.n_local_tiles - (min(V.k_hi, P.n_local_tiles) - V.k_lo);  // tiles before k_lo and from k_hi on
       for (int i = (int)blockIdx.x * PERSIST_WAVES + wave; i < outside; i += n_waves) {
