@@ -705,15 +705,20 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     Lv.size = lv.offset[l + 1] - lv.offset[l];
     Lv.hashed = d->grid_type == NRF_GRID_HASH;
     // replay grid_index's stride loop (grid.h:106-114) in uint32 to classify the level
-    uint32_t stride = 1;
+    uint32_t stride = 1, mult[3] = {0, 0, 0};  // mult: what grid_index multiplies x, y, z with (0: the term is skipped)
     int dims = 0;
-    for (; dims < 3 && stride <= Lv.size; ++dims) stride *= Lv.res;
+    for (; dims < 3 && stride <= Lv.size; ++dims) {
+      mult[dims] = stride;
+      stride *= Lv.res;  // uint32, as in the reference: wraps for res^3 >= 2^32
+    }
     const bool uses_hash = Lv.hashed && Lv.size < stride;
-    if (uses_hash && (Lv.size & (Lv.size - 1)) == 0) Lv.mode = LV_HASH_POW2;
+    const bool pow2_size = Lv.size >= 2 && (Lv.size & (Lv.size - 1)) == 0;
+    if (uses_hash && pow2_size) Lv.mode = LV_HASH_POW2;
     else if (!uses_hash && dims == 3 && Lv.res >= 2 && (uint64_t)Lv.res * Lv.res * Lv.res <= Lv.size) Lv.mode = LV_DENSE;
-    else if (!uses_hash && Lv.res == 65536u && (Lv.size & (Lv.size - 1)) == 0 && Lv.size >= 65536u)
-      Lv.mode = LV_XY_POW2;  // the uint32 stride wrapped to 0 after the y term: (x + y * 65536) & (size - 1), see nrf_device.h
+    else if (!uses_hash && pow2_size && dims >= 1) Lv.mode = LV_ADD_POW2;  // (x + y * mult[1] + z * mult[2]) & (size - 1), see nrf_device.h
     else Lv.mode = LV_GENERIC;
+    Lv.my_b = mult[1] << 2;  // (the hashed levels' constants replace these below)
+    Lv.mz_b = mult[2] << 2;
     generic_grid = generic_grid || Lv.mode == LV_GENERIC;
   }
   // The register-resident instance is the shape of the reference's base.json; everything else is the generic one.
@@ -759,7 +764,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   grid16.reserve(n_grid + (size_t)F * (16 * 4096 + ((size_t)1 << d->log2_hashmap_size)));
   for (uint32_t l = 0; l < L; ++l) {
     LevelParams& Lv = lp[l];
-    if (Lv.mode == LV_HASH_POW2 || Lv.mode == LV_XY_POW2)  // aligned to its own (power-of-two) size: `index & mask | offset` (level_gather)
+    if (Lv.mode == LV_HASH_POW2 || Lv.mode == LV_ADD_POW2)  // aligned to its own (power-of-two) size: `index & mask | offset` (level_gather)
       while ((grid16.size() / F) % Lv.size != 0) grid16.push_back((_Float16)0.0f);
     Lv.offset = (uint32_t)(grid16.size() / F);
     const float* src = gp + (size_t)lv.offset[l] * F;
@@ -782,9 +787,11 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   for (LevelParams& L : lp) {  // byte-offset constants of level_gather
     const bool hashed_pow2 = L.mode == LV_HASH_POW2;
     L.off_b = L.offset << 2;
-    L.my_b = hashed_pow2 ? (2654435761u << 2) : (L.res << 2);
-    L.mz_b = hashed_pow2 ? (805459861u << 2) : ((L.res * L.res) << 2);  // LV_XY_POW2: res * res == 0 in uint32, as in grid_index
-    L.mask_b = (hashed_pow2 || L.mode == LV_XY_POW2) ? ((L.size - 1) << 2) : 0xffffffffu;
+    if (hashed_pow2) {
+      L.my_b = 2654435761u << 2;
+      L.mz_b = 805459861u << 2;
+    }  // else: the additive multipliers of the stride loop above (dense: res, res^2; LV_ADD_POW2: possibly wrapped / 0)
+    L.mask_b = (hashed_pow2 || L.mode == LV_ADD_POW2) ? ((L.size - 1) << 2) : 0xffffffffu;
   }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
@@ -1019,6 +1026,13 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
     for (int sl = 0; sl < COUNTER_SLOTS; ++sl) out[i] = i == 14 ? std::max(out[i], raw[sl * 16 + i]) : out[i] + raw[sl * 16 + i];  // 14: a maximum
   }
   return NRF_OK;
+}
+
+// Diagnostic (not part of include/nerfhip.h): which kernel instance renders the loaded model -- 0 register-resident,
+// 1 generic, 2 wide; + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
+extern "C" int nrf_debug_instance(nrf_context* c) {
+  if (!c || !c->model_loaded) return -1;
+  return (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0)) + (c->dm.persistent ? 16 : 0);
 }
 
 // Diagnostic build: entry / exit stamps (s_memtime) of the persistent kernel's waves, 2 x n values.

@@ -35,9 +35,13 @@ enum : uint32_t {
   LV_DENSE = 0,    // x + y*res + z*res^2, then one conditional subtract (index < 2*size always)
   LV_HASH_POW2 = 1,  // fast_hash & (size-1)
   LV_GENERIC = 2,  // literal restatement with integer modulo (tiled grids, non-pow2 hash sizes)
-  LV_XY_POW2 = 3   // res == 2^16 on a power-of-two table: grid_index's uint32 stride (grid.h:106-109) wraps to 0 after
-                   // the y term, so `hashmap_size < stride` is false and the level is (x + y * res) & (size - 1), no hash,
-                   // no z.  instant-ngp's geometry reaches it: 2048 * aabb_scale = 65536 at aabb_scale 32.
+  LV_ADD_POW2 = 3  // additive index on a power-of-two table: (x + y * m1 + z * m2) & (size - 1) with the multipliers grid_index
+                   // ends up with in uint32 (grid.h:106-114) -- m1 = res, m2 = res * res mod 2^32, or 0 for a term the stride
+                   // loop skips.  Tiled grids, and what becomes of a HASH level whose stride overflows: res^3 >= 2^32
+                   // wraps `stride` below the table size, `hashmap_size < stride` is false, and the level is indexed
+                   // additively, no hash -- res 65536 (instant-ngp at aabb_scale 32: m2 = 0, a 2-D level), and the finest
+                   // levels (res 1626 ... 2048) of every table of 2^22 entries or more (m2 = res^2 is a multiple of... or
+                   // collides with ... the table size: for res 2048 on 2^22 entries the z term vanishes as well).
 };
 
 struct LevelParams {
@@ -103,7 +107,7 @@ struct DevModel {
   uint32_t generic;      // 0: the shape of the reference's base.json (L = 16, F = 2, 64 neurons, 1 + 2 hidden layers, a
                          // 16-wide direction encoding -- or a Frequency encoding of up to 80 values: `wide` --, hidden
                          // ReLU / density output None / sigma Exponential / rgb output None or Sigmoid, linear
-                         // interpolation, every level dense, power-of-two hashed or LV_XY_POW2): the register-resident
+                         // interpolation, every level dense, power-of-two hashed or LV_ADD_POW2): the register-resident
                          // instance (this file);
                          // 1: everything else: the generic instance (nrf_generic.h), described by `gen`
   const struct GenModel* gen;  // device memory; nullptr unless generic
@@ -524,7 +528,7 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
       for (int c = 0; c < 8; ++c) off[c] = ax[c & 1] + ay[(c >> 1) & 1] + az[(c >> 2) & 1];
     } else {
       // lanes of one instruction mix dense and hashed levels: both 2-term forms, one v_cndmask per corner.
-      // The additive form is masked as well: dense levels carry mask = ~0, an LV_XY_POW2 level its (size - 1) << 2
+      // The additive form is masked as well: dense levels carry mask = ~0, an LV_ADD_POW2 level its (size - 1) << 2
       // with mz_b = 0 (nrf_load_model); the level offset is added last (hashed / XY levels are aligned, see above)
       const uint32_t axr[2] = {gx << 2, (gx << 2) + 4u};
       const uint32_t am[2] = {(axr[0] & mask) | level_off, (axr[1] & mask) | level_off};

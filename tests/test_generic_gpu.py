@@ -6,6 +6,8 @@ hidden-layer counts, n_features_per_level 1/4/8, fewer levels, Nearest / Smooths
 Tolerances as in test_parity_gpu.py: hash-grid and SH encodings BIT-EXACT, Frequency 4e-3 (v_sin_f32 on
 arguments up to 2^11 pi against libm's sinf; the reference itself uses __sinf), MLP outputs a few fp16 ulps
 (fp32 summation order), frames max |d| <= 2/255 and PSNR >= 45 dB."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -235,7 +237,7 @@ def test_instant_ngp_geometry_runs_in_the_register_resident_instance(ctx):
     """instant-ngp's level geometry at aabb_scale 32 (per_level_scale from 2048 * 32 / 16: the finest level has
     res = 65536) meets grid_index's uint32 stride overflow (grid.h:106-109): stride wraps to 0 after the y term, the
     level is (x + y * res) & (size - 1) without hash and without z.  Oracle and kernel follow the uint32 arithmetic
-    literally; the hot instance covers the level (LV_XY_POW2) and instant-ngp's logistic colours (rgb output Sigmoid),
+    literally; the hot instance covers the level (LV_ADD_POW2) and instant-ngp's logistic colours (rgb output Sigmoid),
     so such a model renders at the base shape's speed.  Encoding bit-exact, frames at the usual tolerance."""
     pls = nh.default_per_level_scale(32.0, 16, 16)
     for log2T, H in ((12, 32), (19, 32)):
@@ -263,6 +265,60 @@ def test_instant_ngp_geometry_runs_in_the_register_resident_instance(ctx):
         assert ctx.stats().n_samples > 0
         assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0
         assert rgba[..., :3].max() <= 1.0 + 1e-3  # logistic colours + white background stay in range
+
+
+def _instance(ctx):
+    ctx.lib.nrf_debug_instance.argtypes = [C.c_void_p]
+    return ctx.lib.nrf_debug_instance(ctx.h) & 15  # 0 register-resident, 1 generic, 2 wide
+
+
+def test_large_tables_keep_the_register_resident_instance(ctx):
+    """A hash table of 2^22 entries or more meets grid_index's uint32 stride overflow at its finest levels (grid.h:106-114):
+    for res in 1626 .. sqrt(T) the stride res^3 wraps below the table size, `hashmap_size < stride` is false and the level
+    is indexed ADDITIVELY, (x + y res + z res^2 mod 2^32) & (T - 1), not hashed -- at res 2048 on 2^22 entries the z term
+    vanishes as well.  Such levels used to send the whole model to the generic instance (2.2 instead of 11 Gsamples/s at
+    1080p); they are LV_ADD_POW2 levels of the register-resident one.  Encoding bit-exact against the oracle (which
+    restates the uint32 loop literally), a frame at the usual tolerance."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=22, H=32)
+    lt = nh.level_table(desc)
+    assert lt.resolution[15] == 2048 and lt.offset[16] - lt.offset[15] == 1 << 22
+    ctx.load_model(desc)
+    assert _instance(ctx) == 0
+    o = op.Oracle(desc)
+    rng = np.random.default_rng(9)
+    pos = np.concatenate([rng.random((4000, 3), dtype=np.float32),
+                          np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.999999, 1e-7, 0.5], [0.25, 1, 1]], np.float32)])
+    want = o.encode_grid(pos)
+    out = torch.empty((len(pos), 32), dtype=torch.int16, device="cuda")
+    p_d = dev(pos)
+    sync()
+    ctx.encode_grid(p_d.data_ptr(), len(pos), out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), want)
+    # the finest level really is additive there: two positions that differ in z only (same x, y cell) read the same entries
+    assert o.grid_index(15, 100, 200, 5) == o.grid_index(15, 100, 200, 1900) == (100 + 200 * 2048) % (1 << 22)
+    W, Hh = 96, 64
+    cam, pose = syn.default_camera(W, Hh), syn.orbit_pose(200, 35)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, Hh)
+    ctx.render(cam, pose)
+    rgba, depth = ctx.read_f32()
+    wantf, wdepth, wst = o.render(cam, pose, W, Hh, schedule=op.SCHED_PER_RAY)
+    assert ctx.stats().n_samples > 0
+    assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0
+
+
+def test_tiled_grid_with_power_of_two_table_runs_register_resident(ctx):
+    """A Tiled grid never hashes: its levels beyond the dense ones are (x + y res + z res^2) % T -- LV_ADD_POW2 as well."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, grid_type="Tiled")
+    ctx.load_model(desc)
+    assert _instance(ctx) == 0
+    o = op.Oracle(desc)
+    pos = np.random.default_rng(3).random((3000, 3), dtype=np.float32)
+    out = torch.empty((len(pos), 32), dtype=torch.int16, device="cuda")
+    p_d = dev(pos)
+    sync()
+    ctx.encode_grid(p_d.data_ptr(), len(pos), out.data_ptr())
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), o.encode_grid(pos))
 
 
 @pytest.mark.parametrize("kw", [dict(dir_otype="Frequency", n_frequencies=12), dict(n_neurons=32, n_features_per_level=4, n_levels=8)])
