@@ -18,10 +18,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 enum { OP_FMA = 0, OP_CVT_PK, OP_PK_ADD_F16, OP_PK_MAX_F16, OP_MUL_LO_U32, OP_EXP, OP_PK_MUL_F32, OP_MFMA16, OP_MFMA16_PLUS_VALU, OP_LDS_READ_B128,
-       OP_FMA_MIX, OP_XOR, N_OPS };
+       OP_FMA_MIX, OP_XOR, OP_PK_MAX_I16, OP_MAX_I32, OP_CVT_F16, OP_CVT_PKRTZ, OP_PERM, OP_MED3, OP_MAX_F32, OP_BITOP3, OP_ADD_U32, OP_AND, OP_CNDMASK, OP_LSHL, OP_CVT_I32, OP_FRACT, OP_LSHL_ADD, OP_ADD3, OP_MUL_F32, OP_SUB_F32, OP_MOV, OP_CVT_F32_F16, N_OPS };
 static const char* kNames[N_OPS] = {"v_fma_f32", "v_cvt_pk_f16_f32", "v_pk_add_f16", "v_pk_max_f16", "v_mul_lo_u32", "v_exp_f32",
                                     "v_pk_mul_f32", "v_mfma_f32_16x16x32_f16", "mfma + 4 v_cvt_pk_f16_f32 (per 5 instr)", "ds_read_b128",
-                                    "v_fma_mix_f32", "v_xor_b32"};
+                                    "v_fma_mix_f32", "v_xor_b32", "v_pk_max_i16", "v_max_i32", "v_cvt_f16_f32", "v_cvt_pkrtz_f16_f32", "v_perm_b32",
+                                    "v_med3_f32", "v_max_f32", "v_bitop3_b32", "v_add_u32", "v_and_b32", "v_cndmask_b32", "v_lshlrev_b32", "v_cvt_i32_f32", "v_fract_f32", "v_lshl_add_u32", "v_add3_u32", "v_mul_f32", "v_sub_f32", "v_mov_b32", "v_cvt_f32_f16"};
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -57,6 +58,86 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters)
       asm volatile(R8("v_pk_max_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n"
                       "v_pk_max_f16 %4, %4, %8\n v_pk_max_f16 %5, %5, %8\n v_pk_max_f16 %6, %6, %8\n v_pk_max_f16 %7, %7, %8\n")
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_PK_MAX_I16) {
+      asm volatile(R8("v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n"
+                      "v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_MAX_I32) {
+      asm volatile(R8("v_max_i32 %0, %0, %8\n v_max_i32 %1, %1, %8\n v_max_i32 %2, %2, %8\n v_max_i32 %3, %3, %8\n"
+                      "v_max_i32 %4, %4, %8\n v_max_i32 %5, %5, %8\n v_max_i32 %6, %6, %8\n v_max_i32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_CVT_F16) {
+      asm volatile(R8("v_cvt_f16_f32 %0, %0\n v_cvt_f16_f32 %1, %1\n v_cvt_f16_f32 %2, %2\n v_cvt_f16_f32 %3, %3\n"
+                      "v_cvt_f16_f32 %4, %4\n v_cvt_f16_f32 %5, %5\n v_cvt_f16_f32 %6, %6\n v_cvt_f16_f32 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_CVT_PKRTZ) {
+      asm volatile(R8("v_cvt_pkrtz_f16_f32 %0, %0, %8\n v_cvt_pkrtz_f16_f32 %1, %1, %8\n v_cvt_pkrtz_f16_f32 %2, %2, %8\n v_cvt_pkrtz_f16_f32 %3, %3, %8\n"
+                      "v_cvt_pkrtz_f16_f32 %4, %4, %8\n v_cvt_pkrtz_f16_f32 %5, %5, %8\n v_cvt_pkrtz_f16_f32 %6, %6, %8\n v_cvt_pkrtz_f16_f32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_PERM) {
+      asm volatile(R8("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
+                      "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_MED3) {
+      asm volatile(R8("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+                      "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    } else if (OP == OP_MAX_F32) {
+      asm volatile(R8("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                      "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_BITOP3) {
+      asm volatile(R8("v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\n v_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\n v_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\n v_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\n"
+                      "v_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\n v_bitop3_b32 %5, %5, %8, %9 bitop3:0x96\n v_bitop3_b32 %6, %6, %8, %9 bitop3:0x96\n v_bitop3_b32 %7, %7, %8, %9 bitop3:0x96\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_ADD_U32) {
+      asm volatile(R8("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                      "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_AND) {
+      asm volatile(R8("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                      "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_CNDMASK) {
+      asm volatile(R8("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                      "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_LSHL) {
+      asm volatile(R8("v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 3, %3\n"
+                      "v_lshlrev_b32 %4, 3, %4\n v_lshlrev_b32 %5, 3, %5\n v_lshlrev_b32 %6, 3, %6\n v_lshlrev_b32 %7, 3, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_CVT_I32) {
+      asm volatile(R8("v_cvt_i32_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n"
+                      "v_cvt_i32_f32 %4, %4\n v_cvt_i32_f32 %5, %5\n v_cvt_i32_f32 %6, %6\n v_cvt_i32_f32 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_FRACT) {
+      asm volatile(R8("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3\n"
+                      "v_fract_f32 %4, %4\n v_fract_f32 %5, %5\n v_fract_f32 %6, %6\n v_fract_f32 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_LSHL_ADD) {
+      asm volatile(R8("v_lshl_add_u32 %0, %0, 2, %8\n v_lshl_add_u32 %1, %1, 2, %8\n v_lshl_add_u32 %2, %2, 2, %8\n v_lshl_add_u32 %3, %3, 2, %8\n"
+                      "v_lshl_add_u32 %4, %4, 2, %8\n v_lshl_add_u32 %5, %5, 2, %8\n v_lshl_add_u32 %6, %6, 2, %8\n v_lshl_add_u32 %7, %7, 2, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_ADD3) {
+      asm volatile(R8("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n"
+                      "v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_MUL_F32) {
+      asm volatile(R8("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                      "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_SUB_F32) {
+      asm volatile(R8("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                      "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_MOV) {
+      asm volatile(R8("v_mov_b32 %0, %0\n v_mov_b32 %1, %1\n v_mov_b32 %2, %2\n v_mov_b32 %3, %3\n"
+                      "v_mov_b32 %4, %4\n v_mov_b32 %5, %5\n v_mov_b32 %6, %6\n v_mov_b32 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    } else if (OP == OP_CVT_F32_F16) {
+      asm volatile(R8("v_cvt_f32_f16 %0, %0\n v_cvt_f32_f16 %1, %1\n v_cvt_f32_f16 %2, %2\n v_cvt_f32_f16 %3, %3\n"
+                      "v_cvt_f32_f16 %4, %4\n v_cvt_f32_f16 %5, %5\n v_cvt_f32_f16 %6, %6\n v_cvt_f32_f16 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
     } else if (OP == OP_MUL_LO_U32) {
       asm volatile(R8("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
                       "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n")
@@ -167,6 +248,26 @@ int main() {
     run<OP_CVT_PK>(w, iters, d_out, h);
     run<OP_PK_ADD_F16>(w, iters, d_out, h);
     run<OP_PK_MAX_F16>(w, iters, d_out, h);
+    run<OP_PK_MAX_I16>(w, iters, d_out, h);
+    run<OP_MAX_I32>(w, iters, d_out, h);
+    run<OP_MED3>(w, iters, d_out, h);
+    run<OP_CVT_F16>(w, iters, d_out, h);
+    run<OP_CVT_PKRTZ>(w, iters, d_out, h);
+    run<OP_PERM>(w, iters, d_out, h);
+    run<OP_MAX_F32>(w, iters, d_out, h);
+    run<OP_BITOP3>(w, iters, d_out, h);
+    run<OP_ADD_U32>(w, iters, d_out, h);
+    run<OP_AND>(w, iters, d_out, h);
+    run<OP_CNDMASK>(w, iters, d_out, h);
+    run<OP_LSHL>(w, iters, d_out, h);
+    run<OP_CVT_I32>(w, iters, d_out, h);
+    run<OP_FRACT>(w, iters, d_out, h);
+    run<OP_LSHL_ADD>(w, iters, d_out, h);
+    run<OP_ADD3>(w, iters, d_out, h);
+    run<OP_MUL_F32>(w, iters, d_out, h);
+    run<OP_SUB_F32>(w, iters, d_out, h);
+    run<OP_MOV>(w, iters, d_out, h);
+    run<OP_CVT_F32_F16>(w, iters, d_out, h);
     run<OP_MUL_LO_U32>(w, iters, d_out, h);
     run<OP_EXP>(w, iters, d_out, h);
     run<OP_PK_MUL_F32>(w, iters, d_out, h);
