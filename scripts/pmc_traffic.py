@@ -43,12 +43,16 @@ f16 = g("SQ_INSTS_VALU_ADD_F16") + g("SQ_INSTS_VALU_MUL_F16") + g("SQ_INSTS_VALU
 trans = g("SQ_INSTS_VALU_TRANS_F32") + g("SQ_INSTS_VALU_TRANS_F16")
 cvt, int32, mfma = g("SQ_INSTS_VALU_CVT"), g("SQ_INSTS_VALU_INT32"), g("SQ_INSTS_MFMA")
 other = max(valu - f32 - f16 - trans - cvt - int32 - mfma, 0.0)
-# issue cost in SIMD-cycles per wave64 instruction (scripts/issue_rate, profiles/r02/issue_rate.txt): fp32 add/mul/fma 2;
-# int32 2..4 (v_mul_lo_u32 is 4: priced 2.5 on this mix); cvt and packed fp16 4; v_fma_mix_f32 4 -- it is counted as
-# FMA_F32, and the interpolation issues exactly two of them per v_pk_add_f16 (the only fp16 add of the kernel);
-# transcendental 8; the remainder (moves, compares, med3, selects, bit operations) 2; an MFMA holds the SIMD's vector issue for 8
+# issue cost in SIMD-cycles per wave64 instruction (scripts/issue_rate, profiles/r02/issue_rate.txt; 34 opcodes measured):
+# the VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max /
+# med3, every conversion, shifts, v_add3, v_perm, v_mul_lo_u32, packed 16-bit, v_fma_mix_f32); transcendentals 8; an MFMA
+# holds the SIMD's vector issue port for 8.  Per counter class: fp32 add/mul/fma 2.25, except v_fma_mix_f32 -- counted as
+# FMA_F32, the interpolation issues exactly two per v_pk_add_f16 (the only fp16 add of the kernel) -- 4.1; cvt and packed
+# fp16 4.1; int32 3.0 and the remainder 3.2: the averages of those two classes' opcodes in the kernel's listing (int32:
+# v_add_u32 / and / xor against shifts and v_mul_lo_u32; remainder: v_mov / v_bitop3 against v_cndmask, compares, v_fract,
+# v_med3, the division sequences)
 mix = min(2 * g("SQ_INSTS_VALU_ADD_F16"), g("SQ_INSTS_VALU_FMA_F32"))
-cycles = 2 * (f32 - mix) + 4 * mix + 2.5 * int32 + 4 * cvt + 4 * f16 + 8 * trans + 2 * other + 8 * mfma
+cycles = 2.25 * (f32 - mix) + 4.1 * mix + 3.0 * int32 + 4.1 * cvt + 4.1 * f16 + 8 * trans + 3.2 * other + 8 * mfma
 simd_cycles = g("GRBM_GUI_ACTIVE") / 8 * 1024  # per-XCD active cycles x 1024 SIMDs
 ta_busy = g("TA_TA_BUSY_sum") / max(g("GRBM_GUI_ACTIVE") / 8 * 256, 1)  # 256 texture addressers (one per CU)
 wave_cycles = max(g("SQ_WAVE_CYCLES"), 1)
@@ -74,16 +78,20 @@ doc = {
                         "parked_on_waitcnt_or_barrier": round(g("SQ_WAIT_ANY") / wave_cycles, 3)},
     "l2_hit_rate": round(g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1), 4),
     "limiter": {
-        "resource": "texture-address (gather) path, with the VALU issue port close behind",
-        "frac": round(ta_busy, 4),
+        # two units are loaded about equally; `frac` is the busier one's figure, both are given
+        "resource": ("VALU issue port, with the texture-address (gather) path close behind" if cycles / max(simd_cycles, 1) > ta_busy
+                     else "texture-address (gather) path, with the VALU issue port close behind"),
+        "frac": round(max(ta_busy, cycles / max(simd_cycles, 1)), 4),
+        "ta_busy_frac": round(ta_busy, 4),
         "counter": "TA_TA_BUSY_sum / (GRBM_GUI_ACTIVE / 8 x 256 TAs)",
         "valu_issue_frac": round(cycles / max(simd_cycles, 1), 4),
         "valu_issue_counter": "SQ_INSTS_VALU_* classes x measured issue cost / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
         "valu_issue_cycles_per_launch": cycles,
         "simd_cycles_per_launch": simd_cycles,
-        "note": "fp32 add/mul/fma and plain int32 issue in 2 cycles per wave64 instruction, cvt / packed fp16 / v_fma_mix in 4, "
-                "transcendentals in 8, an MFMA holds the issue port for 8 (scripts/issue_rate/issue_rate.hip, "
-                "profiles/r02/issue_rate.txt).  The busiest unit is the texture addresser: every 64-lane gather of "
+        "note": "The VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max / "
+                "med3, conversions, shifts, v_mul_lo_u32, packed fp16, v_fma_mix); transcendentals 8; an MFMA holds the issue port for 8 "
+                "(scripts/issue_rate/issue_rate.hip, profiles/r02/issue_rate.txt: 34 opcodes; the int32 and remainder counter classes are "
+                "priced at the average of their opcodes in the kernel's listing, 3.0 and 3.2).  The texture addresser: every 64-lane gather of "
                 "4-byte table entries occupies it for ~17 cycles (4 addresses per clock), 128 such gathers per 16 samples.  "
                 f"HBM is not the limiter: hbm_bytes_per_launch / kernel time is {(g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / (statistics.mean(agg[grid]['_ms']) * 1e-3) / 1e12:.1f} TB/s "
                 "(the table lives in L2 / Infinity Cache).",
