@@ -76,15 +76,18 @@ CLOCK_HZ = 2.4e9                   # max engine clock (the chip holds ~2.2-2.3 G
 DEFAULT_VIEWS = 16                 # camera views per step (one launch)
 DEFAULT_DEPTH = 1                  # steps in flight at N = 1 (N > 1: 2, so that the gather of one step overlaps the next)
 CONFIG5_REQUESTS, CONFIG5_RES = 64, 800  # BASELINE.json configs[4]
-PMC_FILE = ROOT / "profiles" / "r02" / "pmc_traffic.json"
+PMC_FILE = ROOT / "profiles" / "r03" / "pmc_traffic.json"
 
 
 def kernel_source_sha16() -> str:
     """Fingerprint of the kernel sources the committed PMC summary was collected for (bench.py drops the
     PMC-derived fields when the sources have changed since)."""
     h = hashlib.sha256()
-    for f in ("nrf_device.h", "nrf_kernels.hip"):
-        h.update((ROOT / "nerf-cuda_amd" / "csrc" / f).read_bytes())
+    # every file under csrc/ feeds the render launch: device code, launch shapes (nrf_api.hip, nrf_launch.h), the generic instance
+    for f in sorted((ROOT / "nerf-cuda_amd" / "csrc").iterdir()):
+        if f.suffix in (".h", ".hip"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 
@@ -472,6 +475,7 @@ def main():
     if world == 1:
         out["config"]["samples_per_frame"] = int(mean_samples_launch / V)
         if not replica:
+            out["api"] = api_bench(nh, torch, dev, desc, cam, poses, W, H)
             with torch.cuda.stream(stream):
                 out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
             if not args.no_cpu_baseline:
@@ -479,6 +483,95 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def api_bench(nh, torch, dev, desc, cam, poses, W, H):
+    """The host end of the path: what a caller of the reference's API sees.  NerfRender::render_frame returns HOST memory
+    (8-bit rgb + depth, R/src/nerf_render.cu:345-359); its counterpart here is nrf_render_host_u8 (the kernel writes the
+    8-bit Image, the copy engine brings the rows of the region of interest into pinned host memory, the calling thread
+    fills the background rows meanwhile).  Wall-clock around the C-ABI call, through ctypes."""
+    import numpy as np
+
+    g = nh.NerfHip(dev.index)
+    g.load_model(desc)
+    g.set_resolution(W, H)
+    V = DEFAULT_VIEWS
+    g.set_max_views(V)
+    cam1 = np.ascontiguousarray(cam, np.float32).reshape(1, 4)
+    p1 = [np.ascontiguousarray(p, np.float32).reshape(1, 16) for p in poses]
+    camV = np.ascontiguousarray(np.stack([cam] * V), np.float32)
+    pV = [np.ascontiguousarray(np.stack([poses[(i * V + v) % len(poses)] for v in range(V)]), np.float32).reshape(V, 16)
+          for i in range(2)]
+    for i in range(6):
+        g.render_host_u8_raw(cam1, p1[i % len(p1)])
+    n1 = 48
+    wall, devms, copied = [], [], []
+    for i in range(n1):
+        t0 = time.perf_counter()
+        f = g.render_host_u8_raw(cam1, p1[i % len(p1)])
+        wall.append((time.perf_counter() - t0) * 1e3)
+        devms.append(float(f.render_ms))
+        copied.append(int(f.copied_bytes))
+    for i in range(2):
+        g.render_host_u8_raw(camV, pV[i % 2])
+    nb = 12
+    t0 = time.perf_counter()
+    bdev, bcopied = [], []
+    for i in range(nb):
+        f = g.render_host_u8_raw(camV, pV[i % 2])
+        bdev.append(float(f.render_ms))
+        bcopied.append(int(f.copied_bytes))
+    batch_ms = (time.perf_counter() - t0) * 1e3 / nb
+    # two batches in flight: the copy (and the caller) of batch k under the render of batch k + 1
+    tickets = [g.submit_host_u8(camV, pV[0])]
+    t0 = time.perf_counter()
+    for i in range(1, nb + 1):
+        tickets.append(g.submit_host_u8(camV, pV[i % 2]))
+        g.lib.nrf_wait_host_u8(g.h, tickets[i - 1], None)
+    pipe_ms = (time.perf_counter() - t0) * 1e3 / nb
+    g.lib.nrf_wait_host_u8(g.h, tickets[-1], None)
+    # the after-the-fact path of round 2 for comparison: float planes, then nrf_read_u8 (quantise launch + blocking copies)
+    old = []
+    for i in range(8):
+        t0 = time.perf_counter()
+        g.render(cam, poses[i % len(poses)])
+        g.read_u8()
+        old.append((time.perf_counter() - t0) * 1e3)
+    g.close()
+    # a plain pinned D2H copy of the same size as one frame's planes, for the link's rate
+    src = torch.empty((W * H * 4,), dtype=torch.uint8, device=dev)
+    dst = torch.empty((W * H * 4,), dtype=torch.uint8, pin_memory=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    link_gbs = 10 * W * H * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    w, d = float(np.mean(wall)), float(np.mean(devms))
+    bd = float(np.mean(bdev))
+    return {"what": "the reference's render_frame() ends in host memory (8-bit rgb + depth): nrf_render_host_u8, wall-clock per C-ABI call",
+            "render_frame_host_u8_ms": round(w, 4),
+            "render_frame_host_u8_ms_median": round(float(np.median(wall)), 4),
+            "render_frame_device_ms": round(d, 4),
+            "render_frame_host_tail_ms": round(w - d, 4),
+            "frames_per_s_render_frame": round(1e3 / w, 2),
+            "host_copy_bytes_per_frame": int(np.mean(copied)),
+            "frame_bytes": W * H * 4,
+            "render_frames_host_u8_ms_per_frame": round(batch_ms / V, 4),
+            "render_frames_device_ms_per_frame": round(bd / V, 4),
+            "render_frames_host_u8_pipelined_ms_per_frame": round(pipe_ms / V, 4),
+            "frames_per_s_host_u8_batched": round(V * 1e3 / batch_ms, 2),
+            "frames_per_s_host_u8_pipelined": round(V * 1e3 / pipe_ms, 2),
+            "views_per_batch": V,
+            # the link's rate (a plain pinned device-to-host copy of one frame's size); the path's own copies run beside the
+            # render (finished strip rows are copied while the rest renders), so what a batch still waits for is the tail:
+            "d2h_gbs": round(link_gbs, 2),
+            "host_tail_ms_per_batch": round(batch_ms - bd, 4),
+            "copy_ms_per_batch_at_link_rate": round(float(np.mean(bcopied)) / (link_gbs * 1e9) * 1e3, 4),
+            "render_plus_read_u8_ms": round(float(np.mean(old[2:])), 4)}
 
 
 def mlp_microbench(ctx, torch, dev):

@@ -15,7 +15,9 @@
  *   - every function returns an int status: 0 = NRF_OK, otherwise an
  *     NRF_E_* code; nrf_last_error() returns a thread-local message.
  *     No C++ exception crosses this boundary.
- *   - one context per device; a context is used by one thread at a time.
+ *   - one context per device; a context is used by one thread at a time.  Render calls of one context may overlap
+ *     on different streams: every call takes its own statistics counters and work queues from a ring of 16, so at
+ *     most 16 render calls of a context may be in flight; nrf_get_stats reports the last call.
  *   - there is NO CPU fallback: if the HIP runtime finds no gfx950 device,
  *     nrf_create fails with NRF_E_NODEVICE.
  */
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 3
+#define NRF_ABI_VERSION 4
 #define NRF_MAX_VIEWS 128 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -255,11 +257,40 @@ int nrf_bind_output(nrf_context* ctx, void* rgba, void* depth);
  * NRF_E_STATE, nrf_frame::rgba / depth are NULL); NULL returns to the float planes.  What a rank of a multi-GPU
  * step binds: its shard goes onto the wire as rendered.                                                    */
 int nrf_bind_output_rgbd8(nrf_context* ctx, void* rgbd8);
+/* Binds caller-owned device (or device-visible pinned host) buffers in the layout of the reference's host Image
+ * (common.h:75-89, filled by nerf_render.cu:352-359): rgb u8 [n_views * view_stride_px][3], depth u8
+ * [n_views * view_stride_px], row-major, single-shard frames only; both 4-byte aligned.  The kernel writes these
+ * 4 bytes per pixel itself -- bit-identical to nrf_read_u8 of the float planes -- as whole dwords assembled inside
+ * the tile's wavefront.  nrf_read_* return NRF_E_STATE; NULL, NULL returns to the float planes.               */
+int nrf_bind_output_u8(nrf_context* ctx, void* rgb8, void* depth8);
 /* nrf_render on the context's own stream WITHOUT waiting for it (the way the
  * reference overlaps its NGPU devices, nerf_render.cu:252-362); nrf_sync waits. */
 int nrf_render_async(nrf_context* ctx, const float cam[4], const float pose[16], nrf_frame* out);
 int nrf_sync(nrf_context* ctx);
-/* Host copy + quantisation, nerf_render.cu:345-359 (saturating, row-major). */
+/* ---- host frames: NerfRender::render_frame's result is HOST memory (nerf_render.cu:345-359: D2H of the float planes and
+ * a single-threaded quantise / de-interleave loop per GPU; Image, common.h:75-89).  nrf_submit_host_u8 renders n_views
+ * cameras into 8-bit planes (the kernel writes the Image's bytes itself), has the copy engine move the rows of every
+ * view's region of interest into pinned host memory owned by the context, and fills the remaining rows -- background by
+ * construction -- from the calling thread while the GPU renders.  It returns at once; nrf_wait_host_u8 blocks until the
+ * frames of that ticket are in host memory.  Two slots: the copy of one call overlaps the render of the next, and the
+ * pointers of a ticket stay valid until the SECOND next nrf_submit_host_u8 on the context (that call waits for the
+ * slot's copy, not for its reader).  NRF_HOST_RGB_ONLY: depth is not copied (nrf_host_frame::depth = NULL) -- what a
+ * render_server needs.  Bytes identical to nrf_render + nrf_read_u8.  Single-shard frames only.                      */
+enum { NRF_HOST_RGB_ONLY = 1 };
+typedef struct nrf_host_frame {
+  int32_t width, height, n_views;
+  const uint8_t* rgb;      /* pinned host: view v at rgb + v * view_stride_px * 3, [H][W][3] */
+  const uint8_t* depth;    /* pinned host: view v at depth + v * view_stride_px, [H][W]; NULL with NRF_HOST_RGB_ONLY */
+  int64_t view_stride_px;
+  float render_ms;         /* device time of this call's render launches (events on their stream) */
+  uint64_t copied_bytes;   /* what the copy engine moved for this call (the rows of the regions of interest) */
+} nrf_host_frame;
+int nrf_submit_host_u8(nrf_context* ctx, int n_views, const float* cams, const float* poses, int flags, int* ticket);
+int nrf_wait_host_u8(nrf_context* ctx, int ticket, nrf_host_frame* out);
+/* submit + wait: one NerfRender::render_frame(s) call of the reference                                               */
+int nrf_render_host_u8(nrf_context* ctx, int n_views, const float* cams, const float* poses, int flags, nrf_host_frame* out);
+/* Host copy + quantisation, nerf_render.cu:345-359 (saturating, row-major), of a frame rendered into float planes
+ * (a quantise launch + two blocking copies per view: the after-the-fact path; nrf_render_host_u8 is the fast one). */
 int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
 /* The same quantisation on the device for any float frame / shard / batch of
  * n_px pixels: out[i] = r | g << 8 | b << 16 | depth << 24.  Four bytes per
@@ -268,6 +299,9 @@ int nrf_read_u8(nrf_context* ctx, uint8_t* rgb, uint8_t* depth);
  * through nrf_untile(_views) with channels = 1.                               */
 int nrf_quantize_rgbd8(nrf_context* ctx, const void* rgba, const void* depth, uint64_t n_px,
                        void* out_u32, void* stream);
+/* The same quantisation into the planar layout of the reference's Image: rgb u8 [n_px][3], depth u8 [n_px] (device). */
+int nrf_quantize_u8(nrf_context* ctx, const void* rgba, const void* depth, uint64_t n_px, void* rgb8, void* depth8,
+                    void* stream);
 /* Host copy of the float buffers (row-major; single-shard frames only).      */
 int nrf_read_f32(nrf_context* ctx, float* rgba, float* depth);
 /* nrf_read_f32 / nrf_read_u8 for view `view` of the last nrf_render_views.    */
@@ -288,6 +322,12 @@ int nrf_untile(nrf_context* ctx, const void* gathered, int shard_count,
 int nrf_untile_views(nrf_context* ctx, const void* gathered, int shard_count,
                      int tiles_per_shard, int channels, int n_views,
                      void* out_rowmajor, void* stream);
+/* Gathered PACKED shards ([shard][view][n_tiles_max][64] uint32 r | g << 8 | b << 16 | depth << 24, as rendered with
+ * nrf_bind_output_rgbd8) -> the planar layout of the reference's Image: rgb u8 [view][H][W][3], depth u8 [view][H][W]
+ * (device or device-visible pinned host memory; the shards 16-byte aligned, the planes 4-byte aligned when the width is a multiple of 4).  The de-interleave + quantise loop of
+ * nerf_render.cu:352-359 for a device group, on the device.                                                    */
+int nrf_untile_views_u8(nrf_context* ctx, const void* gathered_rgbd8, int shard_count, int tiles_per_shard, int n_views,
+                        void* rgb8, void* depth8, void* stream);
 int nrf_tiles_per_shard(int width, int height, int shard_count, int* n);
 int nrf_get_stats(nrf_context* ctx, nrf_stats* s);
 
@@ -313,6 +353,11 @@ int nrf_group_render_views(nrf_group* grp, int n_views, const float* cams, const
                            nrf_frame* out);
 int nrf_group_read_view_f32(nrf_group* grp, int view, float* rgba, float* depth);
 int nrf_group_read_view_u8(nrf_group* grp, int view, uint8_t* rgb, uint8_t* depth);
+/* Host frames of a group (see nrf_submit_host_u8): the members render packed 8-bit shards, devices[0] untiles them
+ * into the Image layout and ONE copy per call brings all views to pinned host memory; same ticket rules.          */
+int nrf_group_submit_host_u8(nrf_group* grp, int n_views, const float* cams, const float* poses, int flags, int* ticket);
+int nrf_group_wait_host_u8(nrf_group* grp, int ticket, nrf_host_frame* out);
+int nrf_group_render_host_u8(nrf_group* grp, int n_views, const float* cams, const float* poses, int flags, nrf_host_frame* out);
 int nrf_group_get_stats(nrf_group* grp, nrf_stats* s); /* sums; render_ms = slowest member */
 
 /* ---- stage entry points (unit parity against the oracle) -----------------

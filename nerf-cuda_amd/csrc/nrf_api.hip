@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -190,12 +191,39 @@ struct nrf_context {
   size_t n_alloc_px = 0;
   void* d_rgba = nullptr;
   void* d_depth = nullptr;
-  void* d_counters = nullptr;
+  void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
+  int call_index = 0;          // ring position of the last render call
   void* d_rgb8 = nullptr;
   void* d_depth8 = nullptr;
   void* bound_rgba = nullptr;  // caller-owned targets (nrf_bind_output)
   void* bound_depth = nullptr;
   void* bound_rgbd8 = nullptr;  // caller-owned packed 8-bit target (nrf_bind_output_rgbd8)
+  void* bound_rgb8 = nullptr;   // caller-owned 8-bit planar targets (nrf_bind_output_u8)
+  void* bound_depth8 = nullptr;
+  // host frames (nrf_submit_host_u8): HOST_SLOTS x {device 8-bit planes the kernel writes, pinned host planes the copy
+  // engine fills}, so that the copy of one call overlaps the render of the next
+  struct HostSlot {
+    void* d_buf = nullptr;     // device: rgb [views][px][3] | depth [views][px]
+    uint8_t* h_buf = nullptr;  // pinned host, same layout
+    size_t views = 0, px = 0;  // capacity
+    hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;  // done: the call's last copy; t0 / t1: around its render launches
+    std::vector<int> row_lo, row_hi;  // per view: the rows of the pinned planes that do not hold the background value
+    int bg = -1;               // the 8-bit background value the other rows hold (-1: nothing filled yet)
+    int n_views = 0, W = 0, H = 0;
+    bool with_depth = true, pending = false;
+    uint64_t copied = 0;
+    std::vector<int> rows;     // this call: per view the rows [lo, hi) of its region of interest (what is copied)
+    // progress reporting (FrameParams::prog_*): the kernel flags finished strip rows, nrf_wait_host_u8 copies them meanwhile
+    unsigned* d_done = nullptr;   // device [views][tiles_y]
+    unsigned* h_flags = nullptr;  // pinned host [views][tiles_y]
+    size_t prog_entries = 0;
+    unsigned epoch = 0;
+    bool progressive = false, copies_issued = false;
+  } hs[2];
+  int hs_next = 0;
+  hipStream_t copy_stream = nullptr;
+  bool host_progressive = true;  // NRF_HOST_PROGRESSIVE=0: every copy of a host frame waits for the end of its render (A/B runs)
+  bool host_skip_outside = true; // NRF_HOST_SKIP_OUTSIDE=0: the kernel writes the background rows of a host frame as well (A/B runs)
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
   int march_budget = 256;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
@@ -223,6 +251,26 @@ void free_model(nrf_context* c) {
   c->d_wfrag_gen = nullptr;
   c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = c->d_gen = nullptr;
   c->model_loaded = false;
+}
+
+constexpr int CALL_RING = 16;  // render calls of one context that may be in flight on different streams
+constexpr size_t CALL_SLOT_BYTES = COUNTER_BYTES + 128 + 65536;  // statistics | work queues | the diagnostic build's per-wave stamps
+constexpr int HOST_SLOTS = 2;
+inline char* call_slot(const nrf_context* c, int index) { return (char*)c->d_counters + (size_t)(index % CALL_RING) * CALL_SLOT_BYTES; }
+
+void free_host_slots(nrf_context* c) {
+  for (auto& h : c->hs) {
+    if (h.d_buf) (void)hipFree(h.d_buf);
+    if (h.h_buf) (void)hipHostFree(h.h_buf);
+    if (h.d_done) (void)hipFree(h.d_done);
+    if (h.h_flags) (void)hipHostFree(h.h_flags);
+    h.d_buf = nullptr;
+    h.h_buf = nullptr;
+    h.d_done = h.h_flags = nullptr;
+    h.views = h.px = h.prog_entries = 0;
+    h.bg = -1;
+    h.pending = false;
+  }
 }
 
 void free_frame(nrf_context* c) {
@@ -283,7 +331,10 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.max_steps = c->opt.max_steps;
   P.march_budget = c->march_budget;
   P.centre_out = c->centre_out ? 1 : 0;
-  P.out_rgbd8 = c->bound_rgbd8 ? 1 : 0;
+  P.out_mode = c->bound_rgbd8 ? OUT_RGBD8 : (c->bound_rgb8 ? OUT_U8 : OUT_F32);
+  P.skip_outside = 0;
+  P.prog_done = P.prog_flags = nullptr;
+  P.prog_epoch = 0;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
 }
@@ -612,8 +663,25 @@ int nrf_create(int device, nrf_context** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->d_counters, COUNTER_BYTES + 128 + 65536));  // + the persistent kernel's work-queue counter (+ the diagnostic build's per-wave stamps)
-  HIP_TRY(hipMemset(c->d_counters, 0, COUNTER_BYTES));
+  if (const char* e = std::getenv("NRF_HOST_PROGRESSIVE")) c->host_progressive = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_HOST_SKIP_OUTSIDE")) c->host_skip_outside = std::atoi(e) != 0;
+  // The copy stream gets a hardware queue of its own.  HIP maps streams onto a few hardware queues (4 by default) and a
+  // device-to-host copy issued while a render is resident on a queue it shares does not start before that render has
+  // ended (scripts/copy_overlap_probe.py: a 133 MB copy issued 2 ms into a 14 ms render ended 2.3 ms after the render's
+  // END; on a queue of its own it ran beside the render and ended 4.5 ms after its start).  Streams of another priority
+  // come from another pool of hardware queues, whatever GPU_MAX_HW_QUEUES says.
+  {
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi));
+  }
+  for (auto& h : c->hs) {
+    HIP_TRY(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&h.t0));
+    HIP_TRY(hipEventCreate(&h.t1));
+  }
+  HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
+  HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
   *out = c;
   return NRF_OK;
 }
@@ -624,6 +692,13 @@ int nrf_destroy(nrf_context* c) {
   (void)hipDeviceSynchronize();
   free_model(c);
   free_frame(c);
+  free_host_slots(c);
+  for (auto& h : c->hs) {
+    if (h.done) (void)hipEventDestroy(h.done);
+    if (h.t0) (void)hipEventDestroy(h.t0);
+    if (h.t1) (void)hipEventDestroy(h.t1);
+  }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -943,28 +1018,40 @@ int nrf_set_max_views(nrf_context* c, int max_views) {
   return alloc_frame(c);
 }
 
-// One launch per NRF_MAX_VIEWS cameras; all launches of a batch go to the same stream back to back.
-int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float* poses, void* stream, nrf_frame* out) {
-  int rc = need_model(c);
-  if (rc) return rc;
-  if (!cams || !poses) return fail(NRF_E_INVALID, "null argument");
-  if (n_views < 1) return fail(NRF_E_INVALID, "n_views must be >= 1");
-  if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
-  if (c->grid_missing)
-    return fail(NRF_E_STATE, "the model was loaded without a density grid: call nrf_generate_density_grid first");
-  if (!c->bound_rgba && !c->bound_rgbd8 && n_views > c->max_views)
-    return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
+}  // extern "C"
+
+namespace {
+// the rows [lo, hi) of a frame that the strip rows of a view's region of interest cover (what launch_render queues for the
+// persistent kernel); every pixel outside them is the background
+void roi_rows(const int roi[4], int H, int& lo, int& hi) {
+  lo = hi = 0;
+  if (roi[2] < roi[0] || roi[3] < roi[1]) return;
+  const int tiles_y = (H + 7) / 8;
+  const int ty0 = std::max(roi[1] >> 3, 0), ty1 = std::min(roi[3] >> 3, tiles_y - 1);
+  if (ty1 < ty0) return;
+  lo = 8 * ty0;
+  hi = std::min(H, 8 * (ty1 + 1));
+}
+
+// One launch per NRF_MAX_VIEWS cameras; all launches of a call go to the same stream back to back.  Every call takes the
+// next slot of the context's ring of statistics counters + work queues (cleared on the call's own stream), so calls of
+// one context that overlap on different streams never share a queue.
+// rows_out (optional): per view the rows [lo, hi) its region of interest covers.
+struct ProgressArgs {
+  unsigned* done;   // device [n_views][tiles_y], zeroed on the stream before the launches
+  unsigned* flags;  // pinned host [n_views][tiles_y]
+  unsigned epoch;
+};
+int render_views_impl(nrf_context* c, int n_views, const float* cams, const float* poses, hipStream_t st, void* rgba, void* depth,
+                      size_t stride_px, int out_mode, int skip_outside, int* rows_out, const ProgressArgs* prog = nullptr) {
   FrameParams P;
   fill_frame_params(c, cams, poses, P);
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, COUNTER_BYTES + RENDER_QUEUE_BYTES, st));  // statistics + the first launch's work queues
+  P.out_mode = out_mode;
+  P.skip_outside = skip_outside;
+  c->call_index = (c->call_index + 1) % CALL_RING;
+  char* counters = call_slot(c, c->call_index);
+  HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_BYTES + RENDER_QUEUE_BYTES, st));  // statistics + the first launch's work queues
   HIP_TRY(hipEventRecord(c->ev0, st));
-  void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
-  void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
-  if (c->bound_rgbd8) {  // 4 bytes per pixel where the depth plane would be (store_pixel)
-    rgba = nullptr;
-    depth = c->bound_rgbd8;
-  }
   // views per launch: NRF_MAX_VIEWS, fewer when the frames are so large that the persistent kernel's 24-bit queue positions
   // (strip rows of all views x strips per row) would not hold the launch (8K frames: 64 views)
   int per_launch = MAX_VIEWS;
@@ -972,37 +1059,337 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
     const long long per_view = (long long)P.tiles_y * ((P.tiles_x + 3) / 4);
     if (per_view * per_launch >= 0xffffff) per_launch = (int)std::max(1LL, 0xfffffeLL / std::max(per_view, 1LL));
   }
+  const size_t px_bytes_a = out_mode == OUT_U8 ? 3 : 16, px_bytes_b = out_mode == OUT_U8 ? 1 : 4;
   for (int first = 0; first < n_views; first += per_launch) {
     ViewBatch VB;
     std::memset(&VB, 0, sizeof(VB));
     VB.n_views = n_views - first < per_launch ? n_views - first : per_launch;
-    VB.view_stride_px = c->n_out_px;
+    VB.view_stride_px = stride_px;
     for (int v = 0; v < VB.n_views; ++v) {
       nerf_matrix_to_ngp(poses + 16 * (size_t)(first + v), c->desc.scale, VB.v[v].R, VB.v[v].org);
       for (int i = 0; i < 4; ++i) VB.v[v].cam[i] = cams[4 * (size_t)(first + v) + i];
       view_roi(VB.v[v].R, VB.v[v].org, VB.v[v].cam, c->dm.occ_box, c->W, c->H, VB.v[v].roi);
+      if (rows_out) roi_rows(VB.v[v].roi, c->H, rows_out[2 * (first + v)], rows_out[2 * (first + v) + 1]);
     }
-    HIP_TRY(launch_render(c->dm, P, VB, rgba ? (char*)rgba + (size_t)first * c->n_out_px * 16 : nullptr, (char*)depth + (size_t)first * c->n_out_px * 4,
-                          c->d_counters, st, first == 0));
+    if (prog) {  // (the kernel indexes its progress arrays by the launch's own view numbers)
+      P.prog_done = prog->done + (size_t)first * P.tiles_y;
+      P.prog_flags = prog->flags + (size_t)first * P.tiles_y;
+      P.prog_epoch = (int)prog->epoch;
+    }
+    HIP_TRY(launch_render(c->dm, P, VB, rgba ? (char*)rgba + (size_t)first * stride_px * px_bytes_a : nullptr,
+                          (char*)depth + (size_t)first * stride_px * px_bytes_b, counters, st, first == 0));
   }
-  c->last_rgba = rgba;
-  c->last_depth = rgba ? depth : nullptr;  // (a packed 8-bit frame is the caller's to read)
   c->last_views = n_views;
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->last_stream = st;
   c->rendered = true;
+  return NRF_OK;
+}
+
+int check_renderable(nrf_context* c, const float* cams, const float* poses, int n_views) {
+  int rc = need_model(c);
+  if (rc) return rc;
+  if (!cams || !poses) return fail(NRF_E_INVALID, "null argument");
+  if (n_views < 1) return fail(NRF_E_INVALID, "n_views must be >= 1");
+  if (c->W <= 0 || !c->d_rgba) return fail(NRF_E_STATE, "set_resolution has not been called");
+  if (c->grid_missing)
+    return fail(NRF_E_STATE, "the model was loaded without a density grid: call nrf_generate_density_grid first");
+  return NRF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float* poses, void* stream, nrf_frame* out) {
+  int rc = check_renderable(c, cams, poses, n_views);
+  if (rc) return rc;
+  const bool bound = c->bound_rgba || c->bound_rgbd8 || c->bound_rgb8;
+  if (!bound && n_views > c->max_views)
+    return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
+  if (c->bound_rgb8 && c->opt.shard_count != 1)
+    return fail(NRF_E_STATE, "8-bit planar output (nrf_bind_output_u8) needs a single-shard (row-major) frame");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
+  void* depth = c->bound_depth ? c->bound_depth : c->d_depth;
+  int mode = OUT_F32;
+  if (c->bound_rgbd8) {  // 4 bytes per pixel where the depth plane would be (store_pixel)
+    rgba = nullptr;
+    depth = c->bound_rgbd8;
+    mode = OUT_RGBD8;
+  } else if (c->bound_rgb8) {
+    rgba = c->bound_rgb8;
+    depth = c->bound_depth8;
+    mode = OUT_U8;
+  }
+  rc = render_views_impl(c, n_views, cams, poses, st, rgba, depth, c->n_out_px, mode, 0, nullptr);
+  if (rc) return rc;
+  const bool floats = mode == OUT_F32;
+  c->last_rgba = floats ? rgba : nullptr;  // (an 8-bit frame in a bound buffer is the caller's to read)
+  c->last_depth = floats ? depth : nullptr;
   if (!stream) HIP_TRY(hipStreamSynchronize(st));
   if (out) {
     out->width = c->W;
     out->height = c->H;
     out->n_tiles = c->n_local_tiles;
-    out->rgba = rgba;
-    out->depth = rgba ? depth : nullptr;
-    out->tile_major = P.tile_major;
+    out->rgba = floats ? rgba : nullptr;
+    out->depth = floats ? depth : nullptr;
+    out->tile_major = c->opt.shard_count > 1;
     out->n_views = n_views;
     out->view_stride_px = (int64_t)c->n_out_px;
   }
   return NRF_OK;
+}
+
+// ---- host frames: the reference's render_frame ends in HOST memory (R/src/nerf_render.cu:345-359: D2H of the float
+// planes, then a single-threaded quantise / de-interleave loop per GPU).  Here the kernel writes the 8-bit Image itself
+// (OUT_U8), the rows of the view's region of interest travel by one asynchronous copy per plane into pinned memory the
+// context owns, and the rows outside it -- background by construction -- are filled by the calling thread while the GPU
+// renders (only those that held something else: a camera that moves a little costs a few rows).  Two slots: the copy of
+// one call overlaps the render of the next.
+static uint8_t host_quant_u8(float v) {  // quant_u8 of nrf_kernels.hip
+  const double s = 255.0 * (double)v;
+  if (!(s > 0.0)) return 0;
+  if (s >= 255.0) return 255;
+  return (uint8_t)s;
+}
+
+namespace {
+// copies the rows [lo, hi) of view v of a host-frame slot (both planes) on the context's copy stream
+int copy_rows(nrf_context* c, nrf_context::HostSlot& h, int v, int lo, int hi) {
+  if (hi <= lo) return NRF_OK;
+  const size_t Wb = (size_t)h.W, px = h.px, depth_off = h.views * px * 3;
+  const size_t ro = ((size_t)v * px + (size_t)lo * Wb) * 3, rn = (size_t)(hi - lo) * Wb * 3;
+  HIP_TRY(hipMemcpyAsync(h.h_buf + ro, (const uint8_t*)h.d_buf + ro, rn, hipMemcpyDeviceToHost, c->copy_stream));
+  h.copied += rn;
+  if (h.with_depth) {
+    const size_t dofs = depth_off + (size_t)v * px + (size_t)lo * Wb, dn = (size_t)(hi - lo) * Wb;
+    HIP_TRY(hipMemcpyAsync(h.h_buf + dofs, (const uint8_t*)h.d_buf + dofs, dn, hipMemcpyDeviceToHost, c->copy_stream));
+    h.copied += dn;
+  }
+  return NRF_OK;
+}
+
+// The copies of a progressive call, issued by the waiting thread while the render is still running: a band of strip rows
+// goes to the copy engine as soon as the kernel has flagged all of its rows (the bytes are in memory by then: write-through
+// stores, acknowledged before the row was counted -- nrf_kernels.hip tile_written); whatever is left when the kernel's end
+// event fires is copied then.  The loop ends with the kernel at the latest: it cannot wait for a flag that never comes.
+int progressive_copies(nrf_context* c, nrf_context::HostSlot& h) {
+  struct Band { int view, lo, hi, s0, s1; };  // pixel rows [lo, hi) = strip rows [s0, s1) of the view
+  std::vector<Band> bands;
+  const int tiles_y = (h.H + 7) / 8;
+  // ~16 bands per call (one view alone: bands of ~70 rows at 1080p; a batch of 16 views: one band per view), but no copy
+  // below 64 KiB: the runtime moves smaller ones with a blit KERNEL, which gets no compute unit while the persistent render
+  // is resident -- it, and every copy queued behind it, would wait for the render's end (scripts/copy_overlap_probe2.py:
+  // 16 KiB copies issued during a 13 ms render all ended with it, 64 KiB ones ran beside it).  The smallest copy of a band
+  // is its depth plane (W bytes per row; rgb-only frames: 3 W).
+  long total = 0;
+  for (int v = 0; v < h.n_views; ++v) total += (h.rows[2 * v + 1] + 7) / 8 - h.rows[2 * v] / 8;
+  const long want_rows = std::max(4L, (total + 15) / 16);  // strip rows per band
+  const long row_bytes = (long)h.W * (h.with_depth ? 1 : 3);
+  const long min_rows = (65536 + 8 * row_bytes - 1) / (8 * row_bytes);  // strip rows whose smallest plane is 64 KiB
+  for (int v = 0; v < h.n_views; ++v) {
+    const int lo = h.rows[2 * v], hi = h.rows[2 * v + 1];
+    if (hi <= lo) continue;
+    const long s_lo = lo / 8, s_hi = (hi + 7) / 8, n = s_hi - s_lo;
+    const long per = std::max(want_rows, min_rows);
+    const long n_bands = std::max(1L, n / per);  // (the remainder is spread over the bands: none is smaller than `per`)
+    for (long b = 0; b < n_bands; ++b) {
+      const int s0 = (int)(s_lo + n * b / n_bands), s1 = (int)(s_lo + n * (b + 1) / n_bands);
+      bands.push_back({v, std::max(lo, 8 * s0), std::min(hi, 8 * s1), s0, s1});
+    }
+  }
+  size_t remaining = bands.size();
+  bool kernel_done = false;
+  unsigned spins = 0;
+  static const bool debug = std::getenv("NRF_HOST_DEBUG") != nullptr;
+  std::vector<hipEvent_t> dbg_events;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  while (remaining) {
+    bool progress = false;
+    for (Band& b : bands) {
+      if (b.view < 0) continue;
+      bool ready = kernel_done;
+      if (!ready) {
+        ready = true;
+        const unsigned* f = h.h_flags + (size_t)b.view * tiles_y;
+        for (int r = b.s0; r < b.s1 && ready; ++r) ready = __atomic_load_n(f + r, __ATOMIC_ACQUIRE) == h.epoch;
+      }
+      if (!ready) continue;
+      if (debug) std::fprintf(stderr, "[host frame] +%.3f ms: band view %d rows %d..%d%s\n", since(), b.view, b.lo, b.hi, kernel_done ? " (kernel done)" : "");
+      hipEvent_t d0 = nullptr, d1 = nullptr;
+      if (debug) { (void)hipEventCreate(&d0); (void)hipEventCreate(&d1); (void)hipEventRecord(d0, c->copy_stream); }
+      int rc = copy_rows(c, h, b.view, b.lo, b.hi);
+      if (rc) return rc;
+      if (debug) { (void)hipEventRecord(d1, c->copy_stream); dbg_events.push_back(d0); dbg_events.push_back(d1); }
+      b.view = -1;
+      --remaining;
+      progress = true;
+    }
+    if (!remaining || progress) continue;
+    if ((++spins & 31u) == 0u) {
+      const hipError_t e = hipEventQuery(h.t1);
+      if (e == hipSuccess) kernel_done = true;
+      else if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  HIP_TRY(hipEventRecord(h.done, c->copy_stream));
+  h.copies_issued = true;
+  if (debug) {  // when the copy engine really moved each band, relative to the start of the render
+    (void)hipEventSynchronize(h.done);
+    for (size_t i = 0; i + 1 < dbg_events.size(); i += 2) {
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, h.t0, dbg_events[i]);
+      (void)hipEventElapsedTime(&b, h.t0, dbg_events[i + 1]);
+      std::fprintf(stderr, "[host frame] copy %zu ran %.3f .. %.3f ms after the render's start\n", i / 2, a, b);
+      (void)hipEventDestroy(dbg_events[i]);
+      (void)hipEventDestroy(dbg_events[i + 1]);
+    }
+  }
+  return NRF_OK;
+}
+}  // namespace
+
+int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const float* poses, int flags, int* ticket) {
+  int rc = check_renderable(c, cams, poses, n_views);
+  if (rc) return rc;
+  if (!ticket) return fail(NRF_E_INVALID, "null argument");
+  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "host frames need a single-shard (row-major) frame");
+  const int si = c->hs_next;
+  nrf_context::HostSlot& h = c->hs[si];
+  // the slot's previous frames are overwritten (nerfhip.h: valid until the second next submit); a call nobody waited for
+  // has no copy in flight -- its render precedes this one on the context's stream
+  if (h.pending && h.copies_issued) HIP_TRY(hipEventSynchronize(h.done));
+  h.pending = false;
+  const size_t px = (size_t)c->W * c->H;
+  const int tiles_y = (c->H + 7) / 8;
+  if (h.px != px || h.views < (size_t)n_views) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (void* q : {h.d_buf, (void*)h.d_done}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)h.h_buf, (void*)h.h_flags}) if (q) (void)hipHostFree(q);
+    h.d_buf = nullptr;
+    h.h_buf = nullptr;
+    h.d_done = h.h_flags = nullptr;
+    h.views = std::max((size_t)n_views, (size_t)c->max_views);
+    h.px = px;
+    h.prog_entries = h.views * (size_t)tiles_y;
+    void* hp = nullptr;
+    HIP_TRY(hipHostMalloc(&hp, h.views * px * 4, hipHostMallocPortable));
+    h.h_buf = (uint8_t*)hp;
+    HIP_TRY(hipMalloc(&h.d_buf, h.views * px * 4));
+    HIP_TRY(hipMalloc((void**)&h.d_done, h.prog_entries * 4));
+    HIP_TRY(hipHostMalloc(&hp, h.prog_entries * 4, hipHostMallocPortable | hipHostMallocMapped));
+    h.h_flags = (unsigned*)hp;
+    std::memset(h.h_flags, 0, h.prog_entries * 4);
+    h.epoch = 0;
+    h.row_lo.assign(h.views, 0);
+    h.row_hi.assign(h.views, c->H);  // unknown content: everything counts as "not background"
+    h.bg = -1;
+  }
+  h.W = c->W;
+  h.H = c->H;
+  h.n_views = n_views;
+  h.with_depth = !(flags & NRF_HOST_RGB_ONLY);
+  h.copied = 0;
+  h.copies_issued = false;
+  // progress reporting needs the persistent form of the kernel (launch_render's choice for this model)
+  h.progressive = c->host_progressive && c->dm.persistent && c->dm.lds_coarse_words > 0;
+  const size_t depth_off = h.views * px * 3;  // depth planes follow the rgb planes of ALL views the slot holds
+  h.rows.assign((size_t)2 * n_views, 0);
+  ProgressArgs prog{h.d_done, h.h_flags, 0u};
+  if (h.progressive) {
+    prog.epoch = ++h.epoch;
+    HIP_TRY(hipMemsetAsync(h.d_done, 0, (size_t)n_views * tiles_y * 4, c->stream));
+  }
+  HIP_TRY(hipEventRecord(h.t0, c->stream));
+  rc = render_views_impl(c, n_views, cams, poses, c->stream, h.d_buf, (uint8_t*)h.d_buf + depth_off, px, OUT_U8, c->host_skip_outside ? 1 : 0, h.rows.data(),
+                         h.progressive ? &prog : nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h.t1, c->stream));
+  c->last_rgba = c->last_depth = nullptr;
+  if (!h.progressive) {  // every copy after the render's end
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, h.t1, 0));
+    for (int v = 0; v < n_views; ++v) {
+      rc = copy_rows(c, h, v, h.rows[2 * v], h.rows[2 * v + 1]);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(h.done, c->copy_stream));
+    h.copies_issued = true;
+  }
+  // while the GPU works: the rows outside the regions of interest.  Pinned rows hold the background value unless a copy
+  // has written them since (row_lo / row_hi), so only the difference to the new ranges is filled.
+  {
+    const int bg = host_quant_u8(c->opt.bg_color);
+    const bool all = h.bg != bg;
+    const size_t Wb = (size_t)c->W;
+    auto fill = [&](int v, int a, int b) {
+      if (b <= a) return;
+      std::memset(h.h_buf + ((size_t)v * px + (size_t)a * Wb) * 3, bg, (size_t)(b - a) * Wb * 3);
+      std::memset(h.h_buf + depth_off + (size_t)v * px + (size_t)a * Wb, 0, (size_t)(b - a) * Wb);  // depth of a missed ray: 0
+    };
+    for (int v = 0; v < (int)h.views; ++v) {
+      if (v < n_views) {
+        const int lo = h.rows[2 * v], hi = h.rows[2 * v + 1];
+        const int plo = all ? 0 : h.row_lo[v], phi = all ? c->H : h.row_hi[v];
+        if (hi <= lo) fill(v, plo, phi);
+        else {
+          fill(v, plo, std::min(phi, lo));
+          fill(v, std::max(plo, hi), phi);
+        }
+        h.row_lo[v] = lo;
+        h.row_hi[v] = hi;
+      } else if (all) {  // (not part of this call: stays as it is, counted as unknown)
+        h.row_lo[v] = 0;
+        h.row_hi[v] = c->H;
+      }
+    }
+    h.bg = bg;
+  }
+  h.pending = true;
+  c->hs_next = (si + 1) % HOST_SLOTS;
+  *ticket = si;
+  return NRF_OK;
+}
+
+int nrf_wait_host_u8(nrf_context* c, int ticket, nrf_host_frame* out) {
+  if (!c || ticket < 0 || ticket >= HOST_SLOTS) return fail(NRF_E_INVALID, "bad ticket");
+  nrf_context::HostSlot& h = c->hs[ticket];
+  if (!h.h_buf || h.n_views < 1) return fail(NRF_E_STATE, "nothing was submitted with this ticket");
+  int rc = set_device(c);
+  if (rc) return rc;
+  if (h.pending) {
+    if (!h.copies_issued) {
+      rc = progressive_copies(c, h);
+      if (rc) return rc;
+    }
+    // the last copy is a few tens of microseconds away: poll before blocking
+    hipError_t e = hipErrorNotReady;
+    for (int i = 0; i < 4000 && e == hipErrorNotReady; ++i) e = hipEventQuery(h.done);
+    if (e == hipErrorNotReady) e = hipEventSynchronize(h.done);
+    if (e != hipSuccess) return hip_fail(e, "waiting for the host frame's copies");
+  }
+  h.pending = false;
+  if (out) {
+    out->width = h.W;
+    out->height = h.H;
+    out->n_views = h.n_views;
+    out->rgb = h.h_buf;
+    out->depth = h.with_depth ? h.h_buf + h.views * h.px * 3 : nullptr;
+    out->view_stride_px = (int64_t)h.px;
+    out->render_ms = 0.f;
+    out->copied_bytes = h.copied;
+    (void)hipEventElapsedTime(&out->render_ms, h.t0, h.t1);
+  }
+  return NRF_OK;
+}
+
+int nrf_render_host_u8(nrf_context* c, int n_views, const float* cams, const float* poses, int flags, nrf_host_frame* out) {
+  int ticket = -1;
+  int rc = nrf_submit_host_u8(c, n_views, cams, poses, flags, &ticket);
+  if (rc) return rc;
+  return nrf_wait_host_u8(c, ticket, out);
 }
 
 int nrf_render_batch(nrf_context* c, int n_views, const float* cams, const float* poses, void* stream, nrf_frame* out) {
@@ -1020,7 +1407,7 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
   if (!c || !out) return fail(NRF_E_INVALID, "null argument");
   HIP_TRY(hipEventSynchronize(c->ev1));
   unsigned long long raw[COUNTER_SLOTS * 16];
-  HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(raw, call_slot(c, c->call_index), COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) {
     out[i] = 0;
     for (int sl = 0; sl < COUNTER_SLOTS; ++sl) out[i] = i == 14 ? std::max(out[i], raw[sl * 16 + i]) : out[i] + raw[sl * 16 + i];  // 14: a maximum
@@ -1039,7 +1426,7 @@ extern "C" int nrf_debug_instance(nrf_context* c) {
 extern "C" int nrf_debug_wave_times(nrf_context* c, unsigned long long* out, int n_waves) {
   if (!c || !out || n_waves < 1 || n_waves > 4096) return fail(NRF_E_INVALID, "bad argument");
   HIP_TRY(hipEventSynchronize(c->ev1));
-  HIP_TRY(hipMemcpy(out, (char*)c->d_counters + COUNTER_BYTES + 128, (size_t)n_waves * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, call_slot(c, c->call_index) + COUNTER_BYTES + 128, (size_t)n_waves * 16, hipMemcpyDeviceToHost));
   return NRF_OK;
 }
 
@@ -1063,13 +1450,24 @@ int nrf_bind_output(nrf_context* c, void* rgba, void* depth) {
   c->bound_rgba = rgba;
   c->bound_depth = depth;
   c->bound_rgbd8 = nullptr;
+  c->bound_rgb8 = c->bound_depth8 = nullptr;
   return NRF_OK;
 }
 
 int nrf_bind_output_rgbd8(nrf_context* c, void* rgbd8) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   c->bound_rgbd8 = rgbd8;
-  if (rgbd8) c->bound_rgba = c->bound_depth = nullptr;
+  if (rgbd8) c->bound_rgba = c->bound_depth = c->bound_rgb8 = c->bound_depth8 = nullptr;
+  return NRF_OK;
+}
+
+int nrf_bind_output_u8(nrf_context* c, void* rgb8, void* depth8) {
+  if (!c) return fail(NRF_E_INVALID, "null context");
+  if ((rgb8 == nullptr) != (depth8 == nullptr)) return fail(NRF_E_INVALID, "bind both planes or neither");
+  if (((uintptr_t)rgb8 | (uintptr_t)depth8) & 3u) return fail(NRF_E_INVALID, "8-bit planes must be 4-byte aligned");
+  c->bound_rgb8 = rgb8;
+  c->bound_depth8 = depth8;
+  if (rgb8) c->bound_rgba = c->bound_depth = c->bound_rgbd8 = nullptr;
   return NRF_OK;
 }
 
@@ -1080,7 +1478,7 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   if (rc) return rc;
   HIP_TRY(hipEventSynchronize(c->ev1));
   unsigned long long raw[COUNTER_SLOTS * 16], cnt[3] = {0, 0, 0};
-  HIP_TRY(hipMemcpy(raw, c->d_counters, COUNTER_BYTES, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(raw, call_slot(c, c->call_index), COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int sl = 0; sl < COUNTER_SLOTS; ++sl) {
     cnt[0] += raw[sl * 16];
     cnt[1] += raw[sl * 16 + 1];
@@ -1156,6 +1554,35 @@ int nrf_quantize_rgbd8(nrf_context* c, const void* rgba, const void* depth, uint
   if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIP_TRY(launch_quantize_rgbd8(rgba, depth, n_px, out_u32, st));
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
+int nrf_quantize_u8(nrf_context* c, const void* rgba, const void* depth, uint64_t n_px, void* rgb8, void* depth8, void* stream) {
+  if (!c || !rgba || !depth || !rgb8 || !depth8) return fail(NRF_E_INVALID, "null argument");
+  if (n_px >= (1ull << 31)) return fail(NRF_E_INVALID, "n_px must be below 2^31");
+  int rc = set_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(launch_quantize(rgba, depth, (int)n_px, rgb8, depth8, st));
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
+int nrf_untile_views_u8(nrf_context* c, const void* gathered_rgbd8, int shard_count, int tiles_per_shard, int n_views, void* rgb8,
+                        void* depth8, void* stream) {
+  if (!c || !gathered_rgbd8 || !rgb8 || !depth8 || shard_count < 1 || tiles_per_shard < 1 || n_views < 1)
+    return fail(NRF_E_INVALID, "bad argument");
+  if (c->W <= 0) return fail(NRF_E_STATE, "set_resolution has not been called");
+  if (((uintptr_t)gathered_rgbd8 & 15u) || ((c->W & 3) == 0 && (((uintptr_t)rgb8 | (uintptr_t)depth8) & 3u)))
+    return fail(NRF_E_INVALID, "the gathered shards must be 16-byte aligned, the 8-bit planes 4-byte aligned (widths that are multiples of 4)");
+  int rc = set_device(c);
+  if (rc) return rc;
+  int tps = 0;
+  nrf_tiles_per_shard(c->W, c->H, shard_count, &tps);
+  if (tps != tiles_per_shard) return fail(NRF_E_INVALID, "tiles_per_shard does not match the resolution");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(launch_untile_rgbd8_u8(gathered_rgbd8, shard_count, tiles_per_shard, c->W, c->H, n_views, rgb8, depth8, st));
   if (!stream) HIP_TRY(hipStreamSynchronize(st));
   return NRF_OK;
 }

@@ -153,6 +153,7 @@ struct ViewBatch {
   unsigned long long view_stride_px;   // pixels between consecutive views in the output planes
 };
 
+enum : int { OUT_F32 = 0, OUT_RGBD8 = 1, OUT_U8 = 2 };
 struct FrameParams {
   float R[9];    // view 0 (stage kernels): rotation of nerf_matrix_to_ngp(pose)
   float org[3];  // translation
@@ -166,8 +167,18 @@ struct FrameParams {
   int max_steps;
   int march_budget;  // cell trips a lane may spend per round (tuning knob, default 256)
   int queue_classes;  // persistent kernel, unsharded frames: work queues (8: one per XCD; 1: a single queue); 0: default
-  int out_rgbd8;    // the frame goes to a packed 8-bit buffer (r | g << 8 | b << 16 | depth << 24) passed as the depth plane
+  int out_mode;     // OUT_F32: float planes; OUT_RGBD8: packed 8-bit pixels (r | g << 8 | b << 16 | depth << 24) passed as the depth
+                    // plane; OUT_U8: the reference's host Image layout -- rgb u8 [px][3] passed as the rgba plane, depth u8 [px]
+  int skip_outside; // persistent kernel: the tiles outside the strip rows a view's region of interest touches are NOT written
+                    // (the host-frame path fills those rows of its pinned buffer itself and copies only the other rows)
   int centre_out;   // persistent kernel: a view's strip rows are queued from the middle of its region of interest outwards
+  // persistent kernel, OUT_U8 host frames: progress reporting, so that the host can start copying a frame's finished rows
+  // while the rest still renders.  prog_done [n_views][tiles_y] (device, zeroed per call): tiles of that strip row whose
+  // pixels have been written (write-through, acknowledged); the wave that completes a row stores prog_epoch into
+  // prog_flags [n_views][tiles_y] (pinned host memory).  nullptr: off.
+  int prog_epoch;
+  unsigned* prog_done;
+  unsigned* prog_flags;
 };
 
 // ------------------------------------------------------------------ misc ----

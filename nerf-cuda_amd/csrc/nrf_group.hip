@@ -7,6 +7,10 @@
 // peer-to-peer: point-to-point links, so the n-1 copies into device 0 run on n-1 different links)
 // and the first member untiles all views in one launch.  No host thread, no host copy, no RCCL
 // (RCCL is the exchange of the one-process-per-GPU form, bench.py).
+// Host frames (nrf_group_submit_host_u8: what ngp::NerfRender::render_frame returns): the members render their shards
+// as PACKED 8-bit pixels (4 B/px on the links instead of 20), the first member untiles them straight into the planar
+// layout of the reference's Image, and one asynchronous copy per plane brings the batch into pinned host memory; two
+// slots, so that this copy overlaps the next call's render.
 // Built only on the public ABI plus HIP peer copies.
 
 #include <hip/hip_runtime.h>
@@ -47,17 +51,50 @@ struct nrf_group {
   void* gathered_depth = nullptr; //                [member][view][tps*64]    f32
   void* frame_rgba = nullptr;     // on devices[0]: [view][H][W][4]
   void* frame_depth = nullptr;    //                [view][H][W]
-  void* packed = nullptr;         // readback scratch: [H][W] u32
+  void* scratch8 = nullptr;       // nrf_group_read_view_u8 scratch on devices[0]: rgb u8 [H][W][3] | depth u8 [H][W]
+  // host frames
+  struct HostSlot {
+    void* gathered = nullptr;      // devices[0]: [member][view][tps*64] packed pixels
+    void* d_buf = nullptr;         // devices[0]: rgb u8 [views][px][3] | depth u8 [views][px]
+    uint8_t* h_buf = nullptr;      // pinned host, same layout
+    hipEvent_t untiled = nullptr, done = nullptr, t0 = nullptr;  // t0 .. untiled: the call's device time on devices[0]
+    int n_views = 0, views = 0;    // views of the last call / views the slot's buffers hold
+    bool with_depth = true, pending = false, single = false;
+    int member_ticket = -1;        // single-member groups: the member context's own ticket
+  } hs[2];
+  int hs_next = 0, shard_views = 0;  // shard_views: views the members' shard buffers hold
+  std::vector<void*> shard8;        // member i, on its device: [view][tps*64] packed pixels
+  hipStream_t copy_stream = nullptr;  // on devices[0]
 };
 
 namespace {
 void free_buffers(nrf_group* g) {
   if (g->devices.empty()) return;
   (void)hipSetDevice(g->devices[0]);
-  for (void** p : {&g->gathered_rgba, &g->gathered_depth, &g->frame_rgba, &g->frame_depth, &g->packed}) {
+  for (void** p : {&g->gathered_rgba, &g->gathered_depth, &g->frame_rgba, &g->frame_depth, &g->scratch8}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+}
+
+void free_host_slots(nrf_group* g) {
+  if (g->devices.empty()) return;
+  for (size_t i = 0; i < g->shard8.size(); ++i) {
+    (void)hipSetDevice(g->devices[i]);
+    if (g->shard8[i]) (void)hipFree(g->shard8[i]);
+    g->shard8[i] = nullptr;
+  }
+  (void)hipSetDevice(g->devices[0]);
+  for (auto& h : g->hs) {
+    if (h.gathered) (void)hipFree(h.gathered);
+    if (h.d_buf) (void)hipFree(h.d_buf);
+    if (h.h_buf) (void)hipHostFree(h.h_buf);
+    h.gathered = h.d_buf = nullptr;
+    h.h_buf = nullptr;
+    h.pending = false;
+    h.views = 0;
+  }
+  g->shard_views = 0;
 }
 
 int ensure_buffers(nrf_group* g, int n_views) {
@@ -73,7 +110,7 @@ int ensure_buffers(nrf_group* g, int n_views) {
   GHIP(hipMalloc(&g->gathered_depth, n * n_views * shard_px * 4));
   GHIP(hipMalloc(&g->frame_rgba, (size_t)n_views * frame_px * 16));
   GHIP(hipMalloc(&g->frame_depth, (size_t)n_views * frame_px * 4));
-  GHIP(hipMalloc(&g->packed, frame_px * 4));
+  GHIP(hipMalloc(&g->scratch8, frame_px * 4));
   return NRF_OK;
 }
 }  // namespace
@@ -111,6 +148,18 @@ int nrf_group_create(int n_devices, const int* devices, nrf_group** out) {
       }
     }
   }
+  g->shard8.assign(g->ctx.size(), nullptr);
+  // (a stream of another priority: a hardware queue it shares with no render stream -- see nrf_create)
+  int prio_lo = 0, prio_hi = 0;
+  bool ok = hipSetDevice(g->devices[0]) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&g->copy_stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  for (auto& h : g->hs)
+    ok = ok && hipEventCreate(&h.untiled) == hipSuccess && hipEventCreate(&h.t0) == hipSuccess &&
+         hipEventCreateWithFlags(&h.done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    nrf_group_destroy(g);
+    return gfail(NRF_E_HIP, "nrf_group_create: stream / event creation failed");
+  }
   *out = g;
   return NRF_OK;
 }
@@ -122,6 +171,14 @@ int nrf_group_destroy(nrf_group* g) {
     (void)hipDeviceSynchronize();
   }
   free_buffers(g);
+  free_host_slots(g);
+  if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+  for (auto& h : g->hs) {
+    if (h.untiled) (void)hipEventDestroy(h.untiled);
+    if (h.t0) (void)hipEventDestroy(h.t0);
+    if (h.done) (void)hipEventDestroy(h.done);
+  }
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   for (size_t i = 0; i < g->stream.size(); ++i) {
     (void)hipSetDevice(g->devices[i]);
     if (g->done[i]) (void)hipEventDestroy(g->done[i]);
@@ -164,6 +221,7 @@ int nrf_group_set_resolution(nrf_group* g, int width, int height) {
   g->H = height;
   GTRY(nrf_tiles_per_shard(width, height, (int)g->ctx.size(), &g->tps));
   free_buffers(g);
+  free_host_slots(g);
   g->max_views = 0;
   return ensure_buffers(g, 1);
 }
@@ -223,21 +281,122 @@ int nrf_group_read_view_u8(nrf_group* g, int view, uint8_t* rgb, uint8_t* depth)
   if (g->ctx.size() == 1) return nrf_read_view_u8(g->ctx[0], view, rgb, depth);
   const size_t px = (size_t)g->W * g->H;
   GHIP(hipSetDevice(g->devices[0]));
-  GTRY(nrf_quantize_rgbd8(g->ctx[0], (const char*)g->frame_rgba + (size_t)view * px * 16,
-                          (const char*)g->frame_depth + (size_t)view * px * 4, px, g->packed, (void*)g->stream[0]));
+  // quantised into the Image layout on the device (nerf_render.cu:352-359 is a host loop); the copies go to the caller's memory
+  uint8_t* d_rgb = (uint8_t*)g->scratch8;
+  uint8_t* d_depth = d_rgb + px * 3;
+  GTRY(nrf_quantize_u8(g->ctx[0], (const char*)g->frame_rgba + (size_t)view * px * 16, (const char*)g->frame_depth + (size_t)view * px * 4,
+                       px, d_rgb, d_depth, (void*)g->stream[0]));
   GHIP(hipStreamSynchronize(g->stream[0]));
-  std::vector<uint32_t> host(px);
-  GHIP(hipMemcpy(host.data(), g->packed, px * 4, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < px; ++i) {
-    const uint32_t v = host[i];
-    if (rgb) {
-      rgb[3 * i] = (uint8_t)(v & 0xffu);
-      rgb[3 * i + 1] = (uint8_t)((v >> 8) & 0xffu);
-      rgb[3 * i + 2] = (uint8_t)((v >> 16) & 0xffu);
+  if (rgb) GHIP(hipMemcpy(rgb, d_rgb, px * 3, hipMemcpyDeviceToHost));
+  if (depth) GHIP(hipMemcpy(depth, d_depth, px, hipMemcpyDeviceToHost));
+  return NRF_OK;
+}
+
+// ---- host frames (nerfhip.h "host frames")
+int nrf_group_submit_host_u8(nrf_group* g, int n_views, const float* cams, const float* poses, int flags, int* ticket) {
+  if (!g || !cams || !poses || !ticket || n_views < 1) return gfail(NRF_E_INVALID, "bad argument");
+  if (g->W <= 0) return gfail(NRF_E_STATE, "nrf_group_set_resolution has not been called");
+  const size_t n = g->ctx.size();
+  const int si = g->hs_next;
+  nrf_group::HostSlot& h = g->hs[si];
+  g->hs_next = (si + 1) % 2;
+  h.n_views = n_views;
+  h.with_depth = !(flags & NRF_HOST_RGB_ONLY);
+  *ticket = si;
+  if (n == 1) {  // one member: its own host-frame path (region-of-interest rows only, no untile)
+    h.single = true;
+    h.pending = true;
+    return nrf_submit_host_u8(g->ctx[0], n_views, cams, poses, flags, &h.member_ticket);
+  }
+  h.single = false;
+  GHIP(hipSetDevice(g->devices[0]));
+  if (h.pending) GHIP(hipEventSynchronize(h.done));
+  h.pending = false;
+  const size_t shard_px = (size_t)g->tps * 64, frame_px = (size_t)g->W * g->H;
+  if (n_views > g->shard_views) {  // the members' shard buffers (their streams are drained first: a render may still write them)
+    for (size_t i = 0; i < n; ++i) {
+      GHIP(hipSetDevice(g->devices[i]));
+      GHIP(hipStreamSynchronize(g->stream[i]));
+      if (g->shard8[i]) (void)hipFree(g->shard8[i]);
+      g->shard8[i] = nullptr;
+      GHIP(hipMalloc(&g->shard8[i], (size_t)n_views * shard_px * 4));
     }
-    if (depth) depth[i] = (uint8_t)(v >> 24);
+    g->shard_views = n_views;
+    GHIP(hipSetDevice(g->devices[0]));
+  }
+  if (n_views > h.views) {  // this slot only: the other one may hold frames that have not been read yet
+    GHIP(hipStreamSynchronize(g->stream[0]));
+    GHIP(hipStreamSynchronize(g->copy_stream));
+    if (h.gathered) (void)hipFree(h.gathered);
+    if (h.d_buf) (void)hipFree(h.d_buf);
+    if (h.h_buf) (void)hipHostFree(h.h_buf);
+    h.gathered = h.d_buf = nullptr;
+    h.h_buf = nullptr;
+    void* hp = nullptr;
+    GHIP(hipMalloc(&h.gathered, n * n_views * shard_px * 4));
+    GHIP(hipMalloc(&h.d_buf, (size_t)n_views * frame_px * 4));
+    GHIP(hipHostMalloc(&hp, (size_t)n_views * frame_px * 4, hipHostMallocPortable));
+    h.h_buf = (uint8_t*)hp;
+    h.views = n_views;
+  }
+  GHIP(hipSetDevice(g->devices[0]));
+  GHIP(hipEventRecord(h.t0, g->stream[0]));
+  for (size_t i = 0; i < n; ++i) {  // every member renders its packed shard and ships it on its own stream
+    GTRY(nrf_bind_output_rgbd8(g->ctx[i], g->shard8[i]));
+    const int rc = nrf_render_views(g->ctx[i], n_views, cams, poses, (void*)g->stream[i], nullptr);
+    (void)nrf_bind_output_rgbd8(g->ctx[i], nullptr);
+    if (rc != NRF_OK) return rc;
+    GHIP(hipSetDevice(g->devices[i]));
+    GHIP(hipMemcpyPeerAsync((char*)h.gathered + i * n_views * shard_px * 4, g->devices[0], g->shard8[i], g->devices[i],
+                            (size_t)n_views * shard_px * 4, g->stream[i]));
+    GHIP(hipEventRecord(g->done[i], g->stream[i]));
+  }
+  GHIP(hipSetDevice(g->devices[0]));
+  for (size_t i = 1; i < n; ++i) GHIP(hipStreamWaitEvent(g->stream[0], g->done[i], 0));
+  uint8_t* d_rgb = (uint8_t*)h.d_buf;
+  uint8_t* d_depth = d_rgb + (size_t)h.views * frame_px * 3;
+  GTRY(nrf_untile_views_u8(g->ctx[0], h.gathered, (int)n, g->tps, n_views, d_rgb, d_depth, (void*)g->stream[0]));
+  GHIP(hipEventRecord(h.untiled, g->stream[0]));
+  GHIP(hipStreamWaitEvent(g->copy_stream, h.untiled, 0));
+  GHIP(hipMemcpyAsync(h.h_buf, d_rgb, (size_t)n_views * frame_px * 3, hipMemcpyDeviceToHost, g->copy_stream));
+  if (h.with_depth)
+    GHIP(hipMemcpyAsync(h.h_buf + (size_t)h.views * frame_px * 3, d_depth, (size_t)n_views * frame_px, hipMemcpyDeviceToHost,
+                        g->copy_stream));
+  GHIP(hipEventRecord(h.done, g->copy_stream));
+  h.pending = true;
+  g->last_views = 0;  // (the float frames of nrf_group_render_views are not what was rendered last)
+  return NRF_OK;
+}
+
+int nrf_group_wait_host_u8(nrf_group* g, int ticket, nrf_host_frame* out) {
+  if (!g || ticket < 0 || ticket >= 2) return gfail(NRF_E_INVALID, "bad ticket");
+  nrf_group::HostSlot& h = g->hs[ticket];
+  if (h.n_views < 1) return gfail(NRF_E_STATE, "nothing was submitted with this ticket");
+  if (h.single) {
+    h.pending = false;
+    return nrf_wait_host_u8(g->ctx[0], h.member_ticket, out);
+  }
+  GHIP(hipSetDevice(g->devices[0]));
+  if (h.pending) GHIP(hipEventSynchronize(h.done));
+  h.pending = false;
+  if (out) {
+    out->width = g->W;
+    out->height = g->H;
+    out->n_views = h.n_views;
+    out->rgb = h.h_buf;
+    out->depth = h.with_depth ? h.h_buf + (size_t)h.views * g->W * g->H * 3 : nullptr;
+    out->view_stride_px = (int64_t)g->W * g->H;
+    out->render_ms = 0.f;
+    out->copied_bytes = (uint64_t)h.n_views * g->W * g->H * (h.with_depth ? 4 : 3);
+    (void)hipEventElapsedTime(&out->render_ms, h.t0, h.untiled);
   }
   return NRF_OK;
+}
+
+int nrf_group_render_host_u8(nrf_group* g, int n_views, const float* cams, const float* poses, int flags, nrf_host_frame* out) {
+  int ticket = -1;
+  GTRY(nrf_group_submit_host_u8(g, n_views, cams, poses, flags, &ticket));
+  return nrf_group_wait_host_u8(g, ticket, out);
 }
 
 int nrf_group_get_stats(nrf_group* g, nrf_stats* s) {

@@ -288,18 +288,127 @@ __device__ __forceinline__ unsigned char quant_u8(float v) {
   return (unsigned char)s;
 }
 
-// One pixel of a frame.  Float planes (rgba [px][4], depth [px]) -- or, when the caller bound a packed 8-bit target
-// (nrf_bind_output_rgbd8: FrameParams::out_rgbd8), the reference's output format r | g << 8 | b << 16 | depth << 24
-// written where the depth plane would be (4 bytes per pixel either way, so the per-view offsets are the same);
-// padding pixels of a shard's tile-major buffer are zero in both forms.
+// One pixel of a frame.  Three output forms (FrameParams::out_mode):
+//   OUT_F32    float planes rgba [px][4], depth [px];
+//   OUT_RGBD8  the reference's 8-bit values packed per pixel, r | g << 8 | b << 16 | depth << 24, written where the depth
+//              plane would be (nrf_bind_output_rgbd8: what a rank of a multi-GPU step puts on the wire);
+//   OUT_U8     the reference's host Image itself (R/src/nerf_render.cu:352-359, common.h:75-89): rgb u8 [px][3] where the
+//              rgba plane would be, depth u8 [px] -- row-major frames only (store_tile_u8 below).
+// Padding pixels of a shard's tile-major buffer are zero.
 __device__ __forceinline__ uint32_t pack_rgbd8(float4 c, float d) {
   return (uint32_t)quant_u8(c.x) | ((uint32_t)quant_u8(c.y) << 8) | ((uint32_t)quant_u8(c.z) << 16) | ((uint32_t)quant_u8(d) << 24);
 }
+// The planes of view `view` of a launch (the view stride is in pixels whatever a pixel's size is).
+struct OutPlanes {
+  float4* rgba;  // OUT_F32: rgba; OUT_U8: rgb bytes; OUT_RGBD8: unused
+  float* depth;  // OUT_F32: depth; OUT_RGBD8: packed pixels; OUT_U8: depth bytes
+};
+template <int OUT8 = -1>
+__device__ __forceinline__ OutPlanes view_planes(const FrameParams& P, float4* rgba0, float* depth0, int view, unsigned long long stride_px) {
+  OutPlanes o;
+  const size_t off = (size_t)view * stride_px;
+  if (OUT8 == 1 || (OUT8 < 0 && P.out_mode == OUT_U8)) {
+    o.rgba = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(rgba0) + 3 * off);
+    o.depth = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(depth0) + off);
+  } else {
+    o.rgba = rgba0 ? rgba0 + off : nullptr;
+    o.depth = depth0 + off;
+  }
+  return o;
+}
+// The 8-bit planes are written THROUGH the L2 (system-scope stores: global_store ... sc0 sc1): once a wave's s_waitcnt
+// vmcnt(0) has returned, the copy engine reads these bytes from memory while the kernel is still running (progress
+// reporting of the persistent kernel, tile_written below).  8 MB per frame: the write combining they forgo is not missed.
+template <typename T>
+__device__ __forceinline__ void store_through(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Progress reporting (FrameParams::prog_*): called by the whole wave after the stores of one tile of strip row `row` of
+// view `view`.  The wave waits for the acknowledgement of its (write-through) stores, then counts the tile; the wave
+// that counts the row's last tile tells the host (one store into pinned memory).  Every other wave of the row had its
+// stores acknowledged before it counted, so whoever sees the flag may read the row's bytes from memory.
+__device__ __forceinline__ void tile_written(const FrameParams& P, int view, int row, int lane) {
+  if (P.prog_done == nullptr) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const size_t i = (size_t)view * P.tiles_y + row;
+    const unsigned old = atomicAdd(P.prog_done + i, 1u);
+    if (old + 1u == (unsigned)P.tiles_x) __hip_atomic_store(P.prog_flags + i, (unsigned)P.prog_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// OUT_U8, one 8x8 tile by one whole wave (every lane active).  A tile row is 24 rgb bytes and 8 depth bytes: for a tile
+// that lies wholly inside a frame whose width is a multiple of 4 the wave assembles them as 6 + 2 aligned dwords per row
+// (ds_bpermute / DPP moves of the packed pixels) and writes 48 + 16 dwords with two store instructions instead of 256
+// byte stores; any other tile takes the byte stores.
+__device__ __forceinline__ void store_tile_u8(const FrameParams& P, unsigned char* rgb8, unsigned char* depth8, int tx, int ty, int lane,
+                                              int px, int py, bool in_img, uint32_t v) {
+  const bool whole = (P.W & 3) == 0 && tx * 8 + 8 <= P.W && ty * 8 + 8 <= P.H;  // wave-uniform
+  if (whole) {
+    // (everything below depends on the lane only, i.e. is invariant in the persistent kernel's tile loop: without the
+    //  empty asm the compiler hoists it out and keeps seven more VGPRs alive through the march and network phases)
+    asm volatile("" : "+v"(lane));
+    const int L = lane < 48 ? lane : 0;
+    const int r = L / 6, q = L - 6 * r;  // dword q of tile row r: bytes 4q .. 4q + 3 = pixels pa, pa + 1
+    const int pa = q + (q >= 3 ? 1 : 0);
+    const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute((r * 8 + pa) << 2, (int)v);
+    const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((r * 8 + pa + 1) << 2, (int)v);
+    const int s = 8 * (q - 3 * (q >= 3 ? 1 : 0));  // 0, 8, 16: the first byte of the dword is channel s / 8 of pixel pa
+    const uint32_t w = ((va & 0xffffffu) >> s) | (vb << (24 - s));
+    uint32_t dd = v >> 24;
+    dd |= (uint32_t)__shfl_down((int)dd, 1) << 8;
+    dd |= (uint32_t)__shfl_down((int)dd, 2) << 16;
+    if (lane < 48) store_through(reinterpret_cast<uint32_t*>(rgb8 + ((size_t)(ty * 8 + r) * P.W + (size_t)tx * 8) * 3 + 4 * q), w);
+    if ((lane & 3) == 0) store_through(reinterpret_cast<uint32_t*>(depth8 + (size_t)py * P.W + px), dd);
+  } else if (in_img) {
+    const size_t idx = (size_t)py * P.W + px;
+    store_through(rgb8 + 3 * idx, (unsigned char)(v & 0xffu));
+    store_through(rgb8 + 3 * idx + 1, (unsigned char)((v >> 8) & 0xffu));
+    store_through(rgb8 + 3 * idx + 2, (unsigned char)((v >> 16) & 0xffu));
+    store_through(depth8 + idx, (unsigned char)(v >> 24));
+  }
+}
+// The same for a tile whose 64 pixels all hold the packed value v (background tiles): no cross-lane traffic.
+__device__ __forceinline__ void store_tile_u8_uniform(const FrameParams& P, unsigned char* rgb8, unsigned char* depth8, int tx, int ty, int lane,
+                                                      int px, int py, bool in_img, uint32_t v) {
+  const bool whole = (P.W & 3) == 0 && tx * 8 + 8 <= P.W && ty * 8 + 8 <= P.H;  // wave-uniform
+  if (whole) {
+    asm volatile("" : "+v"(lane));  // (as in store_tile_u8)
+    const int L = lane < 48 ? lane : 0;
+    const int r = L / 6, q = L - 6 * r;
+    const int s = 8 * (q - 3 * (q >= 3 ? 1 : 0));
+    const uint32_t w = ((v & 0xffffffu) >> s) | (v << (24 - s));
+    const uint32_t d = v >> 24, dd = d | (d << 8) | (d << 16) | (d << 24);
+    if (lane < 48) store_through(reinterpret_cast<uint32_t*>(rgb8 + ((size_t)(ty * 8 + r) * P.W + (size_t)tx * 8) * 3 + 4 * q), w);
+    if ((lane & 3) == 0) store_through(reinterpret_cast<uint32_t*>(depth8 + (size_t)py * P.W + px), dd);
+  } else if (in_img) {
+    const size_t idx = (size_t)py * P.W + px;
+    store_through(rgb8 + 3 * idx, (unsigned char)(v & 0xffu));
+    store_through(rgb8 + 3 * idx + 1, (unsigned char)((v >> 8) & 0xffu));
+    store_through(rgb8 + 3 * idx + 2, (unsigned char)((v >> 16) & 0xffu));
+    store_through(depth8 + idx, (unsigned char)(v >> 24));
+  }
+}
+// called by all 64 lanes of the tile's wave together (tx, ty, k_local are wave-uniform)
+// OUT8: -1 = P.out_mode decides at run time (render_kernel); 1 / 0 = the instance is / is not the OUT_U8 one (the persistent
+// kernel is at its 128-VGPR limit: with the 8-bit store's cross-lane code inlined at its three store sites the hot instance
+// went from 121 to 128 VGPRs and the wide one spilled, so that code lives in instances of its own)
+// UNIFORM: all 64 pixels of the tile have this colour (a background tile)
+template <int OUT8 = -1, bool UNIFORM = false>
 __device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, float* depth, int k_local, int lane, int px, int py,
                                             bool in_img, float4 color, float dn) {
+  if (OUT8 == 1 || (OUT8 < 0 && P.out_mode == OUT_U8)) {
+    if constexpr (UNIFORM)
+      store_tile_u8_uniform(P, reinterpret_cast<unsigned char*>(rgba), reinterpret_cast<unsigned char*>(depth), px >> 3, py >> 3, lane, px, py,
+                            in_img, pack_rgbd8(color, dn));
+    else
+      store_tile_u8(P, reinterpret_cast<unsigned char*>(rgba), reinterpret_cast<unsigned char*>(depth), px >> 3, py >> 3, lane, px, py, in_img,
+                    pack_rgbd8(color, dn));
+    return;
+  }
+  if constexpr (OUT8 == 1) return;
   if (!in_img && !P.tile_major) return;
   const size_t idx = P.tile_major ? (size_t)k_local * 64 + lane : (size_t)py * P.W + px;
-  if (P.out_rgbd8) {
+  if (P.out_mode == OUT_RGBD8) {
     reinterpret_cast<uint32_t*>(depth)[idx] = in_img ? pack_rgbd8(color, dn) : 0u;
   } else {
     rgba[idx] = in_img ? color : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -481,8 +590,11 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   // measured 2-10 % slower: the views then compete for L1/L2 with disjoint table regions.)
   const int view = (int)blockIdx.x / VB.blocks_per_view;  // wave-uniform (SALU)
   const ViewParams& V = VB.v[view];
-  if (rgba) rgba += (size_t)view * VB.view_stride_px;  // (NULL: packed 8-bit output, store_pixel)
-  depth += (size_t)view * VB.view_stride_px;
+  {
+    const OutPlanes op = view_planes(P, rgba, depth, view, VB.view_stride_px);
+    rgba = op.rgba;  // (NULL: packed 8-bit output, store_pixel)
+    depth = op.depth;
+  }
   const int swz = (int)blockIdx.x - view * VB.blocks_per_view;
   const int strips_x = (P.tiles_x + 3) >> 2;
   const int k_local = swz * RENDER_WAVES + wave;
@@ -499,7 +611,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
     // waves of the workgroup take this exit together, before any barrier)
     const int sx0 = (strip % strips_x) * 32, sy0 = ty * 8;
     if (sx0 > V.roi[2] || sx0 + 31 < V.roi[0] || sy0 > V.roi[3] || sy0 + 7 < V.roi[1]) {
-      if (valid_tile) store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f), 0.f);
+      if (valid_tile) store_pixel<-1, true>(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f), 0.f);
       return;
     }
   }
@@ -720,7 +832,8 @@ static_assert(offsetof(PersistArgs, P) == (sizeof(DevModel) + alignof(FrameParam
               "PersistArgs mirrors the kernarg segment of render_persistent_kernel");
 
 // WLDS (generic instance): the layers' weight fragments are staged in LDS as well, instead of streamed from L2 per pass.
-template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false>
+// U8: the instance that writes the reference's 8-bit Image layout (OUT_U8, store_tile_u8)
+template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false, bool U8 = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
                                                                               float4* __restrict__ rgba0, float* __restrict__ depth0,
                                                                               unsigned long long* __restrict__ counters,
@@ -735,6 +848,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   const ViewBatch& VB = VB0;
   constexpr int PERSIST_WAVES = WAVES;
   constexpr bool GEN = NET == NET_GENERIC;
+  constexpr int OUT8 = U8 ? 1 : 0;
   LdsMap lm = lds_map<NET>(smem, M, wave, PERSIST_WAVES);
   uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(lm.tables);
   float* ctab_lds = reinterpret_cast<float*>(coarse_lds + M.lds_coarse_words);
@@ -838,8 +952,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     if (ls * N + P.shard_index >= s_row + sxn) continue;            // this row holds fewer of the rank's strips
     const int k_local = ls * 4 + (int)bt;
     if (k_local >= V.k_hi || k_local >= P.n_local_tiles) continue;  // padding of the last strip
-    float4* rgba = rgba0 ? rgba0 + (size_t)view * VB.view_stride_px : nullptr;  // (NULL: packed 8-bit output, store_pixel)
-    float* depth = depth0 + (size_t)view * VB.view_stride_px;
+    const OutPlanes op = view_planes<OUT8>(P, rgba0, depth0, view, VB.view_stride_px);
+    float4* rgba = op.rgba;  // (NULL: packed 8-bit output, store_pixel)
+    float* depth = op.depth;
     const int strips_x = (P.tiles_x + 3) >> 2;
     const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
     const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
@@ -848,7 +963,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     const float4 background = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
     // the tile's own 8x8 pixels against the region of interest (render_kernel tests the strip's 32x8)
     if (tx * 8 > V.roi[2] || tx * 8 + 7 < V.roi[0] || ty * 8 > V.roi[3] || ty * 8 + 7 < V.roi[1]) {
-      store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, background, 0.f);
+      store_pixel<OUT8, true>(P, rgba, depth, k_local, lane, px, py, in_img, background, 0.f);
+      if constexpr (U8) if (tx < P.tiles_x) tile_written(P, view, ty, lane);  // (not the padding tiles of a ragged strip)
       continue;
     }
     NRF_STAMP(t_begin);
@@ -963,7 +1079,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
          : (float)(t_begin - t_loop_begin) * 1e-6f;
     }
 #endif
-    store_pixel(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
+    store_pixel<OUT8>(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
+    if constexpr (U8) if (tx < P.tiles_x) tile_written(P, view, ty, lane);
   }
 
 #ifdef NRF_PHASE_TIMING
@@ -981,21 +1098,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   }
 #endif
   // ---- the tiles the queue does not hold are background: a static sweep, one tile per wave and step
-  {
+  // (skip_outside: the caller fills those rows of the frame itself, nrf_api.hip host frames)
+  if (!P.skip_outside) {
     const float4 background = make_float4(P.bg_color, P.bg_color, P.bg_color, 0.f);
     const int n_waves = (int)gridDim.x * PERSIST_WAVES;
     const int strips_x = (P.tiles_x + 3) >> 2;
     for (int view = 0; view < VB.n_views; ++view) {
       const ViewParams& V = VB.v[view];
-      float4* rgba = rgba0 ? rgba0 + (size_t)view * VB.view_stride_px : nullptr;
-      float* depth = depth0 + (size_t)view * VB.view_stride_px;
+      const OutPlanes op = view_planes<OUT8>(P, rgba0, depth0, view, VB.view_stride_px);
+      float4* rgba = op.rgba;
+      float* depth = op.depth;
       const int outside = P.n_local_tiles - (min(V.k_hi, P.n_local_tiles) - V.k_lo);  // tiles before k_lo and from k_hi on
       for (int i = (int)blockIdx.x * PERSIST_WAVES + wave; i < outside; i += n_waves) {
         const int k_local = i < V.k_lo ? i : i + (min(V.k_hi, P.n_local_tiles) - V.k_lo);
         const int strip = (k_local >> 2) * P.shard_count + P.shard_index;
         const int tx = (strip % strips_x) * 4 + (k_local & 3), ty = strip / strips_x;
         const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-        store_pixel(P, rgba, depth, k_local, lane, px, py, px < P.W && py < P.H, background, 0.f);
+        store_pixel<OUT8, true>(P, rgba, depth, k_local, lane, px, py, px < P.W && py < P.H, background, 0.f);
       }
     }
   }
@@ -1498,12 +1617,17 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     int eb = 0;
     const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
     const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+#define NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, O8)                                                                        \
+  do {                                                                                                                   \
+    e = allow_lds(render_persistent_kernel<G, U, WV, WL, O8>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                                                       \
+    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL, O8>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,        \
+                       (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
+  } while (0)
 #define NRF_LAUNCH_PERSISTENT_W(G, U, WV, WL)                                                                             \
   do {                                                                                                                   \
-    e = allow_lds(render_persistent_kernel<G, U, WV, WL>, lds);                                                          \
-    if (e != hipSuccess) return e;                                                                                       \
-    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,            \
-                       (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
+    if (P.out_mode == OUT_U8) NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, true);                                               \
+    else NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, false);                                                                   \
   } while (0)
 #define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G), false)
     if (M.generic) {  // (the generic instance has one march form)
@@ -1522,6 +1646,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     }
 #undef NRF_LAUNCH_PERSISTENT
 #undef NRF_LAUNCH_PERSISTENT_W
+#undef NRF_LAUNCH_PERSISTENT_O
     return hipGetLastError();
   }
   const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
@@ -1682,6 +1807,55 @@ hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(quantize_rgbd8_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float4*)rgba, (const float*)depth, (size_t)n,
                      (uint32_t*)out);
+  return hipGetLastError();
+}
+
+// gathered packed pixels [shard][view][tiles_per_shard][64] (r | g << 8 | b << 16 | depth << 24, what the members of a device
+// group render with nrf_bind_output_rgbd8) -> the reference's host Image layout: rgb u8 [view][H][W][3], depth u8 [view][H][W].
+// One thread per 4 horizontally adjacent pixels (they lie in one tile row: 16 contiguous bytes of the shard) when the
+// width is a multiple of 4: three dword stores of rgb and one of depth; else one thread per pixel with byte stores.
+__global__ __launch_bounds__(256) void untile_rgbd8_u8_kernel(const uint32_t* __restrict__ gathered, int shard_count, int tiles_per_shard,
+                                                              int W, int H, int tiles_x, int n_views, unsigned char* __restrict__ rgb8,
+                                                              unsigned char* __restrict__ depth8) {
+  const size_t frame = (size_t)W * H;
+  const int strips_x = (tiles_x + 3) >> 2;
+  auto src_of = [&](int view, int px, int py) {
+    const int tx = px >> 3, ty = py >> 3;
+    const int strip = ty * strips_x + (tx >> 2);
+    const int shard = strip % shard_count, k = (strip / shard_count) * 4 + (tx & 3);
+    return gathered + (((size_t)shard * n_views + view) * tiles_per_shard + k) * 64 + (py & 7) * 8 + (px & 7);
+  };
+  if ((W & 3) == 0) {
+    const size_t quads = frame / 4, total = quads * (size_t)n_views;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int view = (int)(i / quads);
+      const size_t p = (i - (size_t)view * quads) * 4;
+      const uint4 v = *reinterpret_cast<const uint4*>(src_of(view, (int)(p % W), (int)(p / W)));
+      uint32_t* o = reinterpret_cast<uint32_t*>(rgb8 + ((size_t)view * frame + p) * 3);
+      o[0] = (v.x & 0xffffffu) | (v.y << 24);
+      o[1] = ((v.y & 0xffffffu) >> 8) | (v.z << 16);
+      o[2] = ((v.z & 0xffffffu) >> 16) | (v.w << 8);
+      *reinterpret_cast<uint32_t*>(depth8 + (size_t)view * frame + p) = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+    }
+  } else {
+    const size_t total = frame * (size_t)n_views;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int view = (int)(i / frame);
+      const size_t p = i - (size_t)view * frame;
+      const uint32_t v = *src_of(view, (int)(p % W), (int)(p / W));
+      rgb8[3 * i] = (unsigned char)(v & 0xffu);
+      rgb8[3 * i + 1] = (unsigned char)((v >> 8) & 0xffu);
+      rgb8[3 * i + 2] = (unsigned char)((v >> 16) & 0xffu);
+      depth8[i] = (unsigned char)(v >> 24);
+    }
+  }
+}
+
+hipError_t launch_untile_rgbd8_u8(const void* gathered, int shard_count, int tiles_per_shard, int W, int H, int n_views, void* rgb8,
+                                  void* depth8, hipStream_t st) {
+  const uint64_t work = (uint64_t)W * H * n_views / ((W & 3) == 0 ? 4 : 1);
+  hipLaunchKernelGGL(untile_rgbd8_u8_kernel, dim3(grid_for(work)), dim3(256), 0, st, (const uint32_t*)gathered, shard_count,
+                     tiles_per_shard, W, H, (W + 7) / 8, n_views, (unsigned char*)rgb8, (unsigned char*)depth8);
   return hipGetLastError();
 }
 

@@ -29,6 +29,8 @@ hipError_t launch_composite(const void* sigmas, const void* rgbs, const void* de
                             void* state, hipStream_t st);
 hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, int n_views, void* out,
                          hipStream_t st);
+hipError_t launch_untile_rgbd8_u8(const void* gathered, int shard_count, int tiles_per_shard, int W, int H, int n_views, void* rgb8,
+                                  void* depth8, hipStream_t st);
 hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n, void* out, hipStream_t st);
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
 int render_lds_bytes();

@@ -50,6 +50,12 @@ void NerfRender::check(int rc, const char* what) const {
   if (rc != NRF_OK) throw std::runtime_error{std::string(what) + ": " + nrf_last_error()};
 }
 
+NerfRender::NerfRender(const std::vector<int>& devices) {
+  if (devices.empty()) throw std::runtime_error{"NerfRender: empty device list"};
+  check(nrf_group_create((int)devices.size(), devices.data(), &m_group), "nrf_group_create");
+  for (int i = 0; i < (int)devices.size(); ++i) m_ctx.push_back(nrf_group_member(m_group, i));
+}
+
 NerfRender::NerfRender(int n_gpus) {
   if (n_gpus < 0) return;  // host-only instance (snapshot tooling / CPU tests): no device context
   if (n_gpus == 0) {
@@ -450,42 +456,55 @@ void NerfRender::reset_network() {
 void NerfRender::set_resolution(Vector2i res) {
   resolution = res;
   if (m_group) check(nrf_group_set_resolution(m_group, res[0], res[1]), "nrf_group_set_resolution");
-  us_image.assign((size_t)res[0] * res[1] * 3, 0);  // nerf_render.cu:232-235
-  us_depth.assign((size_t)res[0] * res[1], 0);
+  // (the reference allocates its host image here, nerf_render.cu:232-235; the pinned host planes of this mirror belong
+  //  to the C ABI's host-frame slots and are sized by the first render)
 }
 
+// render_frame, nerf_render.cu:238-367.  The reference ends with a D2H copy of the float planes and a single-threaded
+// quantise / de-interleave loop per GPU (:345-359); here the kernel writes the 8-bit Image itself and the copy engine
+// moves it into pinned host memory (nrf_group_render_host_u8): the returned pointers are that memory.
 Image NerfRender::render_frame(Camera cam, Matrix4f pos) {
   if (!m_have_network) throw std::runtime_error{"render_frame: no network loaded"};
   const float c4[4] = {cam.fl_x, cam.fl_y, cam.cx, cam.cy};
-  // every member renders its strips concurrently on its own stream; the shards meet on the first device
-  // (the reference's threads + D2H + de-interleave loop, nerf_render.cu:252-362)
-  check(nrf_group_render_views(m_group, 1, c4, pos.m, nullptr), "nrf_group_render_views");
-  check(nrf_group_read_view_u8(m_group, 0, us_image.data(), us_depth.data()), "nrf_group_read_view_u8");
-  return Image(resolution[0], resolution[1], us_image.data(), us_depth.data());
+  nrf_host_frame f{};
+  check(nrf_group_render_host_u8(m_group, 1, c4, pos.m, 0, &f), "nrf_group_render_host_u8");
+  return Image(f.width, f.height, const_cast<unsigned char*>(f.rgb), const_cast<unsigned char*>(f.depth));
+}
+
+int NerfRender::submit_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses, bool rgb_only) {
+  if (!m_have_network) throw std::runtime_error{"render_frames: no network loaded"};
+  if (cams.size() != poses.size()) throw std::runtime_error{"render_frames: cams and poses differ in length"};
+  if (cams.empty()) throw std::runtime_error{"render_frames: no camera"};
+  const int n = (int)cams.size();
+  std::vector<float> c4((size_t)4 * n), p16((size_t)16 * n);
+  for (int v = 0; v < n; ++v) {
+    const float c[4] = {cams[v].fl_x, cams[v].fl_y, cams[v].cx, cams[v].cy};
+    std::memcpy(&c4[4 * (size_t)v], c, sizeof(c));
+    std::memcpy(&p16[16 * (size_t)v], poses[v].m, sizeof(poses[v].m));
+  }
+  int ticket = -1;
+  check(nrf_group_submit_host_u8(m_group, n, c4.data(), p16.data(), rgb_only ? NRF_HOST_RGB_ONLY : 0, &ticket), "nrf_group_submit_host_u8");
+  return ticket;
+}
+
+std::vector<Image> NerfRender::wait_frames(int ticket) {
+  nrf_host_frame f{};
+  check(nrf_group_wait_host_u8(m_group, ticket, &f), "nrf_group_wait_host_u8");
+  m_last_wait_render_ms = f.render_ms;
+  std::vector<Image> out;
+  out.reserve((size_t)f.n_views);
+  for (int v = 0; v < f.n_views; ++v)
+    out.emplace_back(f.width, f.height, const_cast<unsigned char*>(f.rgb) + (size_t)v * f.view_stride_px * 3,
+                     f.depth ? const_cast<unsigned char*>(f.depth) + (size_t)v * f.view_stride_px : nullptr);
+  return out;
 }
 
 std::vector<Image> NerfRender::render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses) {
-  if (!m_have_network) throw std::runtime_error{"render_frames: no network loaded"};
-  if (cams.size() != poses.size()) throw std::runtime_error{"render_frames: cams and poses differ in length"};
-  const int W = resolution[0], H = resolution[1], n = (int)cams.size();
-  const size_t px = (size_t)W * H;
-  m_batch_image.resize(px * 3 * (size_t)n);
-  m_batch_depth.resize(px * (size_t)n);
-  std::vector<Image> out;
-  if (n > 0) {
-    std::vector<float> c4((size_t)4 * n), p16((size_t)16 * n);
-    for (int v = 0; v < n; ++v) {
-      const float c[4] = {cams[v].fl_x, cams[v].fl_y, cams[v].cx, cams[v].cy};
-      std::memcpy(&c4[4 * (size_t)v], c, sizeof(c));
-      std::memcpy(&p16[16 * (size_t)v], poses[v].m, sizeof(poses[v].m));
-    }
-    check(nrf_group_render_views(m_group, n, c4.data(), p16.data(), nullptr), "nrf_group_render_views");
-    for (int v = 0; v < n; ++v)
-      check(nrf_group_read_view_u8(m_group, v, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v),
-            "nrf_group_read_view_u8");
+  if (cams.empty() && poses.empty()) {
+    if (!m_have_network) throw std::runtime_error{"render_frames: no network loaded"};
+    return {};
   }
-  for (int v = 0; v < n; ++v) out.emplace_back(W, H, m_batch_image.data() + px * 3 * v, m_batch_depth.data() + px * v);
-  return out;
+  return wait_frames(submit_frames(cams, poses));
 }
 
 void NerfRender::generate_rays(Camera cam, Matrix4f pos, int threadid) {

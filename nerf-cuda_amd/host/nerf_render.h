@@ -20,7 +20,8 @@ struct Camera {  // reference common.h:68-74
   float fl_x, fl_y, cx, cy;
 };
 
-struct Image {  // reference common.h:76-89; pointers are owned by NerfRender, valid until the next render_frame
+struct Image {  // reference common.h:76-89; pointers are owned by NerfRender (pinned host memory the GPU's copy engine
+                // fills), valid until the second next render call (the reference: until the next render_frame)
   int W, H;
   unsigned char* rgb;    // W * H * 3, row-major
   unsigned char* depth;  // W * H
@@ -49,6 +50,8 @@ class NerfRender {
   // (the reference: one thread per device, D2H copies, host de-interleave, nerf_render.cu:252-362).
   // n_gpus < 0: host-only instance that can load and inspect snapshots but not render.
   explicit NerfRender(int n_gpus = 0);
+  // the same over an explicit device list (e.g. {3}: a single-device renderer on GPU 3, as a render_server worker)
+  explicit NerfRender(const std::vector<int>& devices);
   ~NerfRender();
   NerfRender(const NerfRender&) = delete;
   NerfRender& operator=(const NerfRender&) = delete;
@@ -61,6 +64,13 @@ class NerfRender {
   // Batched form (addition): all views in one launch per NRF_MAX_VIEWS cameras (nrf_render_views); every
   // returned Image equals render_frame of that camera.  The images stay valid until the next render call.
   std::vector<Image> render_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses);
+  // Pipelined form of render_frames (addition): submit_frames starts the render + the copy to host memory and returns
+  // a ticket at once; wait_frames blocks until that batch is in host memory.  Two batches may be in flight, so the
+  // copy (and whatever the caller does with the images) of batch k overlaps the render of batch k + 1; the images of a
+  // ticket stay valid until the second next submit_frames.  rgb_only: Image::depth is nullptr, its plane is not copied.
+  int submit_frames(const std::vector<Camera>& cams, const std::vector<Matrix4f>& poses, bool rgb_only = false);
+  std::vector<Image> wait_frames(int ticket);
+  float last_wait_render_ms() const { return m_last_wait_render_ms; }  // device time of the batch wait_frames returned last
   // device ray buffers of the reference are internal to the fused kernel; this fills host copies
   void generate_rays(Camera cam, Matrix4f pos, int threadid);
   // the density grid from the network (nerf_render.cu:388-429, dead and incomplete in the reference; completed in
@@ -90,8 +100,7 @@ class NerfRender {
   bool m_have_snapshot = false, m_have_network = false;
   std::vector<float> m_params, m_density_grid;
   Vector2i resolution;
-  std::vector<unsigned char> us_image, us_depth;
-  std::vector<unsigned char> m_batch_image, m_batch_depth;  // render_frames
+  float m_last_wait_render_ms = 0.f;
   std::vector<float> m_rays_o, m_rays_d;
 };
 

@@ -4,23 +4,37 @@
 // RGB u8, row-major, no header.  Fixed camera {840, 840, 339, 590} and 1080x1080 as in the reference.
 //
 // Unlike the reference (one client at a time, one render_frame per request) any number of clients
-// may be connected: each connection has a reader thread that queues its pose, and ONE render
-// thread takes everything that is queued -- up to SERVER_BATCH_VIEWS (32) poses -- into a single
-// render_frames call (one launch of the fused kernel).  Requests that arrive while a batch renders
-// form the next batch, so batching needs no timer and a lone client sees no added latency
-// (BASELINE config 5: many concurrent camera requests).
+// may be connected.  Each connection has a reader thread that hands its pose to a DISPATCHER, which
+// deals whole requests to per-GPU queues (the queue with the fewest views waiting or rendering:
+// replica-parallel, every GPU holds the model -- BASELINE config 5, SURVEY 8(f)1 "per-GPU queues").
+// Every GPU has ONE worker thread that owns a single-device NerfRender and runs a two-stage
+// pipeline on the two host-frame slots of the C ABI:
+//     take up to SERVER_BATCH_VIEWS (64) queued poses -> submit_frames (one launch of the fused kernel + an
+//     asynchronous copy of the 8-bit images into pinned host memory) -> ONLY THEN wait for the PREVIOUS batch's
+//     copy and wake its clients,
+// so batch k + 1 renders while batch k is copied, handed over and sent: the GPU is never idle while a
+// reply is in flight.  Requests that arrive while a batch renders form the next batch, so batching needs no
+// timer and a lone client sees no added latency.  A reply is sent straight from the pinned slot (no
+// per-request copy); a client that cannot take its image at once gets the remainder copied out, so that a
+// slow consumer never holds a slot (and with it the GPU) for longer than a memcpy.
+// NERF_SERVER_MODE=tile keeps the reference's own multi-GPU form instead: one NerfRender over all devices,
+// every frame tile-sharded over them (NGPU of common.h:91).
+// Devices: NERF_DEVICES="0,1,..." (repeats allowed: "0,0" rehearses two workers on one GPU), else
+// NERF_NGPU=n -> 0..n-1, else device 0.
 // Extended request (optional, same connection): the 4 bytes "NRF1", u32 n, then n x {f32 cam[4] = fl_x, fl_y,
 // cx, cy; f32 pose[16]}; the answer is n images of 3*W*H bytes in request order.  A raw 64-byte pose keeps
 // meaning what it means to the reference's clients.
 // Robustness (the reference relies on sockpp::socket_initializer for the first point and has none of the others):
 //   * a client that disconnects mid-reply must not take the server down: SIGPIPE is ignored and every send uses
 //     MSG_NOSIGNAL;
-//   * an extended request of n views is served in chunks of SERVER_BATCH_VIEWS (one launch each): at most that many
-//     frames are held per connection, whatever n (<= NRF1_MAX_VIEWS_PER_REQUEST) says;
-//   * client threads are detached and counted, nothing grows with the number of connections served;
+//   * an extended request of n views is served in chunks of SERVER_BATCH_VIEWS: a connection never has more than that
+//     many views queued or in flight, whatever n (<= NRF1_MAX_VIEWS_PER_REQUEST) says;
+//   * at most NRF_SERVER_MAX_CLIENTS (default 256) connections are served at a time, further ones are closed at once;
+//     client threads are detached and share ownership of the server state, so none can outlive it;
 //   * NRF_SERVER_BIND=<ipv4> restricts the listening address (default: any, like the reference's acceptor);
-//   * the "QUIT" message (prints the batch statistics and stops the server) is a test hook: it is honoured only
-//     when NRF_SERVER_TEST_HOOKS=1 is set in the server's environment.
+//   * the "QUIT" message (prints the batch statistics and stops the server) and the "STAT" message (answers with one
+//     text line of the same statistics, 256 bytes, zero-padded) are test hooks: honoured only when
+//     NRF_SERVER_TEST_HOOKS=1 is set in the server's environment.
 //   usage: render_server [port=12345] [snapshot=./freality.msgpack] [width height]
 #include <arpa/inet.h>
 #include <csignal>
@@ -30,6 +44,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -69,97 +84,224 @@ static bool write_n(int fd, const void* buf, size_t n) {
 
 namespace {
 
+constexpr uint32_t NRF1_MAX_VIEWS_PER_REQUEST = 4096;
+constexpr uint32_t SERVER_BATCH_VIEWS = 64;  // frames one launch of a worker renders (BASELINE config 5's 64 requests)
+static_assert(SERVER_BATCH_VIEWS <= NRF_MAX_VIEWS, "a batch is one launch");
+
+// A worker's host-frame slot (two per worker, as the C ABI has): how many of its images are still being sent.
+struct SlotUse {
+  std::mutex m;
+  std::condition_variable cv;
+  int readers = 0;
+};
+
 struct Request {
   Camera cam;
   Matrix4f pose;
-  std::vector<unsigned char> rgb;  // filled by the render thread
+  const unsigned char* rgb = nullptr;  // set by the worker: this request's image inside its pinned host-frame slot
+  SlotUse* slot = nullptr;             // released by the client thread once the image has left the slot
   bool done = false, failed = false;
   std::mutex m;
   std::condition_variable cv;
 };
 
-struct Batcher {
+struct Worker {
+  int device = 0;
+  std::unique_ptr<NerfRender> render;
   std::mutex m;
   std::condition_variable cv;
   std::deque<std::shared_ptr<Request>> queue;
-  std::atomic<bool> stop{false};
+  std::atomic<int> load{0};  // views queued or being rendered
+  SlotUse slot[2];
+  std::thread thread;
+  // statistics
   std::atomic<unsigned long> batches{0}, frames{0};
-  std::atomic<int> live_clients{0};
-  bool test_hooks = false;  // NRF_SERVER_TEST_HOOKS=1
+  std::atomic<unsigned long long> gpu_us{0};  // device time of the launches (event-timed, nrf_stats::render_ms)
 };
-constexpr uint32_t NRF1_MAX_VIEWS_PER_REQUEST = 4096;
-constexpr uint32_t SERVER_BATCH_VIEWS = 32;  // frames one launch of the server renders and holds (<= NRF_MAX_VIEWS)
-static_assert(SERVER_BATCH_VIEWS <= NRF_MAX_VIEWS, "a batch is one launch");
 
-// the one thread that owns the renderer
-void render_loop(NerfRender& render, const size_t frame_bytes, Batcher& b) {
-  while (true) {
-    std::vector<std::shared_ptr<Request>> batch;
-    {
-      std::unique_lock<std::mutex> lk(b.m);
-      b.cv.wait(lk, [&] { return b.stop.load() || !b.queue.empty(); });
-      if (b.stop.load() && b.queue.empty()) return;
-      while (!b.queue.empty() && batch.size() < (size_t)SERVER_BATCH_VIEWS) {
-        batch.push_back(b.queue.front());
-        b.queue.pop_front();
-      }
+struct Server {
+  std::vector<std::unique_ptr<Worker>> workers;
+  std::atomic<bool> stop{false};
+  std::atomic<int> live_clients{0};
+  int max_clients = 256;
+  bool test_hooks = false;  // NRF_SERVER_TEST_HOOKS=1
+  size_t frame_bytes = 0;
+  int listen_fd = -1;
+  std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
+
+  std::string stat_line() const {
+    unsigned long b = 0, f = 0;
+    unsigned long long us = 0;
+    for (const auto& w : workers) {
+      b += w->batches.load();
+      f += w->frames.load();
+      us += w->gpu_us.load();
     }
-    bool ok = true;
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "batches %lu frames %lu workers %zu gpu_ms %.3f wall_ms %.3f", b, f, workers.size(), (double)us * 1e-3,
+                  wall_ms);
+    return buf;
+  }
+};
+
+void finish_batch(Worker& w, std::vector<std::shared_ptr<Request>>& batch, int ticket, int slot_index, bool ok) {
+  std::vector<Image> imgs;
+  if (ok) {
     try {
-      std::vector<Camera> cams;
-      std::vector<Matrix4f> poses;
-      for (const auto& r : batch) {
-        cams.push_back(r->cam);
-        poses.push_back(r->pose);
-      }
-      const std::vector<Image> imgs = render.render_frames(cams, poses);
-      for (size_t i = 0; i < batch.size(); ++i) batch[i]->rgb.assign(imgs[i].rgb, imgs[i].rgb + frame_bytes);
+      imgs = w.render->wait_frames(ticket);
+      w.gpu_us += (unsigned long long)(w.render->last_wait_render_ms() * 1e3);
     } catch (const std::exception& e) {
       std::fprintf(stderr, "render error: %s\n", e.what());
       ok = false;
     }
-    b.batches++;
-    b.frames += batch.size();
-    for (const auto& r : batch) {
-      std::lock_guard<std::mutex> lk(r->m);
-      r->done = true;
-      r->failed = !ok;
-      r->cv.notify_one();
+  }
+  SlotUse& su = w.slot[slot_index];
+  if (ok) {
+    std::lock_guard<std::mutex> lk(su.m);
+    su.readers += (int)batch.size();
+  }
+  w.batches++;
+  w.frames += batch.size();
+  w.load -= (int)batch.size();
+  for (size_t i = 0; i < batch.size(); ++i) {
+    Request& r = *batch[i];
+    std::lock_guard<std::mutex> lk(r.m);
+    r.rgb = ok ? imgs[i].rgb : nullptr;
+    r.slot = ok ? &su : nullptr;
+    r.failed = !ok;
+    r.done = true;
+    r.cv.notify_one();
+  }
+  batch.clear();
+}
+
+// the one thread that owns a GPU's renderer: submit batch k + 1, then complete batch k
+void worker_loop(Server& s, Worker& w) {
+  std::vector<std::shared_ptr<Request>> prev, batch;
+  int prev_ticket = -1, prev_slot = 0, next_slot = 0;
+  while (true) {
+    batch.clear();
+    {
+      std::unique_lock<std::mutex> lk(w.m);
+      // with a batch in flight do not wait for more work: finish that one first
+      if (prev.empty()) w.cv.wait(lk, [&] { return s.stop.load() || !w.queue.empty(); });
+      while (!w.queue.empty() && batch.size() < (size_t)SERVER_BATCH_VIEWS) {
+        batch.push_back(w.queue.front());
+        w.queue.pop_front();
+      }
+    }
+    if (batch.empty() && prev.empty()) {
+      if (s.stop.load()) return;
+      continue;
+    }
+    int ticket = -1;
+    bool ok = true;
+    if (!batch.empty()) {
+      // the slot this submit overwrites (the ticket it will return): every image of its last batch must have left it;
+      // after a failed submit the next ticket is not known: both slots
+      for (int si = 0; si < 2; ++si) {
+        if (next_slot >= 0 && si != next_slot) continue;
+        SlotUse& su = w.slot[si];
+        std::unique_lock<std::mutex> lk(su.m);
+        su.cv.wait(lk, [&] { return su.readers == 0; });
+      }
+      try {
+        std::vector<Camera> cams;
+        std::vector<Matrix4f> poses;
+        for (const auto& r : batch) {
+          cams.push_back(r->cam);
+          poses.push_back(r->pose);
+        }
+        ticket = w.render->submit_frames(cams, poses, /*rgb_only=*/true);
+      } catch (const std::exception& e) {
+        std::fprintf(stderr, "render error: %s\n", e.what());
+        ok = false;
+      }
+    }
+    if (!prev.empty()) finish_batch(w, prev, prev_ticket, prev_slot, true);  // batch k: its copy ran under batch k + 1's render
+    if (!batch.empty()) {
+      if (!ok) {
+        finish_batch(w, batch, -1, 0, false);
+        next_slot = -1;
+      } else {
+        prev.swap(batch);
+        prev_ticket = ticket;
+        prev_slot = ticket;  // tickets ARE the slot indices of the C ABI's host frames (0, 1, 0, ...)
+        next_slot = ticket ^ 1;
+      }
     }
   }
 }
 
-std::shared_ptr<Request> submit(Batcher& b, const Camera& cam, const float pose[16]) {
+// the dispatcher: a whole request goes to the GPU with the fewest views waiting or rendering
+std::shared_ptr<Request> submit(Server& s, const Camera& cam, const float pose[16]) {
   auto req = std::make_shared<Request>();
   req->cam = cam;
   for (int i = 0; i < 16; ++i) req->pose.m[i] = pose[i];
+  Worker* best = s.workers[0].get();
+  for (const auto& w : s.workers)
+    if (w->load.load() < best->load.load()) best = w.get();
+  best->load++;
   {
-    std::lock_guard<std::mutex> lk(b.m);
-    b.queue.push_back(req);
+    std::lock_guard<std::mutex> lk(best->m);
+    best->queue.push_back(req);
   }
-  b.cv.notify_one();
+  best->cv.notify_one();
   return req;
 }
 
+// Sends a finished image straight from its pinned slot.  What the socket does not take at once is copied out first, so
+// the slot is released after at most one memcpy.
 bool wait_and_send(int sock, const std::shared_ptr<Request>& req, size_t frame_bytes) {
   {
     std::unique_lock<std::mutex> lk(req->m);
     req->cv.wait(lk, [&] { return req->done; });
   }
-  return !req->failed && write_n(sock, req->rgb.data(), frame_bytes);
+  if (req->failed) return false;
+  const unsigned char* p = req->rgb;
+  size_t left = frame_bytes;
+  bool ok = true;
+  while (left) {
+    const ssize_t r = ::send(sock, p, left, MSG_NOSIGNAL | MSG_DONTWAIT);
+    if (r > 0) {
+      p += r;
+      left -= (size_t)r;
+      continue;
+    }
+    if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) break;  // socket buffer full: finish from a copy
+    ok = false;
+    break;
+  }
+  std::vector<unsigned char> rest;
+  if (ok && left) rest.assign(p, p + left);
+  {
+    std::lock_guard<std::mutex> lk(req->slot->m);
+    if (--req->slot->readers == 0) req->slot->cv.notify_all();
+  }
+  if (ok && left) ok = write_n(sock, rest.data(), rest.size());
+  return ok;
 }
 
-void serve_client(int sock, const std::string peer, const Camera default_cam, const size_t frame_bytes, Batcher& b, int srv) {
+void serve_client(int sock, const std::string peer, const Camera default_cam, std::shared_ptr<Server> sp) {
+  Server& s = *sp;
+  const size_t frame_bytes = s.frame_bytes;
   std::cout << "Received a connection request from " << peer << std::endl;
   float nerf_pos[16] = {0};
   while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
-    if (b.test_hooks && std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {
-      std::printf("\nbatches %lu frames %lu\n", b.batches.load(), b.frames.load());  // one write: other threads print too
+    if (s.test_hooks && std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {
+      std::printf("\n%s\n", s.stat_line().c_str());  // one write: other threads print too
       std::fflush(stdout);
-      b.stop = true;
-      b.cv.notify_all();
-      ::shutdown(srv, SHUT_RDWR);  // wakes the acceptor
+      s.stop = true;
+      for (const auto& w : s.workers) w->cv.notify_all();
+      ::shutdown(s.listen_fd, SHUT_RDWR);  // wakes the acceptor
       break;
+    }
+    if (s.test_hooks && std::memcmp(nerf_pos, "STAT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {
+      char line[256] = {0};
+      std::snprintf(line, sizeof(line), "%s", s.stat_line().c_str());
+      if (!write_n(sock, line, sizeof(line))) break;
+      continue;
     }
     if (std::memcmp(nerf_pos, "NRF1", 4) == 0) {  // extended request: the 64 bytes read so far are its first 64
       uint32_t n = 0;
@@ -170,24 +312,51 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, co
       std::memcpy(body.data(), (const char*)nerf_pos + 8, have < need ? have : need);
       if (need > have && !read_n(sock, (char*)body.data() + have, need - have)) break;
       bool ok = true;
-      // chunks of SERVER_BATCH_VIEWS: every chunk is queued before its first wait (one launch), sent, and freed before
-      // the next one is queued -- a connection never holds more than SERVER_BATCH_VIEWS rendered frames
+      // chunks of SERVER_BATCH_VIEWS: every chunk is queued before its first wait, sent, and released before the next one is
+      // queued -- a connection never has more than SERVER_BATCH_VIEWS views queued or in flight
       for (uint32_t first = 0; ok && first < n; first += SERVER_BATCH_VIEWS) {
         std::vector<std::shared_ptr<Request>> reqs;
         for (uint32_t v = first; v < n && v < first + SERVER_BATCH_VIEWS; ++v) {
           const float* r = body.data() + (size_t)v * 20;
-          reqs.push_back(submit(b, Camera{r[0], r[1], r[2], r[3]}, r + 4));
+          reqs.push_back(submit(s, Camera{r[0], r[1], r[2], r[3]}, r + 4));
         }
-        for (const auto& r : reqs) ok = ok && wait_and_send(sock, r, frame_bytes);
+        for (const auto& r : reqs) {
+          if (ok) ok = wait_and_send(sock, r, frame_bytes);
+          else {  // the connection is lost: still wait for the image and give its slot back
+            std::unique_lock<std::mutex> lk(r->m);
+            r->cv.wait(lk, [&] { return r->done; });
+            if (r->slot) {
+              std::lock_guard<std::mutex> lk2(r->slot->m);
+              if (--r->slot->readers == 0) r->slot->cv.notify_all();
+            }
+          }
+        }
       }
       if (!ok) break;
       continue;
     }
-    if (!wait_and_send(sock, submit(b, default_cam, nerf_pos), frame_bytes)) break;
+    if (!wait_and_send(sock, submit(s, default_cam, nerf_pos), frame_bytes)) break;
   }
   std::cout << "Connection closed" << std::endl;
   ::close(sock);
-  b.live_clients--;
+  s.live_clients--;
+}
+
+std::vector<int> device_list() {
+  std::vector<int> devices;
+  if (const char* list = std::getenv("NERF_DEVICES")) {
+    for (const char* p = list; *p;) {
+      devices.push_back(std::atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  if (devices.empty()) {
+    const char* e = std::getenv("NERF_NGPU");
+    const int n = e ? std::max(1, std::atoi(e)) : 1;
+    for (int i = 0; i < n; ++i) devices.push_back(i);
+  }
+  return devices;
 }
 
 }  // namespace
@@ -198,15 +367,31 @@ int main(int argc, char** argv) {
   const std::string config_path = argc > 2 ? argv[2] : "./freality.msgpack";
   const int W = argc > 4 ? std::atoi(argv[3]) : 1080, H = argc > 4 ? std::atoi(argv[4]) : 1080;
   std::signal(SIGPIPE, SIG_IGN);
+  // shared with the (detached) client threads: the state lives until the last of them has let go of it
+  auto server = std::make_shared<Server>();
   try {
-    NerfRender render;
-    render.reload_network_from_file(config_path);  // Init Model
-    const float s = (float)W / 1080.0f;
-    const Camera cam = {840 * s, 840 * s, 339 * s, 590 * s};
-    render.set_resolution(Vector2i(W, H));
-    const size_t frame_bytes = (size_t)3 * W * H;
+    Server& s = *server;
+    const std::vector<int> devices = device_list();
+    const char* mode = std::getenv("NERF_SERVER_MODE");
+    const bool tile_mode = mode && std::strcmp(mode, "tile") == 0;
+    // replica-parallel (default): one single-device renderer + queue per GPU; tile mode: ONE renderer over all devices
+    std::vector<std::vector<int>> groups;
+    if (tile_mode) groups.push_back(devices);
+    else for (int d : devices) groups.push_back({d});
+    for (const auto& g : groups) {
+      auto w = std::make_unique<Worker>();
+      w->device = g[0];
+      w->render = std::make_unique<NerfRender>(g);
+      w->render->reload_network_from_file(config_path);  // Init Model
+      w->render->set_resolution(Vector2i(W, H));
+      s.workers.push_back(std::move(w));
+    }
+    const float sc = (float)W / 1080.0f;
+    const Camera cam = {840 * sc, 840 * sc, 339 * sc, 590 * sc};
+    s.frame_bytes = (size_t)3 * W * H;
 
     const int srv = ::socket(AF_INET, SOCK_STREAM, 0);
+    s.listen_fd = srv;
     int one = 1;
     ::setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     sockaddr_in addr{};
@@ -219,34 +404,43 @@ int main(int argc, char** argv) {
       }
     }
     addr.sin_port = htons((uint16_t)port);
-    if (srv < 0 || ::bind(srv, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(srv, 64) != 0) {
+    if (srv < 0 || ::bind(srv, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(srv, 256) != 0) {
       std::cerr << "Error creating the acceptor: " << std::strerror(errno) << std::endl;
       return 1;
     }
-    Batcher batcher;
     {
       const char* hooks = std::getenv("NRF_SERVER_TEST_HOOKS");
-      batcher.test_hooks = hooks && std::strcmp(hooks, "1") == 0;
+      s.test_hooks = hooks && std::strcmp(hooks, "1") == 0;
+      if (const char* mc = std::getenv("NRF_SERVER_MAX_CLIENTS")) s.max_clients = std::max(1, std::atoi(mc));
     }
-    std::thread renderer(render_loop, std::ref(render), frame_bytes, std::ref(batcher));
-    std::cout << "Awaiting connections on port " << port << "..." << std::endl;
-    while (!batcher.stop.load()) {
+    for (auto& w : s.workers) w->thread = std::thread(worker_loop, std::ref(s), std::ref(*w));
+    s.t_start = std::chrono::steady_clock::now();
+    std::cout << "Awaiting connections on port " << port << " (" << s.workers.size() << (tile_mode ? " tile-sharded renderer" : " GPU queue(s)")
+              << ")..." << std::endl;
+    while (!s.stop.load()) {
       sockaddr_in peer{};
       socklen_t len = sizeof(peer);
       const int sock = ::accept(srv, (sockaddr*)&peer, &len);
       if (sock < 0) {
-        if (batcher.stop.load()) break;
+        if (s.stop.load()) break;
         std::cerr << "Error accepting incoming connection: " << std::strerror(errno) << std::endl;
         continue;
       }
+      if (s.live_clients.load() >= s.max_clients) {  // every connection costs a thread and up to a batch of queued views
+        std::cerr << "connection refused: " << s.max_clients << " clients are being served (NRF_SERVER_MAX_CLIENTS)" << std::endl;
+        ::close(sock);
+        continue;
+      }
       ::setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      // detached: a finished connection leaves nothing behind (readers of still-open connections end with the process)
-      batcher.live_clients++;
-      std::thread(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, frame_bytes, std::ref(batcher), srv).detach();
+      // detached: a finished connection leaves nothing behind; the thread shares ownership of the server state
+      s.live_clients++;
+      std::thread(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, server).detach();
     }
-    batcher.stop = true;
-    batcher.cv.notify_all();
-    renderer.join();
+    s.stop = true;
+    for (auto& w : s.workers) {
+      w->cv.notify_all();
+      if (w->thread.joinable()) w->thread.join();
+    }
     ::close(srv);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -23,7 +23,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
-NRF_ABI_VERSION = 3
+NRF_ABI_VERSION = 4
 NRF_MAX_VIEWS = 128
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
 
@@ -103,6 +103,23 @@ class Frame(C.Structure):
     ]
 
 
+class HostFrame(C.Structure):
+    """nrf_host_frame: 8-bit planes in pinned host memory owned by the context (nrf_submit_host_u8)."""
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("n_views", C.c_int32),
+        ("rgb", C.c_void_p),
+        ("depth", C.c_void_p),
+        ("view_stride_px", C.c_int64),
+        ("render_ms", C.c_float),
+        ("copied_bytes", C.c_uint64),
+    ]
+
+
+NRF_HOST_RGB_ONLY = 1
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_rays", C.c_uint64),
@@ -153,6 +170,17 @@ _SIGS = {
     "nrf_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_bind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_bind_output_rgbd8": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nrf_bind_output_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_submit_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
+    "nrf_wait_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(HostFrame)]),
+    "nrf_render_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(HostFrame)]),
+    "nrf_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_untile_views_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_group_submit_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                           C.POINTER(C.c_int)]),
+    "nrf_group_wait_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(HostFrame)]),
+    "nrf_group_render_host_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                           C.POINTER(HostFrame)]),
     "nrf_render_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Frame)]),
     "nrf_sync": (C.c_int, [C.c_void_p]),
     "nrf_generate_rays_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
@@ -493,6 +521,27 @@ def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def _host_frame_arrays(f: HostFrame, copy: bool):
+    """numpy views (or copies) of a HostFrame's pinned planes: rgb u8 [n][H][W][3], depth u8 [n][H][W] (or None)."""
+    n, h, w, stride = f.n_views, f.height, f.width, int(f.view_stride_px)
+    rgb = np.ctypeslib.as_array(C.cast(f.rgb, C.POINTER(C.c_uint8)), shape=(n, stride * 3))[:, :h * w * 3].reshape(n, h, w, 3)
+    depth = None
+    if f.depth:
+        depth = np.ctypeslib.as_array(C.cast(f.depth, C.POINTER(C.c_uint8)), shape=(n, stride))[:, :h * w].reshape(n, h, w)
+    if copy:
+        rgb = rgb.copy()
+        depth = None if depth is None else depth.copy()
+    return rgb, depth
+
+
+def _views(cams, poses):
+    cams = np.ascontiguousarray(cams, dtype=np.float32).reshape(-1, 4)
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    if len(cams) != len(poses):
+        raise ValueError("cams and poses must have the same length")
+    return cams, poses
+
+
 class NerfHip:
     """One context on one device (nrf_context)."""
 
@@ -575,6 +624,37 @@ class NerfHip:
         """Packed 8-bit target (r | g << 8 | b << 16 | depth << 24 per pixel) of subsequent renders; 0: back to the float planes."""
         _check(self.lib.nrf_bind_output_rgbd8(self.h, C.c_void_p(rgbd8_ptr or 0)))
 
+    def bind_output_u8(self, rgb8_ptr, depth8_ptr):
+        """8-bit planar targets (the reference's Image layout) of subsequent renders; 0, 0: back to the float planes."""
+        _check(self.lib.nrf_bind_output_u8(self.h, C.c_void_p(rgb8_ptr or 0), C.c_void_p(depth8_ptr or 0)))
+
+    # ---- host frames: render_frame's result in (pinned) host memory
+    def submit_host_u8(self, cams, poses, flags: int = 0) -> int:
+        cams, poses = _views(cams, poses)
+        t = C.c_int(-1)
+        _check(self.lib.nrf_submit_host_u8(self.h, len(cams), _fptr(cams), _fptr(poses), int(flags), C.byref(t)))
+        return int(t.value)
+
+    def wait_host_u8(self, ticket: int, copy: bool = True):
+        """(rgb u8 [n][H][W][3], depth u8 [n][H][W] or None); copy=False: views of the context's pinned memory, valid
+        until the second next submit."""
+        f = HostFrame()
+        _check(self.lib.nrf_wait_host_u8(self.h, int(ticket), C.byref(f)))
+        return _host_frame_arrays(f, copy)
+
+    def render_host_u8(self, cams, poses, flags: int = 0, copy: bool = True):
+        cams, poses = _views(cams, poses)
+        f = HostFrame()
+        _check(self.lib.nrf_render_host_u8(self.h, len(cams), _fptr(cams), _fptr(poses), int(flags), C.byref(f)))
+        return _host_frame_arrays(f, copy)
+
+    def render_host_u8_raw(self, cams, poses, flags: int = 0) -> HostFrame:
+        """nrf_render_host_u8 with prepared float32 arrays (cams [n][4], poses [n][16]); returns the HostFrame itself
+        (pointers into the context's pinned memory, render_ms, copied_bytes): the timing form bench.py uses."""
+        f = HostFrame()
+        _check(self.lib.nrf_render_host_u8(self.h, len(cams), _fptr(cams), _fptr(poses), int(flags), C.byref(f)))
+        return f
+
     def read_f32(self):
         rgba = np.empty((self.height, self.width, 4), np.float32)
         depth = np.empty((self.height, self.width), np.float32)
@@ -599,6 +679,14 @@ class NerfHip:
     def quantize_rgbd8(self, rgba_ptr, depth_ptr, n_px, out_ptr, stream=None):
         _check(self.lib.nrf_quantize_rgbd8(self.h, C.c_void_p(rgba_ptr), C.c_void_p(depth_ptr), int(n_px), C.c_void_p(out_ptr),
                                            C.c_void_p(stream or 0)))
+
+    def quantize_u8(self, rgba_ptr, depth_ptr, n_px, rgb8_ptr, depth8_ptr, stream=None):
+        _check(self.lib.nrf_quantize_u8(self.h, C.c_void_p(rgba_ptr), C.c_void_p(depth_ptr), int(n_px), C.c_void_p(rgb8_ptr),
+                                        C.c_void_p(depth8_ptr), C.c_void_p(stream or 0)))
+
+    def untile_views_u8(self, gathered_ptr, shard_count, tiles, n_views, rgb8_ptr, depth8_ptr, stream=None):
+        _check(self.lib.nrf_untile_views_u8(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, n_views, C.c_void_p(rgb8_ptr),
+                                            C.c_void_p(depth8_ptr), C.c_void_p(stream or 0)))
 
     def untile_views(self, gathered_ptr, shard_count, tiles, channels, n_views, out_ptr, stream=None):
         _check(self.lib.nrf_untile_views(self.h, C.c_void_p(gathered_ptr), shard_count, tiles, channels, n_views,
@@ -702,6 +790,23 @@ class NerfGroup:
         _check(self.lib.nrf_group_read_view_u8(self.h, int(view), rgb.ctypes.data, depth.ctypes.data))
         return rgb, depth
 
+    def submit_host_u8(self, cams, poses, flags: int = 0) -> int:
+        cams, poses = _views(cams, poses)
+        t = C.c_int(-1)
+        _check(self.lib.nrf_group_submit_host_u8(self.h, len(cams), _fptr(cams), _fptr(poses), int(flags), C.byref(t)))
+        return int(t.value)
+
+    def wait_host_u8(self, ticket: int, copy: bool = True):
+        f = HostFrame()
+        _check(self.lib.nrf_group_wait_host_u8(self.h, int(ticket), C.byref(f)))
+        return _host_frame_arrays(f, copy)
+
+    def render_host_u8(self, cams, poses, flags: int = 0, copy: bool = True):
+        cams, poses = _views(cams, poses)
+        f = HostFrame()
+        _check(self.lib.nrf_group_render_host_u8(self.h, len(cams), _fptr(cams), _fptr(poses), int(flags), C.byref(f)))
+        return _host_frame_arrays(f, copy)
+
     def stats(self) -> Stats:
         s = Stats()
         _check(self.lib.nrf_group_get_stats(self.h, C.byref(s)))
@@ -771,8 +876,9 @@ class NerfRender:
         """Batched form: one launch per NRF_MAX_VIEWS cameras and device; [(rgb u8, depth u8), ...]."""
         if self.desc is None or self.resolution is None:
             raise RuntimeError("reload_network_from_file and set_resolution must be called first")
-        f = self.group.render_views(cams, poses)
-        return [self.group.read_view_u8(v) for v in range(f.n_views)]
+        # the kernel writes the Image's bytes itself; they arrive in pinned host memory by one asynchronous copy
+        rgb, depth = self.group.render_host_u8(cams, poses)
+        return [(rgb[v], depth[v]) for v in range(len(rgb))]
 
     def close(self):
         self.group.close()

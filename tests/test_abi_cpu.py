@@ -48,8 +48,8 @@ def test_product_library_does_not_link_the_oracle():
 
 def test_struct_layout_matches_header():
     # sizes the C compiler produced for the same structs (guards ctypes field drift)
-    src = '#include "nerfhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(nrf_model_desc),' \
-          ' sizeof(nrf_level_table), sizeof(nrf_options), sizeof(nrf_frame), sizeof(nrf_stats));return 0;}'
+    src = '#include "nerfhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(nrf_model_desc),' \
+          ' sizeof(nrf_level_table), sizeof(nrf_options), sizeof(nrf_frame), sizeof(nrf_stats), sizeof(nrf_host_frame));return 0;}'
     import tempfile, os
     with tempfile.TemporaryDirectory() as td:
         c = Path(td) / "s.c"
@@ -58,7 +58,7 @@ def test_struct_layout_matches_header():
         subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
         sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(nh.ModelDesc), C.sizeof(nh.LevelTable), C.sizeof(nh.Options), C.sizeof(nh.Frame),
-                     C.sizeof(nh.Stats)]
+                     C.sizeof(nh.Stats), C.sizeof(nh.HostFrame)]
 
 
 def test_host_helpers():
