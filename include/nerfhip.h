@@ -181,6 +181,9 @@ typedef struct nrf_stats {
   uint64_t n_network_evals; /* network evaluations including the padding of the
                            16-sample MFMA tiles (>= n_samples)                 */
   float render_ms;      /* device time of the last nrf_render (hipEvents)     */
+  uint64_t n_composited; /* samples that entered a ray's compositing sum: what the reference's own per-ray schedule emits
+                           (n_samples also counts the samples a ray queues behind its terminating one; how many those are
+                           depends on how rays are batched into rounds, this count does not)                           */
 } nrf_stats;
 
 typedef struct nrf_context nrf_context;

@@ -1477,12 +1477,13 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipEventSynchronize(c->ev1));
-  unsigned long long raw[COUNTER_SLOTS * 16], cnt[3] = {0, 0, 0};
+  unsigned long long raw[COUNTER_SLOTS * 16], cnt[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpy(raw, call_slot(c, c->call_index), COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int sl = 0; sl < COUNTER_SLOTS; ++sl) {
     cnt[0] += raw[sl * 16];
     cnt[1] += raw[sl * 16 + 1];
     cnt[2] += raw[sl * 16 + 11];
+    cnt[3] += raw[sl * 16 + 7];
   }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1490,6 +1491,7 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   s->n_samples = cnt[0];
   s->n_rounds = cnt[1];
   s->n_network_evals = cnt[2];
+  s->n_composited = cnt[3];
   s->render_ms = ms;
   return NRF_OK;
 }

@@ -409,6 +409,7 @@ int nrf_group_get_stats(nrf_group* g, nrf_stats* s) {
     s->n_samples += m.n_samples;
     s->n_rounds += m.n_rounds;
     s->n_network_evals += m.n_network_evals;
+    s->n_composited += m.n_composited;
     if (m.render_ms > s->render_ms) s->render_ms = m.render_ms;  // members run concurrently
   }
   return NRF_OK;

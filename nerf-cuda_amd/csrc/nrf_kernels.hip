@@ -69,6 +69,15 @@ __device__ __forceinline__ unsigned long long stamp() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+// the device-wide constant-rate counter (100 MHz): s_memtime counts core cycles per clock domain, of which a chip has dozens --
+// stamps of different compute units are only comparable on this one
+__device__ __forceinline__ unsigned long long stamp_rt() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
 #define NRF_STAMP(var) const unsigned long long var = stamp()
 #define NRF_ACC(acc, a, b) acc += (b) - (a)
 #else
@@ -323,17 +332,18 @@ template <typename T>
 __device__ __forceinline__ void store_through(T* p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// Progress reporting (FrameParams::prog_*): called by the whole wave after the stores of one tile of strip row `row` of
-// view `view`.  The wave waits for the acknowledgement of its (write-through) stores, then counts the tile; the wave
-// that counts the row's last tile tells the host (one store into pinned memory).  Every other wave of the row had its
-// stores acknowledged before it counted, so whoever sees the flag may read the row's bytes from memory.
-__device__ __forceinline__ void tile_written(const FrameParams& P, int view, int row, int lane) {
+// Progress reporting (FrameParams::prog_*): called by the whole wave after it has stored `count` of the 64 pixels of a
+// tile of strip row `row` of view `view` (a tile whose rays were split over several waves is reported in parts).  The wave
+// waits for the acknowledgement of its (write-through) stores, then adds its pixels to the row's count; the wave that
+// completes the row tells the host (one store into pinned memory).  Every other wave of the row had its stores
+// acknowledged before it counted, so whoever sees the flag may read the row's bytes from memory.
+__device__ __forceinline__ void tile_written(const FrameParams& P, int view, int row, int lane, unsigned count = 64u) {
   if (P.prog_done == nullptr) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) {
     const size_t i = (size_t)view * P.tiles_y + row;
-    const unsigned old = atomicAdd(P.prog_done + i, 1u);
-    if (old + 1u == (unsigned)P.tiles_x) __hip_atomic_store(P.prog_flags + i, (unsigned)P.prog_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned old = atomicAdd(P.prog_done + i, count);
+    if (old + count == 64u * (unsigned)P.tiles_x) __hip_atomic_store(P.prog_flags + i, (unsigned)P.prog_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 // OUT_U8, one 8x8 tile by one whole wave (every lane active).  A tile row is 24 rgb bytes and 8 depth bytes: for a tile
@@ -416,12 +426,62 @@ __device__ __forceinline__ void store_pixel(const FrameParams& P, float4* rgba, 
   }
 }
 
+// One pixel by its index in the view's planes (row-major: py * W + px; a shard's tile-major buffer: local tile * 64 + lane):
+// the store of a tile whose rays were split over several waves (tail splitting, below), lane by lane.
+template <int OUT8>
+__device__ __forceinline__ void store_ray_pixel(const FrameParams& P, float4* rgba, float* depth, uint32_t idx, float4 color, float dn) {
+  if (OUT8 == 1 || (OUT8 < 0 && P.out_mode == OUT_U8)) {
+    const uint32_t v = pack_rgbd8(color, dn);
+    unsigned char* rgb8 = reinterpret_cast<unsigned char*>(rgba);
+    unsigned char* depth8 = reinterpret_cast<unsigned char*>(depth);
+    store_through(rgb8 + 3 * (size_t)idx, (unsigned char)(v & 0xffu));
+    store_through(rgb8 + 3 * (size_t)idx + 1, (unsigned char)((v >> 8) & 0xffu));
+    store_through(rgb8 + 3 * (size_t)idx + 2, (unsigned char)((v >> 16) & 0xffu));
+    store_through(depth8 + idx, (unsigned char)(v >> 24));
+    return;
+  }
+  if constexpr (OUT8 == 1) return;
+  if (P.out_mode == OUT_RGBD8) {
+    reinterpret_cast<uint32_t*>(depth)[idx] = pack_rgbd8(color, dn);
+  } else {
+    rgba[idx] = color;
+    depth[idx] = dn;
+  }
+}
+
+// ---- tail splitting (persistent kernel) ----
+// One 8x8 tile is one wave's work for its whole life, and the heaviest tiles of a frame are ~1.7 M cycles of strictly
+// sequential rounds: a frame rendered alone ends with a handful of waves finishing such tiles while the other 4 000 have
+// nothing left to do (1.05 ms for one 1080p view against 0.80 ms per view in batches).  Per-ray semantics do not depend on
+// which wave evaluates a ray, so a wave that finds the work queues empty offers itself to the waves of ITS OWN workgroup
+// that are still rendering: it sets its bit in `idle_mask` and waits for mail.  A rendering wave looks at the mask at the
+// top of every round; if a helper is waiting and at least two of its rays are alive, it claims the helper (clears its
+// bit), writes the state of every other live ray into the helper's -- idle -- LDS block, posts the count in the helper's
+// mail word and goes on with the rays it kept.  The helper rebuilds the rays (direction encoding included), runs the same
+// tile_rounds on them -- donating again if more helpers wait -- stores their pixels one by one and offers itself again.
+// `busy` counts the waves that may still produce work (rendering waves, plus a helper from the moment it is claimed):
+// a waiting helper leaves when it is zero -- nobody is left who could send mail -- so every wave ends.
+struct HelpLds {
+  unsigned idle_mask;  // bit w: wave w of the workgroup waits for rays
+  int busy;            // waves of the workgroup that are rendering (or about to: claimed helpers)
+  unsigned mail[16];   // wave w's mail word: 0 = none, else 0x80000000 | view << 8 | rays (1..32)
+};
+enum : int { HELP_PIX = 0, HELP_D0, HELP_D1, HELP_D2, HELP_NEAR, HELP_FAR, HELP_FAR_M, HELP_T, HELP_TC, HELP_WS, HELP_DEP, HELP_CR, HELP_CG,
+             HELP_CB, HELP_NSAMP, HELP_FIELDS };  // the mailbox: uint32 [HELP_FIELDS][32] in the helper's WaveLds
+struct HelpArgs {
+  HelpLds* hl;
+  void* wave_blocks;  // WaveLds of wave 0 of the workgroup (the blocks are contiguous)
+  int view;
+};
+
 // What a ray has composited so far, and a wave's statistics (both live in registers).
 struct TileAcc {
   float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
 };
 struct TileStats {
   unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;  // slots: 16-sample MFMA tiles evaluated x 16 (padding included)
+  unsigned n_composited = 0;  // samples that reached a ray's compositing sum (= what the reference's per-ray schedule emits: the
+                              // samples a ray queues behind its terminating one are evaluated -- n_samples -- but never used)
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
   unsigned n_lane_trips = 0, n_wave_iters = 0;
@@ -430,25 +490,67 @@ struct TileStats {
 
 // The rounds of one 8x8 tile (one wave, no workgroup barrier inside): march -> network -> compositing until no ray
 // of the tile is alive.  t / tc / alive: the rays' state after ray generation and the visibility walk.
-template <int NET, bool COARSE_LDS, int MARCH>
+// acc: in = what the rays have composited before (zero for a fresh tile), out = after their last round.
+// HELP (persistent kernel): tail splitting -- ha names the workgroup's HelpLds; pix_idx / near / far travel with a ray that
+// is handed to a helper; *given = the lane's ray was handed over (its pixel is the helper's to store).
+template <int NET, bool COARSE_LDS, int MARCH, bool HELP = false>
 __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams& P, const MarchConst& mc, const LdsMap& lm,
                                             const uint32_t* coarse_lds, const float* ctab_lds, int lane, const float (&o)[3],
                                             const float (&d)[3], float rdx, float rdy, float rdz, int sx, int sy, int sz,
                                             float far_m, float t_skip, float t, float tc, bool alive, TileAcc& acc,
-                                            TileStats& ts) {
+                                            TileStats& ts, int n_ray_samples = 0, const HelpArgs* ha = nullptr, uint32_t pix_idx = 0u,
+                                            float near = 0.f, float far = 0.f, bool* given_out = nullptr) {
   const uint4* wl = lm.wl;
   const LevelParams* lvs = lm.lvs;
   WaveLds* W = lm.W;
-  float ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-  int n_ray_samples = 0;
+  float ws = acc.ws, dep = acc.dep, cr = acc.cr, cg = acc.cg, cb = acc.cb;
+  bool given = false;
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_march = 0, c_net = 0, c_comp = 0;
   unsigned n_lane_trips = 0, n_wave_iters = 0;
 #endif
   unsigned n_samples = 0, n_rounds = 0, n_tile_slots = 0;
+  unsigned n_comp = 0;  // per lane
 
   while (true) {
-    if (__ballot(alive) == 0ull) break;
+    const unsigned long long alive_mask = __ballot(alive);
+    if (alive_mask == 0ull) break;
+    if constexpr (HELP) {
+      // ---- tail splitting: a helper of this workgroup is waiting -> it gets every other live ray
+      if (__popcll(alive_mask) >= 2) {
+        HelpLds* hl = ha->hl;
+        const unsigned im = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&hl->idle_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (im != 0u) {
+          const int hw = __builtin_ctz(im);
+          unsigned old = 0u;
+          if (lane == 0) old = __hip_atomic_fetch_and(&hl->idle_mask, ~(1u << hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+          if (old & (1u << hw)) {  // claimed (another wave may have been faster)
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(alive_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)alive_mask, 0u));
+            const bool give = alive && (rank & 1);
+            const unsigned long long gm = __ballot(give);
+            const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
+            uint32_t* mb = reinterpret_cast<uint32_t*>(reinterpret_cast<WaveLds*>(ha->wave_blocks) + hw);
+            if (give) {
+              auto put = [&](int f, float v) { mb[f * 32 + slot] = __builtin_bit_cast(uint32_t, v); };
+              mb[HELP_PIX * 32 + slot] = pix_idx;
+              put(HELP_D0, d[0]); put(HELP_D1, d[1]); put(HELP_D2, d[2]);
+              put(HELP_NEAR, near); put(HELP_FAR, far); put(HELP_FAR_M, far_m);
+              put(HELP_T, t); put(HELP_TC, tc);
+              put(HELP_WS, ws); put(HELP_DEP, dep); put(HELP_CR, cr); put(HELP_CG, cg); put(HELP_CB, cb);
+              mb[HELP_NSAMP * 32 + slot] = (uint32_t)n_ray_samples;
+            }
+            if (lane == 0) {
+              __hip_atomic_fetch_add(&hl->busy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(&hl->mail[hw], 0x80000000u | ((unsigned)ha->view << 8) | (unsigned)__popcll(gm), __ATOMIC_RELEASE,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);  // (release: after the mailbox writes of every lane -- LDS operations of a wave execute in order)
+            }
+            alive = alive && !give;
+            given = given || give;
+          }
+        }
+      }
+    }
     NRF_STAMP(t0);
     // ---- march: ballot/mbcnt compaction of the found samples, k-major, into the wave's LDS slots
     unsigned long long slots = 0ull;
@@ -522,6 +624,7 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
         cr += wgt * so.x;
         cg += wgt * so.y;
         cb += wgt * so.z;
+        n_comp++;
         // `T < 1e-4` against a double literal: true exactly for T <= 9.99999974737875e-05f
         if (T <= 9.99999974737875e-05f) { terminated = true; break; }
       }
@@ -539,6 +642,9 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
   }
 
   acc.ws = ws; acc.dep = dep; acc.cr = cr; acc.cg = cg; acc.cb = cb;
+  if constexpr (HELP) *given_out = given;
+  for (int o = 32; o; o >>= 1) n_comp += __shfl_xor(n_comp, o);
+  ts.n_composited += n_comp;
   ts.n_samples += n_samples;
   ts.n_rounds += n_rounds;
   ts.n_tile_slots += n_tile_slots;
@@ -751,6 +857,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
                                       alive, acc, ts);
   const float ws = acc.ws, dep = acc.dep, cr = acc.cr, cg = acc.cg, cb = acc.cb;
   const unsigned n_samples = ts.n_samples, n_rounds = ts.n_rounds, n_tile_slots = ts.n_tile_slots;
+  const unsigned n_composited = ts.n_composited;
 #ifdef NRF_PHASE_TIMING
   const unsigned long long c_march = ts.c_march, c_net = ts.c_net, c_comp = ts.c_comp;
   const unsigned n_lane_trips = ts.n_lane_trips, n_wave_iters = ts.n_wave_iters;
@@ -768,6 +875,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
     atomicAdd(&counters[0], (unsigned long long)n_samples);
     atomicAdd(&counters[1], (unsigned long long)n_rounds);
     atomicAdd(&counters[11], (unsigned long long)n_tile_slots);
+    atomicAdd(&counters[7], (unsigned long long)n_composited);
   }
 #ifdef NRF_PHASE_TIMING
   if (lane == 0) {
@@ -800,6 +908,34 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 #endif
 }
 
+// Direction encoding of one live ray into the wave's LDS block (what the network phase reads per sample).
+template <int NET>
+__device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& lm, int lane, const float (&d)[3]) {
+  float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
+  float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
+  float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
+  if constexpr (NET == NET_GENERIC) {
+    lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
+    lm.gen.rayd[3 * lane + 1] = u1;
+    lm.gen.rayd[3 * lane + 2] = u2;
+  } else {
+    half_t e[16];
+    encode_dir16(M, u0, u1, u2, e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      half2_t h;
+      h.x = e[2 * j];
+      h.y = e[2 * j + 1];
+      lm.W->dirf[lane][j] = h2_bits(h);
+    }
+    if constexpr (NET == NET_WIDE) {  // the entries beyond the first sixteen are evaluated per sample (dir_entries8)
+      lm.gen.rayd[3 * lane] = u0;
+      lm.gen.rayd[3 * lane + 1] = u1;
+      lm.gen.rayd[3 * lane + 2] = u2;
+    }
+  }
+}
+
 // ---------------------------------------------------- the persistent form ----
 // The same tile program as render_kernel with the scheduling turned inside out: ONE workgroup of persist_waves waves per
 // CU stays for the whole launch, stages the weight fragments, the level table and every march table (coarse + dilated
@@ -816,7 +952,8 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
 __host__ __device__ constexpr int persist_waves(int net) { return net == NET_HOT ? 16 : 12; }
-constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4;  // q_begin of every view + the total; the workgroup's block counter
+constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80;  // q_begin of every view + the total; the workgroup's block counter; HelpLds
+static_assert(sizeof(HelpLds) <= 80, "HelpLds lives behind the scheduler word");
 
 // The kernel's by-value arguments as they lie in the kernarg segment (the tile loop re-reads them per tile through a
 // pointer the compiler cannot see through: otherwise every field of the three structs is hoisted out of the loop and
@@ -855,10 +992,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   uint32_t* dil_lds = reinterpret_cast<uint32_t*>(ctab_lds + M.lds_ctab_floats);
   int* q_lds = reinterpret_cast<int*>(dil_lds + M.lds_dilated_words);
   unsigned* sched = reinterpret_cast<unsigned*>(q_lds + MAX_VIEWS + 1);
+  HelpLds* hl = reinterpret_cast<HelpLds*>(sched + 1);
+  static_assert(WAVES <= 16, "HelpLds::mail / idle_mask hold 16 waves");
   // ---- staged once per workgroup (= once per CU and launch)
   if constexpr (!GEN) stage_fragments<NET>(M, lm.wl);
   if constexpr (GEN && WLDS) {  // the generic instance's fragments, behind everything else (16-byte aligned)
-    uint4* w_lds = reinterpret_cast<uint4*>(smem + ((reinterpret_cast<unsigned char*>(sched + 1) - smem + 15) & ~(size_t)15));
+    uint4* w_lds = reinterpret_cast<uint4*>(smem + ((reinterpret_cast<unsigned char*>(hl + 1) - smem + 15) & ~(size_t)15));
     for (uint32_t i = threadIdx.x; i < M.gen_frag_bytes / 16u; i += blockDim.x) w_lds[i] = M.wfrag[i];
     lm.gen.wfrag = w_lds;
   }
@@ -871,6 +1010,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     q_lds[v] = v < VB.n_views ? VB.v[v].q_begin : VB.q_total;
   }
   if (threadIdx.x == 0) *sched = (0xfffffeu << 5) | 4u;  // no strip yet: the first wave to ask fetches one
+  if (threadIdx.x == 0) {
+    hl->idle_mask = 0u;
+    hl->busy = PERSIST_WAVES;
+  }
+  if (threadIdx.x < 16) hl->mail[threadIdx.x] = 0u;
   __syncthreads();
 
   const MarchConst mc = march_const(M, P.dt_gamma);
@@ -892,6 +1036,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   NRF_STAMP(t_loop_begin);
 #ifdef NRF_PHASE_TIMING
   unsigned long long c_sched = 0;
+  const unsigned long long t_rt_begin = stamp_rt();
 #endif
   while (true) {
     NRF_STAMP(t_sched0);
@@ -1023,36 +1168,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       if (any) t_skip = first;
     }
     TileAcc acc;
+    bool given = false;  // tail splitting: this lane's ray went to a helper wave, which stores its pixel
+    const uint32_t pix_idx = P.tile_major ? (uint32_t)k_local * 64u + (uint32_t)lane : (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
     if (__ballot(alive) != 0ull) {
-      if (alive) {  // direction encoding of the rays that will evaluate the network
-        float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
-        float u1 = 0.5f * d[1]; u1 = u1 + 0.5f;
-        float u2 = 0.5f * d[2]; u2 = u2 + 0.5f;
-        if constexpr (GEN) {
-          lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
-          lm.gen.rayd[3 * lane + 1] = u1;
-          lm.gen.rayd[3 * lane + 2] = u2;
-        } else {
-          half_t e[16];
-          encode_dir16(M, u0, u1, u2, e);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            half2_t h;
-            h.x = e[2 * j];
-            h.y = e[2 * j + 1];
-            lm.W->dirf[lane][j] = h2_bits(h);
-          }
-          if constexpr (NET == NET_WIDE) {  // the entries beyond the first sixteen are evaluated per sample (dir_entries8)
-            lm.gen.rayd[3 * lane] = u0;
-            lm.gen.rayd[3 * lane + 1] = u1;
-            lm.gen.rayd[3 * lane + 2] = u2;
-          }
-        }
-      }
+      if (alive) encode_ray_dir<NET>(M, lm, lane, d);  // direction encoding of the rays that will evaluate the network
       wave_sync();
       NRF_STAMP(t_setup_done);
-      tile_rounds<NET, true, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
-                                        alive, acc, ts);
+      const HelpArgs ha = {hl, lm.W - wave, view};
+      tile_rounds<NET, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+                                              alive, acc, ts, 0, &ha, pix_idx, near, far, &given);
 #ifdef NRF_PHASE_TIMING
       if (lane == 0) {
         NRF_STAMP(t_end);
@@ -1079,8 +1203,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
          : (float)(t_begin - t_loop_begin) * 1e-6f;
     }
 #endif
-    store_pixel<OUT8>(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
-    if constexpr (U8) if (tx < P.tiles_x) tile_written(P, view, ty, lane);
+    const unsigned long long given_mask = __ballot(given);
+    if (given_mask == 0ull) {
+      store_pixel<OUT8>(P, rgba, depth, k_local, lane, px, py, in_img, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
+    } else if (!given && (in_img || P.tile_major)) {  // a split tile: the rays this wave kept, lane by lane
+      const bool pad = !in_img;  // (padding pixels of a shard's tile-major buffer are zero)
+      store_ray_pixel<OUT8>(P, rgba, depth, pix_idx, pad ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws),
+                            pad ? 0.f : dn);
+    }
+    if constexpr (U8) if (tx < P.tiles_x) tile_written(P, view, ty, lane, 64u - (unsigned)__popcll(given_mask));
   }
 
 #ifdef NRF_PHASE_TIMING
@@ -1093,9 +1224,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     atomicAdd(&cs[15], c_sched);
     // absolute entry / exit stamps of every wave (nrf_debug_wave_times)
     unsigned long long* wt = counters + COUNTER_SLOTS * 16 + 16 + 2 * ((size_t)blockIdx.x * PERSIST_WAVES + wave);
-    wt[0] = t_loop_begin;
-    wt[1] = t_loop_end;
+    wt[0] = t_rt_begin;
+    wt[1] = stamp_rt();  // (replaced below by the end of the wave's helping)
   }
+  unsigned n_helped = 0;
 #endif
   // ---- the tiles the queue does not hold are background: a static sweep, one tile per wave and step
   // (skip_outside: the caller fills those rows of the frame itself, nrf_api.hip host frames)
@@ -1118,11 +1250,82 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       }
     }
   }
+  // ---- tail splitting: this wave has nothing left of its own -- it takes rays off the waves of its workgroup that are
+  // still rendering (HelpLds above), until none of them is
+  while (true) {
+    if (lane == 0) {
+      __hip_atomic_fetch_add(&hl->busy, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_or(&hl->idle_mask, 1u << wave, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unsigned mail = 0u;
+    while (true) {
+      mail = __hip_atomic_load(&hl->mail[wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (mail != 0u) break;
+      if (__hip_atomic_load(&hl->busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= 0) break;  // nobody is left who could send any
+      __builtin_amdgcn_s_sleep(8);
+    }
+    mail = (unsigned)__builtin_amdgcn_readfirstlane((int)mail);
+    if (mail == 0u) break;
+    const int n_rays = (int)(mail & 0xffu), view = (int)((mail >> 8) & 0xffu);
+    const uint32_t* mb = reinterpret_cast<const uint32_t*>(lm.W);
+    const bool mine = lane < n_rays;
+    const int ml = mine ? lane : 0;
+    auto getf = [&](int f) { return __builtin_bit_cast(float, mb[f * 32 + ml]); };
+    const uint32_t pix_idx = mb[HELP_PIX * 32 + ml];
+    const float d[3] = {getf(HELP_D0), getf(HELP_D1), getf(HELP_D2)};
+    const float near = getf(HELP_NEAR), far = getf(HELP_FAR), far_m = getf(HELP_FAR_M);
+    const float t = getf(HELP_T), tc = getf(HELP_TC);
+    TileAcc acc;
+    acc.ws = getf(HELP_WS); acc.dep = getf(HELP_DEP); acc.cr = getf(HELP_CR); acc.cg = getf(HELP_CG); acc.cb = getf(HELP_CB);
+    const int n_ray_samples = (int)mb[HELP_NSAMP * 32 + ml];
+    wave_sync();  // every lane has read its ray: the block is this wave's own again
+    if (lane == 0) __hip_atomic_store(&hl->mail[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" : "+s"(ka));
+    const DevModel& M = *(const DevModel*)&ka->M;
+    const FrameParams& P = *(const FrameParams*)&ka->P;
+    const ViewBatch& VB = *(const ViewBatch*)&ka->VB;
+    const ViewParams& V = VB.v[view];
+    const float o[3] = {V.org[0], V.org[1], V.org[2]};
+    const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+    const int sx = __builtin_signbitf(d[0]) ? 0 : 1;
+    const int sy = __builtin_signbitf(d[1]) ? 0 : 1;
+    const int sz = __builtin_signbitf(d[2]) ? 0 : 1;
+    if (mine) encode_ray_dir<NET>(M, lm, lane, d);
+    wave_sync();
+    bool given = false;
+    const HelpArgs ha = {hl, lm.W - wave, view};
+    // (t_skip: the occupancy lookups it would skip are of cells known to be empty -- looking them up changes nothing)
+    tile_rounds<NET, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, -3.402823466e+38f, t, tc,
+                                            mine, acc, ts, n_ray_samples, &ha, pix_idx, near, far, &given);
+    const OutPlanes op = view_planes<OUT8>(P, rgba0, depth0, view, VB.view_stride_px);
+    const bool store = mine && !given;
+    if (store) {  // get_image_and_depth, as in the tile loop
+      const float bgw = (1 - acc.ws) * P.bg_color;
+      const float span = far - near;
+      const float dn = span > 0.0f ? fmaxf(acc.dep - near, 0.0f) / span : 0.0f;
+      store_ray_pixel<OUT8>(P, op.rgba, op.depth, pix_idx, make_float4(acc.cr + bgw, acc.cg + bgw, acc.cb + bgw, acc.ws), dn);
+    }
+    if constexpr (U8) {  // (8-bit planes are row-major: the strip row of the rays' tile follows from a pixel index)
+      const int row = __builtin_amdgcn_readfirstlane((int)(pix_idx / (uint32_t)P.W)) >> 3;
+      tile_written(P, view, row, lane, (unsigned)__popcll(__ballot(store)));
+    }
+#ifdef NRF_PHASE_TIMING
+    n_helped += (unsigned)n_rays;
+#endif
+  }
+#ifdef NRF_PHASE_TIMING
+  if (lane == 0) {  // when the wave left for good, and how many rays it took off others: nrf_debug_wave_times slot 1, counters[2 .. ] unchanged
+    const unsigned long long t_help_end = stamp_rt();
+    unsigned long long* wt = counters + COUNTER_SLOTS * 16 + 16 + 2 * ((size_t)blockIdx.x * PERSIST_WAVES + wave);
+    wt[1] = (t_help_end << 8) | (unsigned long long)(n_helped > 255u ? 255u : n_helped);  // low byte: rays helped with (capped)
+  }
+#endif
   counters += (blockIdx.x % COUNTER_SLOTS) * 16;
   if (lane == 0 && ts.n_rounds != 0) {
     atomicAdd(&counters[0], (unsigned long long)ts.n_samples);
     atomicAdd(&counters[1], (unsigned long long)ts.n_rounds);
     atomicAdd(&counters[11], (unsigned long long)ts.n_tile_slots);
+    atomicAdd(&counters[7], (unsigned long long)ts.n_composited);
 #ifdef NRF_PHASE_TIMING
     atomicAdd(&counters[2], ts.c_march);
     atomicAdd(&counters[3], ts.c_net);

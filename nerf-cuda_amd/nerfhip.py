@@ -127,6 +127,7 @@ class Stats(C.Structure):
         ("n_rounds", C.c_uint64),
         ("n_network_evals", C.c_uint64),
         ("render_ms", C.c_float),
+        ("n_composited", C.c_uint64),
     ]
 
 

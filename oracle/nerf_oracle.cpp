@@ -917,6 +917,9 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
     stats->n_rounds = n_rounds;
     stats->n_network_evals = n_samples;  // D-5: the oracle evaluates live samples only, no tile padding
     stats->render_ms = 0.0f;
+    // the per-ray schedule emits exactly the samples a ray composites; the other schedules (n_step > 1) also evaluate
+    // samples behind a ray's terminating one and do not count the composited ones apart: 0 = not counted
+    stats->n_composited = schedule == NRFO_SCHED_PER_RAY ? n_samples : 0;
   }
 #ifdef _OPENMP
   omp_set_num_threads(saved);

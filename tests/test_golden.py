@@ -113,7 +113,9 @@ def test_frame_fingerprints_unchanged():
         c.bind_output(0, 0)
         rgba, depth = t_rgba.cpu().numpy(), t_depth.cpu().numpy()
         # the count of evaluated samples depends on the batching (speculation past a ray's end), the picture does not
-        assert abs(c.stats().n_samples - int(n_samples)) <= 0.02 * int(n_samples) + 64, row
+        # (recorded before tail splitting existed: a frame rendered alone now hands rays of its last tiles to idle waves, which
+        #  queue more samples per ray and round)
+        assert 0.98 * int(n_samples) - 64 <= c.stats().n_samples <= 1.25 * int(n_samples) + 64, row
         assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
         assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, row
     c.close()

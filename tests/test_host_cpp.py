@@ -257,6 +257,75 @@ def test_render_server_batches_concurrent_clients(snapshot):
             srv.kill()
 
 
+@pytest.mark.gpu
+def test_render_server_per_gpu_queues_64_clients(snapshot):
+    """BASELINE config 5 shape through the real server: 64 concurrent clients, two per-GPU queues (both workers on the one
+    device of this box: NERF_DEVICES=0,0), whole requests dealt to the less loaded queue, batches of up to 64 views, batch
+    k + 1 rendering while batch k is copied and sent.  Every reply must equal the binding's render of its pose; a sample
+    is compared with the ORACLE's quantised frame (<= 1 LSB); both workers must have rendered."""
+    import threading
+
+    path, desc, keep, cfg = snapshot
+    W, H, port = 64, 64, 23463
+    env = dict(SERVER_TEST_ENV, NERF_DEVICES="0,0")
+    srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, env=env)
+    n_clients, per_client = 64, 4
+    try:
+        socks = []
+        for c in range(n_clients):
+            s = _connect(port)
+            assert s is not None, "server did not come up"
+            s.settimeout(120)
+            socks.append(s)
+        poses = [[syn.orbit_pose(5.625 * c + 90.0 * i, -10.0 + 20.0 * ((c + i) % 4)) for i in range(per_client)] for c in range(n_clients)]
+        got = [[None] * per_client for _ in range(n_clients)]
+        errors = []
+
+        def client(c):
+            try:
+                for i in range(per_client):
+                    socks[c].sendall(np.ascontiguousarray(poses[c][i], np.float32).tobytes())
+                    got[c][i] = np.frombuffer(_recv_exact(socks[c], 3 * W * H), np.uint8).reshape(H, W, 3)
+            except Exception as e:  # noqa: BLE001
+                errors.append((c, repr(e)))
+
+        threads = [threading.Thread(target=client, args=(c,)) for c in range(n_clients)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(180)
+        assert not errors, errors[:3]
+        ctx = nh.NerfHip(0)
+        ctx.load_model(desc)
+        ctx.set_resolution(W, H)
+        cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
+        for c in range(n_clients):
+            for i in range(per_client):
+                rgb, _ = ctx.render_host_u8([cam], [poses[c][i]])
+                np.testing.assert_array_equal(got[c][i], rgb[0], err_msg=f"client {c} request {i}")
+        ctx.close()
+        for c, i in ((0, 0), (13, 1), (31, 2), (47, 3), (63, 0), (20, 2)):
+            _assert_within_one_lsb(got[c][i], _oracle_rgb8(desc, cam, poses[c][i], W, H), f"client {c} request {i}")
+        # the STAT hook answers with one 256-byte line of text
+        stat_msg = np.zeros(16, np.float32)
+        stat_msg[:1] = np.frombuffer(b"STAT", np.float32)
+        socks[1].sendall(stat_msg.tobytes())
+        words = _recv_exact(socks[1], 256).split(b"\0", 1)[0].decode().split()
+        st = {words[i]: float(words[i + 1]) for i in range(0, len(words), 2)}
+        assert st["frames"] == n_clients * per_client and st["workers"] == 2 and st["batches"] < st["frames"] and st["gpu_ms"] > 0
+        quit_msg = np.zeros(16, np.float32)
+        quit_msg[:1] = np.frombuffer(b"QUIT", np.float32)
+        socks[0].sendall(quit_msg.tobytes())
+        for s in socks:
+            s.close()
+        out, _ = srv.communicate(timeout=30)
+        assert "2 GPU queue(s)" in out
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+
+
 def test_binary_snapshot_blobs_cpp_and_python(tmp_path, snapshot):
     """`params_binary` / `density_grid_binary` (+ `*_type` "__half" | "float": instant-ngp's convention) carry the
     same values in the same order as the reference's arrays of numbers; the C++ loader and the Python one agree
@@ -365,9 +434,9 @@ def test_render_server_survives_rude_clients(snapshot):
         s.sendall(quit_msg.tobytes())              # without the hook: a pose like any other -> one frame comes back
         _recv_exact(s, 3 * W * H)
         assert srv.poll() is None
-        # 40 views in one extended request = two launches (the server renders 32 views per launch), answers in request order
+        # 80 views in one extended request = two chunks (the server renders up to 64 views per launch), answers in request order
         cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
-        views = [syn.orbit_pose(9.0 * i, 25.0) for i in range(40)]
+        views = [syn.orbit_pose(4.5 * i, 25.0) for i in range(80)]
         msg = b"NRF1" + np.uint32(len(views)).tobytes()
         for p in views:
             msg += cam.tobytes() + np.ascontiguousarray(p, np.float32).tobytes()
@@ -376,7 +445,7 @@ def test_render_server_survives_rude_clients(snapshot):
         ctx = nh.NerfHip(0)
         ctx.load_model(desc)
         ctx.set_resolution(W, H)
-        for i in (0, 31, 32, 39):
+        for i in (0, 63, 64, 79):
             ctx.render(cam, views[i])
             np.testing.assert_array_equal(frames[i], ctx.read_u8()[0])
         ctx.close()

@@ -64,13 +64,16 @@ def _render(desc, W, H, poses, env, shard=(0, 1), opts_kw=None):
     ctx.bind_output(rgba.data_ptr(), depth.data_ptr())
     ctx.render_views(np.stack([syn.default_camera(W, H)] * n), np.stack(poses))
     st = ctx.stats()
-    out = rgba.cpu().numpy(), depth.cpu().numpy(), int(st.n_samples), int(st.n_rays)
+    assert st.n_samples >= st.n_composited > 0 or st.n_samples == st.n_composited == 0
+    # (n_samples -- evaluated samples -- depends on how rays are batched into rounds: tail splitting hands rays to idle waves;
+    #  the samples that reach a ray's compositing sum do not)
+    out = rgba.cpu().numpy(), depth.cpu().numpy(), int(st.n_composited), int(st.n_rays)
     ctx.close()
     return out
 
 
 def _same(a, b, what):
-    assert a[2] == b[2] and a[3] == b[3], (what, a[2:], b[2:])          # samples, rays
+    assert a[2] == b[2] and a[3] == b[3], (what, a[2:], b[2:])          # composited samples, rays
     # every pixel the per-strip kernel writes is written (what stays poisoned in both: the padding tiles at the end of a
     # shard's tile-major buffer when the shards are uneven -- nobody's pixels); unsharded frames have no such padding
     assert np.array_equal(a[0] == 7.0, b[0] == 7.0) and np.array_equal(a[1] == 7.0, b[1] == 7.0), what
