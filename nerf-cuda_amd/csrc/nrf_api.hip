@@ -193,6 +193,7 @@ struct nrf_context {
   void* d_depth = nullptr;
   void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
   int call_index = 0;          // ring position of the last render call
+  int tail_split = 1;          // NRF_TAIL_SPLIT=0: no tail splitting in the persistent kernel (A/B runs)
   void* d_rgb8 = nullptr;
   void* d_depth8 = nullptr;
   void* bound_rgba = nullptr;  // caller-owned targets (nrf_bind_output)
@@ -335,6 +336,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.skip_outside = 0;
   P.prog_done = P.prog_flags = nullptr;
   P.prog_epoch = 0;
+  P.tail_split = c->tail_split;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
 }
@@ -680,6 +682,7 @@ int nrf_create(int device, nrf_context** out) {
     HIP_TRY(hipEventCreate(&h.t0));
     HIP_TRY(hipEventCreate(&h.t1));
   }
+  if (const char* e = std::getenv("NRF_TAIL_SPLIT")) c->tail_split = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
   HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
   *out = c;

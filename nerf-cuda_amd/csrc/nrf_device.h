@@ -177,6 +177,8 @@ struct FrameParams {
   // pixels have been written (write-through, acknowledged); the wave that completes a row stores prog_epoch into
   // prog_flags [n_views][tiles_y] (pinned host memory).  nullptr: off.
   int prog_epoch;
+  int tail_split;   // persistent kernel: 1 = waves that find the queues empty take rays off the rendering waves of their
+                    // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   unsigned* prog_done;
   unsigned* prog_flags;
 };

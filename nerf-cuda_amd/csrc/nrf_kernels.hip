@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   }
   // ---- tail splitting: this wave has nothing left of its own -- it takes rays off the waves of its workgroup that are
   // still rendering (HelpLds above), until none of them is
-  while (true) {
+  while (P0.tail_split != 0) {
     if (lane == 0) {
       __hip_atomic_fetch_add(&hl->busy, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_or(&hl->idle_mask, 1u << wave, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

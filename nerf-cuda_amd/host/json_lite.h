@@ -58,10 +58,19 @@ class JsonReader {
           case 'r': out += '\r'; break;
           case 'b': out += '\b'; break;
           case 'f': out += '\f'; break;
-          case 'u': {  // kept as-is (paths in transforms.json are ASCII); 4 hex digits skipped
+          case 'u': {  // \uXXXX -> UTF-8 (surrogate pairs are not joined: each half becomes its own 3-byte sequence)
             if (end_ - p_ < 4) throw std::runtime_error("json: bad \\u escape");
-            out += '?';
+            unsigned cp = 0;
+            for (int i = 0; i < 4; ++i) {
+              const char h = p_[i];
+              const int dgt = h >= '0' && h <= '9' ? h - '0' : (h >= 'a' && h <= 'f' ? h - 'a' + 10 : (h >= 'A' && h <= 'F' ? h - 'A' + 10 : -1));
+              if (dgt < 0) throw std::runtime_error("json: bad \\u escape");
+              cp = cp * 16 + (unsigned)dgt;
+            }
             p_ += 4;
+            if (cp < 0x80) out += (char)cp;
+            else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
           } break;
           default: out += e;  // \" \\ \/
         }
@@ -117,11 +126,30 @@ class JsonReader {
     } else if (literal("null")) {
       v.type = Value::Nil;
     } else {
-      char* endp = nullptr;
-      const std::string tok(p_, (size_t)(end_ - p_) < 64 ? (size_t)(end_ - p_) : 64);
-      const double d = std::strtod(tok.c_str(), &endp);
-      if (endp == tok.c_str()) throw std::runtime_error("json: unexpected character");
-      p_ += endp - tok.c_str();
+      // a JSON number and nothing else: -?digits[.digits][(e|E)[+-]digits] -- strtod alone would also take "inf", "nan",
+      // hex floats and leading '+', and a token cut to fit a buffer would silently split a long number in two
+      const char* q = p_;
+      auto digits = [&] {
+        const char* b = q;
+        while (q < end_ && *q >= '0' && *q <= '9') ++q;
+        return q > b;
+      };
+      if (q < end_ && *q == '-') ++q;
+      if (!digits()) throw std::runtime_error("json: unexpected character");
+      if (q < end_ && *q == '.') {
+        ++q;
+        if (!digits()) throw std::runtime_error("json: digits expected after the decimal point");
+      }
+      if (q < end_ && (*q == 'e' || *q == 'E')) {
+        ++q;
+        if (q < end_ && (*q == '+' || *q == '-')) ++q;
+        if (!digits()) throw std::runtime_error("json: digits expected in the exponent");
+      }
+      if (q - p_ > 400) throw std::runtime_error("json: number token longer than 400 characters");
+      const std::string tok(p_, (size_t)(q - p_));
+      const double d = std::strtod(tok.c_str(), nullptr);
+      if (!(d - d == 0.0)) throw std::runtime_error("json: number out of range");  // inf from overflow (nan cannot be written)
+      p_ = q;
       v.type = Value::Number;
       v.num = d;
     }
