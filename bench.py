@@ -102,7 +102,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders a (W/div)x(H/div) frame")
+    ap.add_argument("--cpu-sample-div", type=int, default=1,
+                    help="CPU baseline renders a (W/div)x(H/div) frame (default: the whole 1920x1080 frame, ~11 s on 128 cores)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="steps in flight; 0 = default (1 at N = 1, else 2)")
     ap.add_argument("--views-per-step", type=int, default=0,
                     help="camera views rendered by ONE launch per step (nrf_render_views); 0 = default")
@@ -119,7 +120,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--check", action="store_true", help="rank 0 also renders the frame unsharded and compares")
+    ap.add_argument("--check", action="store_true", default=None,
+                    help="rank 0 also renders the frame unsharded and compares (default: on whenever there is more than one rank)")
+    ap.add_argument("--no-check", dest="check", action="store_false")
     return ap.parse_args()
 
 
@@ -321,36 +324,49 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-pose sample counts of THIS rank's share (untimed single-view replays; the counts are deterministic),
-    # the duration of one view alone and of one step's launch when it has the chip to itself
-    samples_pose, evals_pose, single_ms, kern_ms = {}, {}, [], []
+    # sample counts of THIS rank's share, from the launches themselves: every distinct step composition is replayed once,
+    # untimed, and the kernel's counters are read (evaluated samples depend -- a little -- on how rays are batched into
+    # rounds, which differs between a view rendered alone and in a batch; the composited ones do not), together with
+    # the duration of one step's launch when it has the chip to itself; and one view alone: what a render_frame costs
     stream = slots[0].stream
-    needed = sorted({j for i in range(args.steps) for j in step_poses(i)})
-    for j in needed:
+    single_ms, kern_ms = [], []
+    for j in sorted({j for i in range(args.steps) for j in step_poses(i)}):
         ctx.render(cam, poses[j], stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
-        st = ctx.stats()
-        samples_pose[j], evals_pose[j] = int(st.n_samples), int(st.n_network_evals)
-        single_ms.append(float(st.render_ms))
-    for i in range(min(args.steps, 4)):
-        ctx.render_views(cams_step, [poses[j] for j in step_poses(i)], stream=stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        kern_ms.append(float(ctx.stats().render_ms))
-    step_samples = [sum(samples_pose[j] for j in step_poses(i)) for i in range(args.steps)]
+        single_ms.append(float(ctx.stats().render_ms))
+    per_step = {}
+    for i in range(args.steps):
+        key = tuple(step_poses(i))
+        if key not in per_step:
+            ctx.render_views(cams_step, [poses[j] for j in key], stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            st = ctx.stats()
+            per_step[key] = (int(st.n_samples), int(st.n_network_evals), int(st.n_composited))
+            kern_ms.append(float(st.render_ms))
+    step_counts = [per_step[tuple(step_poses(i))] for i in range(args.steps)]
+    step_samples = [c[0] for c in step_counts]
+    local_evals, local_composited = sum(c[1] for c in step_counts), sum(c[2] for c in step_counts)
     local_samples = sum(step_samples)
-    devices = [f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}"]
+    # which physical device every rank sits on: two ranks on one GPU would make an N-GPU line out of fewer GPUs
+    props = torch.cuda.get_device_properties(dev_index)
+    dev_id = str(getattr(props, "uuid", "")) or f"pci {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+    devices = [f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)} [{dev_id}]"]
     if world > 1:
-        t = torch.tensor([local_samples], device=dev, dtype=torch.int64)
+        t = torch.tensor([local_samples, local_evals, local_composited], device=dev, dtype=torch.int64)
         dist.all_reduce(t)
-        total_samples = int(t.item())
+        total_samples, total_evals, total_composited = (int(v) for v in t.tolist())
         gathered = [None] * world
-        dist.all_gather_object(gathered, devices[0])
-        devices = gathered
+        dist.all_gather_object(gathered, (devices[0], dev_id))
+        devices = [g[0] for g in gathered]
+        ids = [g[1] for g in gathered]
+        if len(set(ids)) != world and not args.single_device:
+            sys.exit(f"bench.py: {world} ranks on {len(set(ids))} distinct device(s) ({devices}): this would not be an "
+                     f"{world}-GPU measurement (rehearsals on one GPU: --backend gloo --single-device)")
     else:
-        total_samples = local_samples
+        total_samples, total_evals, total_composited = local_samples, local_evals, local_composited
 
     check = None
-    if args.check and world > 1:
+    if (args.check if args.check is not None else world > 1) and world > 1:
         # the gathered (+ untiled) frames of a step must equal unsharded single renders of the same poses
         torch.cuda.synchronize(dev)
         step(0)
@@ -413,7 +429,10 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "frames_per_s": round(V_step * 1e3 / ms_per_step, 2),
         # network evaluations including the padding of the 16-sample MFMA tiles, reported separately
-        "network_evaluations_per_s_M": round(msamples_s * sum(evals_pose.values()) / max(sum(samples_pose.values()), 1), 2),
+        "network_evaluations_per_s_M": round(total_evals / elapsed / 1e6, 2),
+        # the samples that reach a ray's compositing sum = what the reference's own per-ray schedule emits; `value` also counts
+        # the ones a ray queues behind its terminating sample (evaluated, never used: +2-3 %)
+        "useful_msamples_s": round(total_composited / elapsed / 1e6, 2),
         "ms_per_frame": round(ms_per_step / V_step, 4),
         # one render_frame call of the reference's API = one view per launch, nothing else on the chip
         "single_view_ms": round(single_view_ms, 4),
@@ -443,6 +462,9 @@ def main():
             # the contract's figure: ALGORITHMIC gather bytes / kernel time against the HBM peak.  The table
             # (24 MB) is served from L2 / Infinity Cache, so this is a cache-gather rate: see hbm_gbs_measured and limiter
             "bound": "hbm",
+            "bound_note": "the contract's figure: ALGORITHMIC gather bytes (512 B per evaluated sample) over the launch time, against the HBM "
+                          "peak; the table is served from L2 / Infinity Cache (hbm_gbs_measured), what binds the kernel is in `limiter`",
+            "binding_unit": ((pmc.get("limiter") or {}).get("binding_unit") if pmc else None),
             "achieved": round(gather_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -476,6 +498,7 @@ def main():
         out["config"]["samples_per_frame"] = int(mean_samples_launch / V)
         if not replica:
             out["api"] = api_bench(nh, torch, dev, desc, cam, poses, W, H)
+            out["fast_interp"] = fast_interp_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V, ms_per_step / V_step)
             with torch.cuda.stream(stream):
                 out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
             if not args.no_cpu_baseline:
@@ -572,6 +595,40 @@ def api_bench(nh, torch, dev, desc, cam, poses, W, H):
             "host_tail_ms_per_batch": round(batch_ms - bd, 4),
             "copy_ms_per_batch_at_link_rate": round(float(np.mean(bcopied)) / (link_gbs * 1e9) * 1e3, 4),
             "render_plus_read_u8_ms": round(float(np.mean(old[2:])), 4)}
+
+
+def fast_interp_bench(nh, torch, dev, desc, cams, poses, W, H, V, base_ms_per_frame):
+    """nrf_options::fast_interp (OPT-IN, not the headline: the default stays bit-exact): the step's launch with the
+    single-rounding interpolation -- ms per frame, samples/s, and its distance from the default frame."""
+    import numpy as np
+
+    g = nh.NerfHip(dev.index)
+    g.load_model(desc)
+    g.set_resolution(W, H)
+    g.set_max_views(V)
+    st = torch.cuda.Stream(dev)
+    res = {}
+    for fast in (0, 1):
+        o = nh.default_options()
+        o.fast_interp = fast
+        g.set_options(o)
+        ms = []
+        for i in range(6):
+            g.render_views(cams, poses, stream=st.cuda_stream)
+            torch.cuda.synchronize(dev)
+            ms.append(float(g.stats().render_ms))
+        stt = g.stats()
+        res[fast] = (float(np.mean(ms[2:])), int(stt.n_samples), g.read_view_f32(0)[0])
+    g.close()
+    mse = float(np.mean((res[1][2].astype(np.float64) - res[0][2].astype(np.float64)) ** 2))
+    return {"what": "OPT-IN nrf_options.fast_interp = 1 (one rounding per corner of the hash-grid interpolation instead of the reference's "
+                    "three: not bit-exact, default off); same launch as the headline step, device time",
+            "ms_per_frame": round(res[1][0] / V, 4), "default_ms_per_frame_same_run": round(res[0][0] / V, 4),
+            "msamples_s": round(res[1][1] / (res[1][0] * 1e-3) / 1e6, 2),
+            "speedup": round(res[0][0] / res[1][0], 4),
+            "psnr_db_vs_default_frame": round(99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse), 2),
+            "max_abs_vs_default_frame": float(np.abs(res[1][2] - res[0][2]).max()),
+            "tolerance": "features within 4 x 2^-11 of the bit-exact ones, frames <= 2/255 (tests/test_parity_gpu.py)"}
 
 
 def mlp_microbench(ctx, torch, dev):

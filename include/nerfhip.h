@@ -152,6 +152,14 @@ typedef struct nrf_options {
    * interleave p = NGPU*tid + gpu of render_utils.h:37.                      */
   int32_t shard_index; /* 0 */
   int32_t shard_count; /* 1 */
+  /* Opt-in (default 0), NOT the reference's arithmetic: the trilinear interpolation of the hash grid accumulates
+   * (half)(w * h + acc) with one rounding per corner (v_fma_mixlo/hi_f16) instead of the reference's three (grid.h:258-260:
+   * fp32 product, cast to fp16, fp16 sum) -- half the vector instructions of the kernel's most expensive loop.  Features
+   * differ from the bit-exact path by an ulp of a partial sum now and then (more accurate, not identical: within 4 x 2^-11
+   * for table entries of magnitude 0.5); frames within the 2/255 the parity tests allow.  Measured gain: under 1 % -- the
+   * kernel is co-limited by its gather path (DESIGN.md "What binds the kernel").  Honoured by the register-resident instance of the fused kernel in its persistent form and by
+   * nrf_encode_grid; other instances render with the exact arithmetic.                                              */
+  int32_t fast_interp; /* 0 */
 } nrf_options;
 
 /* One rendered frame (device memory owned by the context, valid until the

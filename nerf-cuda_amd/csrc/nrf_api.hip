@@ -337,6 +337,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.prog_done = P.prog_flags = nullptr;
   P.prog_epoch = 0;
   P.tail_split = c->tail_split;
+  P.fast_interp = c->opt.fast_interp ? 1 : 0;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
 }
@@ -610,6 +611,7 @@ void nrf_default_options(nrf_options* o) {
   o->perturb = 0;
   o->shard_index = 0;
   o->shard_count = 1;
+  o->fast_interp = 0;
 }
 
 int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t) {
@@ -1626,7 +1628,7 @@ int nrf_untile(nrf_context* c, const void* gathered, int shard_count, int tiles_
 int nrf_encode_grid(nrf_context* c, const void* pos01, uint32_t n, void* out, void* stream) {
   STAGE_PROLOGUE();
   if (n && (!pos01 || !out)) return fail(NRF_E_INVALID, "null argument");
-  HIP_TRY(launch_encode_grid(c->dm, pos01, n, out, st));
+  HIP_TRY(launch_encode_grid(c->dm, pos01, n, out, st, c->opt.fast_interp != 0));
   STAGE_EPILOGUE();
 }
 

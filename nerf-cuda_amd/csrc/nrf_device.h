@@ -177,6 +177,7 @@ struct FrameParams {
   // pixels have been written (write-through, acknowledged); the wave that completes a row stores prog_epoch into
   // prog_flags [n_views][tiles_y] (pinned host memory).  nullptr: off.
   int prog_epoch;
+  int fast_interp;  // nrf_options::fast_interp: the FAST instances of the persistent register-resident kernel / encode_grid_kernel
   int tail_split;   // persistent kernel: 1 = waves that find the queues empty take rays off the rendering waves of their
                     // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   unsigned* prog_done;
@@ -393,6 +394,15 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
   while (t < far) {
     if (budget <= 0) return MARCH_OUT_OF_BUDGET;
     --budget;
+#ifdef NRF_DIAG_EXTRA_MARCH
+    // diagnostic build (scripts/marginal_cost.sh, never shipped): NRF_DIAG_EXTRA_MARCH extra v_mul_f32 per cell trip whose
+    // results nobody reads: what does a vector instruction of the march phase cost in situ?
+#pragma unroll
+    for (int e = 0; e < NRF_DIAG_EXTRA_MARCH; ++e) {
+      float sink;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sink) : "v"(t), "v"(dx));
+    }
+#endif
     x = clamp3(ox + t * dx, -c.bound, c.bound);
     y = clamp3(oy + t * dy, -c.bound, c.bound);
     z = clamp3(oz + t * dz, -c.bound, c.bound);
@@ -559,27 +569,70 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   for (int c = 0; c < 8; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[c], 0, 0);
 }
 
+// FAST (opt-in, nrf_options::fast_interp; never the default): acc = (half)(w * h + acc) as ONE v_fma_mixlo/hi_f16 per half and
+// corner -- the exact fp32 fma rounded once to fp16 -- instead of the reference's three roundings (product to fp32, to fp16,
+// fp16 sum): 2 instead of 4 half-rate instructions per corner.  More accurate than the reference's arithmetic, but not its
+// bits: features differ by an fp16 ulp now and then (tests/test_parity_gpu.py states the tolerance).
+template <bool FAST = false>
 __device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const float (&frac)[3]) {
   const float wx[2] = {1 - frac[0], frac[0]};
   const float wy[2] = {1 - frac[1], frac[1]};
   const float wz[2] = {1 - frac[2], frac[2]};
+  if constexpr (FAST) {
+    uint32_t a = 0u;  // packed (feature 0, feature 1)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
+      asm("v_fma_mixlo_f16 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "v"(w), "v"(v[c]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, %0 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "+v"(a) : "v"(w), "v"(v[c]));
+    }
+    return a;
+  }
   half2_t acc = {(half_t)0.0f, (half_t)0.0f};
+#ifdef NRF_DIAG_DROP_INTERP_CVT
+  float diag_acc_lo = 0.f, diag_acc_hi = 0.f;
+#endif
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     // weight = ((1 * wx) * wy) * wz in dimension order (grid.h:240-252)
     const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
+#ifdef NRF_DIAG_DROP_INTERP_CVT
+    // diagnostic build (scripts/marginal_cost.sh, never shipped): the same gathers and fp32 products, but the
+    // v_cvt_pk_f16_f32 + v_pk_add_f16 of every corner are gone (wrong values): what do those two instructions cost in situ?
+    {
+      float lo, hi;
+      const float neg_zero = -0.0f;
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(lo) : "v"(w), "v"(v[c]), "v"(neg_zero));
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(hi) : "v"(w), "v"(v[c]), "v"(neg_zero));
+      diag_acc_lo += lo;  // (one full-rate v_add_f32 each keeps the products alive)
+      diag_acc_hi += hi;
+    }
+#else
     acc = acc + weight_times_entry(w, v[c]);  // v_pk_add_f16, RNE: result += (T)(weight * data)
+#endif
+#ifdef NRF_DIAG_EXTRA_INTERP
+    // diagnostic build: NRF_DIAG_EXTRA_INTERP extra v_cvt_pk_f16_f32 per corner whose results nobody reads (right values)
+#pragma unroll
+    for (int e = 0; e < NRF_DIAG_EXTRA_INTERP; ++e) {
+      uint32_t sink;
+      asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(sink) : "v"(w), "v"(frac[e % 3]));
+    }
+#endif
   }
+#ifdef NRF_DIAG_DROP_INTERP_CVT
+  return pack_h2(diag_acc_lo, diag_acc_hi);
+#else
   return h2_bits(acc);
+#endif
 }
 
-template <int UNI = 0>
+template <int UNI = 0, bool FAST = false>
 __device__ __forceinline__ uint32_t encode_level(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L,
                                                  float px, float py, float pz) {
   uint32_t v[8];
   float frac[3];
   level_gather<UNI>(grid, grid_bytes, L, px, py, pz, v, frac);
-  return level_interp(v, frac);
+  return level_interp<FAST>(v, frac);
 }
 
 // ------------------------------------------------------ direction encoding ----

@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
 // RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
 // evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
-template <int NT, int RK = 1>
+template <int NT, int RK = 1, bool FAST = false>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
         else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
       }
 #pragma unroll
-      for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp(gv[jl], gf[jl]);
+      for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp<FAST>(gv[jl], gf[jl]);
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
       if constexpr (RK > 1) {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void gen_network_from_lds(const DevModel& M, const Ge
   gen_wave_sync();  // the next pass overwrites the rows
 }
 
-template <int NET>
+template <int NET, bool FAST = false>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const GenLds& Lw, int S, int lane, float density_scale) {
   constexpr int RK = NET == NET_WIDE ? RK_WIDE : 1;
@@ -230,8 +230,8 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
   } else {
     for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      if (ntile <= 1) network_from_lds<1, RK>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
-      else network_from_lds<NT_MAX, RK>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      if (ntile <= 1) network_from_lds<1, RK, FAST>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      else network_from_lds<NT_MAX, RK, FAST>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
     }
   }
 }
@@ -493,7 +493,7 @@ struct TileStats {
 // acc: in = what the rays have composited before (zero for a fresh tile), out = after their last round.
 // HELP (persistent kernel): tail splitting -- ha names the workgroup's HelpLds; pix_idx / near / far travel with a ray that
 // is handed to a helper; *given = the lane's ray was handed over (its pixel is the helper's to store).
-template <int NET, bool COARSE_LDS, int MARCH, bool HELP = false>
+template <int NET, bool COARSE_LDS, int MARCH, bool HELP = false, bool FAST = false>
 __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams& P, const MarchConst& mc, const LdsMap& lm,
                                             const uint32_t* coarse_lds, const float* ctab_lds, int lane, const float (&o)[3],
                                             const float (&d)[3], float rdx, float rdy, float rdz, int sx, int sy, int sz,
@@ -603,7 +603,7 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
 
     if (S > 0) {
       // ---- network on the S queued samples (sample-major MFMA tiles)
-      network_dispatch<NET>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
+      network_dispatch<NET, FAST>(M, wl, lvs, W, lm.gen, S, lane, P.density_scale);
       wave_sync();
     }
     NRF_STAMP(t2);
@@ -970,7 +970,9 @@ static_assert(offsetof(PersistArgs, P) == (sizeof(DevModel) + alignof(FrameParam
 
 // WLDS (generic instance): the layers' weight fragments are staged in LDS as well, instead of streamed from L2 per pass.
 // U8: the instance that writes the reference's 8-bit Image layout (OUT_U8, store_tile_u8)
-template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false, bool U8 = false>
+// FAST: nrf_options::fast_interp (opt-in single-rounding interpolation; register-resident instance only) -- instances of
+// their own, so that the shipped default symbols keep the bit-exact arithmetic (tests/test_abi_cpu.py checks their ISA)
+template <int NET, int MARCH, int WAVES = persist_waves(NET), bool WLDS = false, bool U8 = false, bool FAST = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const DevModel M0, const FrameParams P0, const ViewBatch VB0,
                                                                               float4* __restrict__ rgba0, float* __restrict__ depth0,
                                                                               unsigned long long* __restrict__ counters,
@@ -1175,8 +1177,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       wave_sync();
       NRF_STAMP(t_setup_done);
       const HelpArgs ha = {hl, lm.W - wave, view};
-      tile_rounds<NET, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
-                                              alive, acc, ts, 0, &ha, pix_idx, near, far, &given);
+      tile_rounds<NET, true, MARCH, true, FAST>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
+                                                    alive, acc, ts, 0, &ha, pix_idx, near, far, &given);
 #ifdef NRF_PHASE_TIMING
       if (lane == 0) {
         NRF_STAMP(t_end);
@@ -1295,8 +1297,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
     bool given = false;
     const HelpArgs ha = {hl, lm.W - wave, view};
     // (t_skip: the occupancy lookups it would skip are of cells known to be empty -- looking them up changes nothing)
-    tile_rounds<NET, true, MARCH, true>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, -3.402823466e+38f, t, tc,
-                                            mine, acc, ts, n_ray_samples, &ha, pix_idx, near, far, &given);
+    tile_rounds<NET, true, MARCH, true, FAST>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, -3.402823466e+38f, t, tc,
+                                                  mine, acc, ts, n_ray_samples, &ha, pix_idx, near, far, &given);
     const OutPlanes op = view_planes<OUT8>(P, rgba0, depth0, view, VB.view_stride_px);
     const bool store = mine && !given;
     if (store) {  // get_image_and_depth, as in the tile loop
@@ -1345,6 +1347,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
 // ------------------------------------------------------------ stage kernels ----
 // Hot instance: the same per-level specialisation render_kernel uses (uni_modes of the level's
 // group of four), so the bit-exact encode test covers the hot path's index arithmetic.
+template <bool FAST>
 __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, const float* __restrict__ pos01, uint32_t n,
                                                           uint32_t* __restrict__ out) {
   __shared__ LevelParams lvs[16];
@@ -1356,9 +1359,9 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
     const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
     const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
-    if (uni == 2u) out[i] = encode_level<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
-    else if (uni == 1u) out[i] = encode_level<1>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
-    else out[i] = encode_level<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    if (uni == 2u) out[i] = encode_level<2, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    else if (uni == 1u) out[i] = encode_level<1, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    else out[i] = encode_level<0, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
   }
 }
 
@@ -1820,12 +1823,21 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     int eb = 0;
     const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
     const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+#define NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, FI)                                                                    \
+  do {                                                                                                                   \
+    e = allow_lds(render_persistent_kernel<G, U, WV, WL, O8, FI>, lds);                                                  \
+    if (e != hipSuccess) return e;                                                                                       \
+    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL, O8, FI>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,    \
+                       (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
+  } while (0)
 #define NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, O8)                                                                        \
   do {                                                                                                                   \
-    e = allow_lds(render_persistent_kernel<G, U, WV, WL, O8>, lds);                                                      \
-    if (e != hipSuccess) return e;                                                                                       \
-    hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL, O8>), dim3(wgs), dim3(64 * WV), lds, st, M, P, VB,        \
-                       (float4*)rgba, (float*)depth, (unsigned long long*)counters, queue);                              \
+    if constexpr (G == NET_HOT) {                                                                                        \
+      if (P.fast_interp) NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, true);                                                \
+      else NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, false);                                                             \
+    } else {                                                                                                             \
+      NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, false);                                                                  \
+    }                                                                                                                    \
   } while (0)
 #define NRF_LAUNCH_PERSISTENT_W(G, U, WV, WL)                                                                             \
   do {                                                                                                                   \
@@ -1850,6 +1862,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 #undef NRF_LAUNCH_PERSISTENT
 #undef NRF_LAUNCH_PERSISTENT_W
 #undef NRF_LAUNCH_PERSISTENT_O
+#undef NRF_LAUNCH_PERSISTENT_F
     return hipGetLastError();
   }
   const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
@@ -1887,13 +1900,16 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
   return hipGetLastError();
 }
 
-hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st) {
+hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st, bool fast_interp) {
   if (!n) return hipSuccess;
   if (M.generic)
     hipLaunchKernelGGL(gen_encode_grid_kernel, dim3(grid_for((uint64_t)n * M.n_levels)), dim3(256), 0, st, M, (const float*)pos01, n,
                        (half_t*)out);
+  else if (fast_interp)
+    hipLaunchKernelGGL(encode_grid_kernel<true>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+                       (uint32_t*)out);
   else
-    hipLaunchKernelGGL(encode_grid_kernel, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
+    hipLaunchKernelGGL(encode_grid_kernel<false>, dim3(grid_for((uint64_t)n * 16)), dim3(256), 0, st, M, (const float*)pos01, n,
                        (uint32_t*)out);
   return hipGetLastError();
 }

@@ -14,7 +14,7 @@ struct ViewBatch;
 constexpr int RENDER_QUEUE_BYTES = 8 * 4;
 hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VB, void* rgba, void* depth, void* counters,
                          hipStream_t st, bool queues_are_zero);
-hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st);
+hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st, bool fast_interp = false);
 hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st);
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,
                               hipStream_t st);

@@ -87,6 +87,7 @@ class Options(C.Structure):
         ("perturb", C.c_int32),
         ("shard_index", C.c_int32),
         ("shard_count", C.c_int32),
+        ("fast_interp", C.c_int32),
     ]
 
 
@@ -133,7 +134,7 @@ class Stats(C.Structure):
 
 def default_options() -> Options:
     """Private member defaults of NerfRender (include/nerf-cuda/nerf_render.h:55-78)."""
-    return Options(1.0, 0.2, 1.0 / 128.0, 1024, 1.0, 0, 0, 1)
+    return Options(1.0, 0.2, 1.0 / 128.0, 1024, 1.0, 0, 0, 1, 0)
 
 
 class NerfHipError(RuntimeError):
