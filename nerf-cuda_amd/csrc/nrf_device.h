@@ -781,6 +781,9 @@ struct MlpOut {
 // this network when one of its snapshots is loaded (nerfhip.py "instant-ngp snapshots").
 // RK > 1 (wide instance): dirx[n][s - 1] = B fragment of K step s of the first rgb layer = direction entries
 // 32 s - 16 + 8 g .. + 7 of sample c of tile n (dir_entries8).
+// (An explicit issue order for this body -- one MFMA, then k vector instructions, by __builtin_amdgcn_sched_group_barrier -- was
+//  measured in round 3 and removed: k = 2 equals the compiler's own schedule, k = 3 / 4 are 5-7 % slower,
+//  profiles/r03/mlp_interleave.txt.)
 template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags, int RK = 1>
 __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
                                           bool rgb_sigmoid = false, const half8_t (*dirx)[RK_WIDE - 1] = nullptr) {

@@ -17,6 +17,7 @@
 // time for the parity tests (include/nerfhip.h "stage entry points").
 
 #include <cstddef>
+#include <cstdlib>
 
 #include "nrf_device.h"
 #include "nrf_generic.h"
