@@ -102,6 +102,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region and its line (no api / fast_interp / mlp_kernel / cpu_baseline objects): what the "
+                         "rocprofv3 passes of scripts/profile_gpu.sh run, so that every launch they see is the headline kernel's")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
                     help="CPU baseline renders a (W/div)x(H/div) frame (default: the whole 1920x1080 frame, ~11 s on 128 cores)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="steps in flight; 0 = default (1 at N = 1, else 2)")
@@ -496,7 +499,7 @@ def main():
         out["sharded_frame_equals_unsharded"] = check
     if world == 1:
         out["config"]["samples_per_frame"] = int(mean_samples_launch / V)
-        if not replica:
+        if not replica and not args.no_extras:
             out["api"] = api_bench(nh, torch, dev, desc, cam, poses, W, H)
             out["fast_interp"] = fast_interp_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V, ms_per_step / V_step)
             with torch.cuda.stream(stream):

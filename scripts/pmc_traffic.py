@@ -33,9 +33,17 @@ for name, g_, counter, value, ms in rows:
         kernel_name = name
 grid = max(agg, key=lambda k: len(agg[k]["_ms"]))
 c = {k: statistics.mean(v) for k, v in agg[grid].items()}
-h = hashlib.sha256()
-for f in ("nrf_device.h", "nrf_kernels.hip"):
-    h.update((ROOT / "nerf-cuda_amd" / "csrc" / f).read_bytes())
+h = hashlib.sha256()  # == bench.py kernel_source_sha16(): every file under csrc/ feeds the render launch
+for f in sorted((ROOT / "nerf-cuda_amd" / "csrc").iterdir()):
+    if f.suffix in (".h", ".hip"):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+marginal = None
+mc = Path(out).parent / "marginal_cost.json"
+if mc.exists():  # the in-situ measurement (scripts/marginal_cost.py): what an added vector instruction costs in wall time
+    m = json.loads(mc.read_text())["variants"]
+    marginal = {k: {"what": v["what"], "ms_per_1e9_wave_instructions": v["ms_per_1e9_wave_instructions"],
+                    "cycles_per_instruction_and_simd": v["cycles_per_instruction_and_simd"]} for k, v in m.items()}
 g = lambda k: c.get(k, 0.0)  # noqa: E731
 valu = g("SQ_INSTS_VALU")
 f32 = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32")
@@ -61,7 +69,7 @@ doc = {
     "launch": f"one bench.py step = {views} views of 1920x1080 in one launch (grid {grid} threads)",
     "views_per_launch": views,
     "kernel_source_sha16": h.hexdigest()[:16],
-    "source": f"{root} (rocprofv3 --pmc passes of `bench.py --steps 8 --warmup 2 --no-cpu-baseline`, scripts/profile_gpu.sh)",
+    "source": f"{root} (rocprofv3 --pmc passes of `bench.py --steps 8 --warmup 2 --no-extras`, scripts/profile_gpu.sh)",
     "fetch_size_kb": g("FETCH_SIZE"),
     "write_size_kb": g("WRITE_SIZE"),
     "hbm_bytes_per_launch": int((g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024),
@@ -88,6 +96,13 @@ doc = {
         "valu_issue_counter": "SQ_INSTS_VALU_* classes x measured issue cost / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
         "valu_issue_cycles_per_launch": cycles,
         "simd_cycles_per_launch": simd_cycles,
+        "binding_unit": "VALU issue port and texture-address (gather) path, co-limiting",
+        # the in-situ check of that attribution (round 3): instructions of a KNOWN count added to / taken from the two big phases
+        "marginal_cost_in_situ": marginal,
+        "marginal_cost_reading": "an added half-rate instruction in the interpolation costs 2.5-2.6 of its 4.1 nominal cycles, an added v_mul_f32 per march "
+                                 "trip 1.5-1.75 of 2.25: the issue port is a real limiter in BOTH phases (the march's instruction count IS a lever, "
+                                 "against round 2's reading) -- but removing interpolation instructions returns only 0.7 cycles each (nocvt) and the "
+                                 "opt-in fast_interp (half of them gone) < 1 %: with less vector work the gather path binds at once",
         "note": "The VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max / "
                 "med3, conversions, shifts, v_mul_lo_u32, packed fp16, v_fma_mix); transcendentals 8; an MFMA holds the issue port for 8 "
                 "(scripts/issue_rate/issue_rate.hip, profiles/r02/issue_rate.txt: 34 opcodes; the int32 and remainder counter classes are "

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --steps 8 --warmup 2 --no-extras"
 OLDPWD=$PWD
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
