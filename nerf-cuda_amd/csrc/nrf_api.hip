@@ -130,6 +130,33 @@ void pack_fragments(const std::vector<_Float16>& w16, uint32_t rgb_in, std::vect
   for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
 }
 
+// The same fragment order for 16 / 32 / 128 neurons (nrf_device.h MlpShape<W>): D0 [W][32] | D1 [16][W] | R0 [W][32] | R1 [W][W] | R2 [16][W],
+// MT = W / 16 row tiles, KS = ceil(W / 32) K steps; columns beyond a matrix's width are zero (W = 16: the upper half of the one step).
+void pack_fragments_width(const std::vector<_Float16>& w16, int Wd, std::vector<_Float16>& frags) {
+  const int MT = Wd / 16, KS = (Wd + 31) / 32;
+  const int fD1 = MT, fR0 = MT + KS, fR1 = 2 * MT + KS, fR2 = 2 * MT + KS + MT * KS, n = 2 * MT + 2 * KS + MT * KS;
+  frags.assign((size_t)n * 64 * 8, (_Float16)0.0f);
+  const _Float16* D0 = w16.data();                 // [W][32]
+  const _Float16* D1 = D0 + (size_t)Wd * 32;       // [16][W]
+  const _Float16* R0 = D1 + (size_t)16 * Wd;       // [W][32]
+  const _Float16* R1 = R0 + (size_t)Wd * 32;       // [W][W]
+  const _Float16* R2 = R1 + (size_t)Wd * Wd;       // [16][W]
+  auto khid = [](int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); };
+  auto put = [&](int f, const _Float16* Wm, int in, int m, auto kmap) {
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 8; ++j) {
+        const int k = kmap(l >> 4, j);
+        frags[((size_t)f * 64 + l) * 8 + j] = k < in ? Wm[(size_t)(16 * m + (l & 15)) * in + k] : (_Float16)0.0f;
+      }
+  };
+  for (int m = 0; m < MT; ++m) put(m, D0, 32, m, [](int g, int j) { return 2 * (4 * (j >> 1) + g) + (j & 1); });
+  for (int s = 0; s < KS; ++s) put(fD1 + s, D1, Wd, 0, [&](int g, int j) { return khid(s, g, j); });
+  for (int m = 0; m < MT; ++m) put(fR0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int m = 0; m < MT; ++m)
+    for (int s = 0; s < KS; ++s) put(fR1 + KS * m + s, R1, Wd, m, [&](int g, int j) { return khid(s, g, j); });
+  for (int s = 0; s < KS; ++s) put(fR2 + s, R2, Wd, 0, [&](int g, int j) { return khid(s, g, j); });
+}
+
 // Generic instance (nrf_generic.h gen_layer): fragment (m, s) of a layer W[N][K], lane l, element j =
 // W[16 m + (l & 15)][32 s + 8 (l >> 4) + j]  (natural K order), zero beyond K.
 void pack_generic_layer(const _Float16* Wm, uint32_t N, uint32_t K, std::vector<_Float16>& frags) {
@@ -174,12 +201,15 @@ struct nrf_context {
   void* d_ctab = nullptr;
   void* d_gen = nullptr;
   void* d_wfrag_gen = nullptr;  // wide models: generic-layout fragments for the stage entry points
+  uint32_t model_hot_width = 0; // the loaded model's width if it has a register-resident width instance (else 0)
+  void* d_wfrag_hot = nullptr;  // 16 / 32 / 128-neuron models of the base.json shape: fragments of their register-resident instance
   GenModel gen{};  // host copy of the generic instance's description (valid when dm.generic)
   std::vector<float> host_grid;  // the float density grid the march tables were built from
   bool grid_missing = false;     // loaded without a density grid and none generated yet
   bool allow_persistent = true;  // NRF_PERSISTENT=0 keeps the one-workgroup-per-strip render_kernel (A/B runs)
   bool centre_out = true;        // NRF_CENTRE_OUT=0: the persistent kernel's queue in row order
   bool allow_gen_wlds = true;    // NRF_GEN_WLDS=0: the generic instance's weight fragments are never staged in LDS
+  bool allow_width_instances = true;  // NRF_WIDTH_INSTANCES=0: 16 / 32 / 128-neuron models render in the generic instance (A/B runs)
   int queue_classes = 0;         // NRF_QUEUE_CLASSES=1..8: work queues of the persistent kernel (default: one per XCD)
   int n_cus = 256;
   nrf_options opt{};
@@ -249,7 +279,8 @@ void free_model(nrf_context* c) {
   if (c->d_dilated) (void)hipFree(c->d_dilated);
   if (c->d_gen) (void)hipFree(c->d_gen);
   if (c->d_wfrag_gen) (void)hipFree(c->d_wfrag_gen);
-  c->d_wfrag_gen = nullptr;
+  if (c->d_wfrag_hot) (void)hipFree(c->d_wfrag_hot);
+  c->d_wfrag_gen = c->d_wfrag_hot = nullptr;
   c->d_grid = c->d_occ = c->d_wfrag = c->d_lv = c->d_coarse = c->d_ctab = c->d_dilated = c->d_gen = nullptr;
   c->model_loaded = false;
 }
@@ -560,7 +591,20 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   M.persistent = 0;
   M.persist_waves = 0;
   M.n_cus = (uint32_t)c->n_cus;
-  if (c->allow_persistent && M.lds_coarse_words > 0) {
+  M.hot_width = c->model_hot_width;  // (decided again for every grid: nrf_generate_density_grid calls this too)
+  bool width_instance = false;  // the model's frames come from the register-resident instance of its width (persistent kernel only)
+  if (c->allow_persistent && M.lds_coarse_words > 0 && M.hot_width) {
+    const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
+    if ((size_t)render_persistent_lds_width_bytes((int)M.hot_width) + tables <= 160u * 1024u) {
+      M.persistent = 1;
+      M.persist_waves = 16;
+      M.gen_weights_lds = 0;
+      M.lds_dilated_words = (uint32_t)dilated.size();
+      width_instance = true;
+    }
+  }
+  if (!width_instance) M.hot_width = 0;  // (the tables do not fit beside its workgroup: the generic instance renders)
+  if (c->allow_persistent && M.lds_coarse_words > 0 && !width_instance) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
     // generic instance: 12 waves with the weight fragments in LDS, 12 waves without, 8 with, 8 without -- the first that fits
     // (NRF_GEN_WLDS=0 at nrf_create: never stage the fragments)
@@ -661,6 +705,7 @@ int nrf_create(int device, nrf_context** out) {
   if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_GEN_WLDS")) c->allow_gen_wlds = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_WIDTH_INSTANCES")) c->allow_width_instances = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_QUEUE_CLASSES")) c->queue_classes = std::atoi(e);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipSetDevice(device));
@@ -810,10 +855,19 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                          d->density_output_activation == NRF_ACT_NONE &&
                          (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                          d->sigma_activation == NRF_ACT_EXPONENTIAL);
-  std::vector<_Float16> frags, frags_gen;
+  // ... except for its width: 16 / 32 / 128 neurons (tcnn's other FullyFusedMLP widths) keep the register-resident form in
+  // the persistent kernel (NET_W16 / NET_W32 / NET_W128); everywhere else such a model is a generic one
+  const bool base_shape_but_width = !generic_grid && F == 2 && L == 16 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 && dir_w == 16 &&
+                                    d->interpolation == NRF_INTERP_LINEAR && d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+                                    d->density_output_activation == NRF_ACT_NONE &&
+                                    (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
+                                    d->sigma_activation == NRF_ACT_EXPONENTIAL;
+  const uint32_t hot_width = (base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u;
+  std::vector<_Float16> frags, frags_gen, frags_hot;
   GenModel G;
   std::memset(&G, 0, sizeof(G));
   if (!generic) pack_fragments(w16, rgb_in, frags);
+  if (hot_width) pack_fragments_width(w16, (int)hot_width, frags_hot);
   // the generic description + fragments: the generic instance's model, and -- for a wide model -- what the stage
   // entry points nrf_encode_dir / nrf_mlp_forward run on (rows of the padded widths)
   if (generic || wide) {
@@ -877,6 +931,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   if (generic || wide) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
   if (wide) HIP_TRY(upload(&c->d_wfrag_gen, frags_gen.data(), frags_gen.size() * 2));
+  if (hot_width) HIP_TRY(upload(&c->d_wfrag_hot, frags_hot.data(), frags_hot.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -924,6 +979,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.gen = (const GenModel*)c->d_gen;
   M.gen_wave_bytes = gen_wave_bytes;
   M.gen_frag_bytes = generic ? (uint32_t)(frags.size() * 2) : 0u;
+  M.hot_width = hot_width;
+  M.wfrag_hot = (const uint4*)c->d_wfrag_hot;
+  c->model_hot_width = hot_width;
   c->gen = G;
   // the density grid of the snapshot (nerf_render.cu:447-466) -- or none yet: nrf_generate_density_grid evaluates it
   // from the network (NerfRender::generate_density_grid); until then the model cannot be rendered
@@ -1421,10 +1479,10 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
 }
 
 // Diagnostic (not part of include/nerfhip.h): which kernel instance renders the loaded model -- 0 register-resident,
-// 1 generic, 2 wide; + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
+// 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons); + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
 extern "C" int nrf_debug_instance(nrf_context* c) {
   if (!c || !c->model_loaded) return -1;
-  return (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0)) + (c->dm.persistent ? 16 : 0);
+  return (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0))) + (c->dm.persistent ? 16 : 0);
 }
 
 // Diagnostic build: entry / exit stamps (s_memtime) of the persistent kernel's waves, 2 x n values.

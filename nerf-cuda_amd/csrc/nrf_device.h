@@ -79,6 +79,18 @@ enum : int {
   N_FRAGS_WIDE_ALL = 32
 };
 constexpr int RK_WIDE = 3;  // K steps of the wide instance's first rgb layer
+// The same fragment order for the other widths of tcnn's FullyFusedMLP (16 / 32 / 128 neurons, T/src/fully_fused_mlp.cu:700-725;
+// one hidden layer in the density MLP, two in the rgb MLP as in base.json): a layer of W outputs is MT = W / 16 fragments per
+// K step, a layer of W inputs KS = ceil(W / 32) K steps (W = 16: one step whose upper half is zero).  For W = 64 these are
+// the FRAG_* values above.
+template <int W>
+struct MlpShape {
+  static_assert(W == 16 || W == 32 || W == 64 || W == 128, "FullyFusedMLP widths");
+  static constexpr int MT = W / 16, KS = (W + 31) / 32;
+  static constexpr int D0 = 0, D1 = MT, R0 = MT + KS, R1 = 2 * MT + KS, R2 = 2 * MT + KS + MT * KS, N = 2 * MT + 2 * KS + MT * KS;
+};
+static_assert(MlpShape<64>::D1 == FRAG_D1 && MlpShape<64>::R0 == FRAG_R0 && MlpShape<64>::R1 == FRAG_R1 && MlpShape<64>::R2 == FRAG_R2 &&
+                  MlpShape<64>::N == N_FRAGS, "MlpShape<64> is the base.json layout");
 
 struct DevModel {
   const uint32_t* grid;      // half2 entries
@@ -123,6 +135,11 @@ struct DevModel {
   uint32_t gen_frag_bytes;  // generic instance: bytes of its weight fragments
   uint32_t gen_weights_lds; // generic instance, persistent kernel: the fragments are staged in LDS (they fit beside rows and tables)
   uint32_t n_cus;           // compute units of the device: workgroups of the persistent kernel
+  // a model of the base.json SHAPE with 16 / 32 / 128 neurons: `generic` is set (stage entry points, the per-strip kernel and
+  // the density-grid generation run the generic instance), but its frames are rendered by a register-resident instance of
+  // the persistent kernel of that width, from fragments in the MlpShape<width> order
+  uint32_t hot_width;       // 0, 16, 32 or 128
+  const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.
@@ -766,6 +783,11 @@ struct LdsFrags {
   int lane;
   __device__ __forceinline__ half8_t operator()(int f) const { return frag_load(wl, f >= FRAG_R0X ? f - FRAG_R0X + N_FRAGS : f, lane); }
 };
+struct LdsFragsPlain {  // the other widths (MlpShape<W>): fragment f of the LDS copy, no wide-instance remapping
+  const uint4* wl;
+  int lane;
+  __device__ __forceinline__ half8_t operator()(int f) const { return frag_load(wl, f, lane); }
+};
 // Outputs of mlp_tiles for NT tiles of 16 samples (fp16 values, as the reference's network_output holds them):
 //   rg[n], bx[n]  packed halves (r, g) and (b, row 3 of the rgb output) of sample c of tile n -- valid in lanes g == 0
 //   sigma         extract_density's activation of density row 0 (nerf_network.h:49-61), for sample c of tile g --
@@ -784,32 +806,37 @@ struct MlpOut {
 // (An explicit issue order for this body -- one MFMA, then k vector instructions, by __builtin_amdgcn_sched_group_barrier -- was
 //  measured in round 3 and removed: k = 2 equals the compiler's own schedule, k = 3 / 4 are 5-7 % slower,
 //  profiles/r03/mlp_interleave.txt.)
-template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags, int RK = 1>
+template <int NT, int D0_BASE = FRAG_D0, typename Frags = LdsFrags, int RK = 1, int W = 64>
 __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
                                           bool rgb_sigmoid = false, const half8_t (*dirx)[RK_WIDE - 1] = nullptr) {
   static_assert(NT == 1 || NT == 2 || NT == 4, "tiles per pass");
+  using S = MlpShape<W>;
+  constexpr int MT = S::MT, KS = S::KS;
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
-  float4_t acc[NT][4];
-  half8_t hb[NT][2];
-  // ---- density layer 0: 32 -> 64
+  float4_t acc[NT][MT];
+  half8_t hb[NT][KS];
+  // a layer's MT accumulator fragments -> the next layer's KS B fragments (W = 16: the upper half of the one step is zero)
+  auto repack = [&]() {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) hb[n][s] = pack_acc(acc[n][2 * s], 2 * s + 1 < MT ? acc[n][2 * s + 1] : zero);
+  };
+  // ---- density layer 0: 32 -> W
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
     const half8_t a = frag(D0_BASE + m);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, feat[n], zero);
   }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
-  }
-  // ---- density layer 1: 64 -> 16
+  repack();
+  // ---- density layer 1: W -> 16
   float4_t dacc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) dacc[n] = zero;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const half8_t a = frag(FRAG_D1 + s);
+  for (int s = 0; s < KS; ++s) {
+    const half8_t a = frag(S::D1 + s);
 #pragma unroll
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
   }
@@ -842,14 +869,15 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
   }
   // extract_density: fp32 activation (Exponential) of the fp16 density output, stored as fp16
   out.sigma = (half_t)expf((float)bits_h2(dall).x);
-  // ---- rgb layer 0: 32 (or 32 RK) -> 64
+  // ---- rgb layer 0: 32 (or 32 RK) -> W
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const half8_t a = frag(FRAG_R0 + m);
+  for (int m = 0; m < MT; ++m) {
+    const half8_t a = frag(S::R0 + m);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, rin[n], zero);
   }
   if constexpr (RK > 1) {
+    static_assert(W == 64, "the wide form exists for 64 neurons");
 #pragma unroll
     for (int s = 1; s < RK; ++s)
 #pragma unroll
@@ -859,34 +887,26 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
         for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, dirx[n][s - 1], acc[n][m]);
       }
   }
+  repack();
+  // ---- rgb layer 1: W -> W
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
-  }
-  // ---- rgb layer 1: 64 -> 64
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n][m] = zero;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8_t a = frag(FRAG_R1 + 2 * m + s);
+    for (int s = 0; s < KS; ++s) {
+      const half8_t a = frag(S::R1 + KS * m + s);
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, hb[n][s], acc[n][m]);
     }
   }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    hb[n][0] = pack_acc(acc[n][0], acc[n][1]);
-    hb[n][1] = pack_acc(acc[n][2], acc[n][3]);
-  }
-  // ---- rgb layer 2: 64 -> 16 (3 used)
+  repack();
+  // ---- rgb layer 2: W -> 16 (3 used)
 #pragma unroll
   for (int n = 0; n < NT; ++n) dacc[n] = zero;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const half8_t a = frag(FRAG_R2 + s);
+  for (int s = 0; s < KS; ++s) {
+    const half8_t a = frag(S::R2 + s);
 #pragma unroll
     for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
   }

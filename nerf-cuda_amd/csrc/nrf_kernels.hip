@@ -42,7 +42,13 @@ static_assert(sizeof(WaveLds) == 2048 + 24 * SLOTS, "WaveLds layout");
 
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // network instances of the kernels below
-enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2 };
+// NET_W16 / NET_W32 / NET_W128: the register-resident instance for the other widths of tcnn's FullyFusedMLP (persistent kernel only)
+enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5 };
+__host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 16 : (net == NET_W32 ? 32 : (net == NET_W128 ? 128 : 64)); }
+__host__ __device__ constexpr int net_wfrag_bytes(int net) {  // weight fragments a workgroup keeps in LDS
+  return net == NET_WIDE ? (N_FRAGS + 4 * (RK_WIDE - 1)) * 1024
+       : net == NET_W16 ? MlpShape<16>::N * 1024 : net == NET_W32 ? MlpShape<32>::N * 1024 : net == NET_W128 ? MlpShape<128>::N * 1024 : N_FRAGS * 1024;
+}
 constexpr int LDS_WFRAG_WIDE_BYTES = (N_FRAGS + 4 * (RK_WIDE - 1)) * 64 * 16;  // 28672: + the extra K steps of the first rgb layer
 constexpr int LDS_RAYD_BYTES = 64 * 3 * 4;  // wide instance: 0.5 d + 0.5 of every ray of a wave (fp32)
 constexpr int LDS_LEVEL_BYTES = 16 * (int)sizeof(LevelParams);  // 512
@@ -92,7 +98,7 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
 // RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
 // evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
-template <int NT, int RK = 1, bool FAST = false>
+template <int NT, int RK = 1, bool FAST = false, int WD = 64>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale) {
   const int g = lane >> 4, c = lane & 15;
@@ -150,7 +156,8 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   MlpOut<NT> o;
-  mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
+  if constexpr (WD == 64) mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
+  else mlp_tiles<NT, 0, LdsFragsPlain, 1, WD>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
   if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -229,10 +236,12 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
     for (int base = 0; base < S; base += GEN_SAMPLES)  // wave-uniform
       gen_network_from_lds<false>(M, G, lvs, W, Lw, S, base, lane, density_scale);
   } else {
-    for (int base = 0; base < S; base += 16 * NT_MAX) {  // wave-uniform
+    constexpr int WD = net_width(NET);
+    constexpr int NTM = WD == 128 ? 1 : NT_MAX;  // 128 neurons: eight accumulator fragments per tile -- one tile per pass
+    for (int base = 0; base < S; base += 16 * NTM) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      if (ntile <= 1) network_from_lds<1, RK, FAST>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
-      else network_from_lds<NT_MAX, RK, FAST>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      else network_from_lds<NTM, RK, FAST, WD>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
     }
   }
 }
@@ -269,7 +278,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.gen.wfrag = M.wfrag;
     m.tables = act + n_waves * gen_act_bytes(G);
   } else {
-    constexpr int WF = NET == NET_WIDE ? LDS_WFRAG_WIDE_BYTES : LDS_WFRAG_BYTES;
+    constexpr int WF = net_wfrag_bytes(NET);
     m.wl = reinterpret_cast<uint4*>(smem);
     m.lvs = reinterpret_cast<LevelParams*>(smem + WF);
     m.W = reinterpret_cast<WaveLds*>(smem + WF + LDS_LEVEL_BYTES) + wave;
@@ -285,6 +294,10 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
 // copies the instance's weight fragments into LDS (hot: 0 .. N_FRAGS - 1; wide: followed by FRAG_R0X ..)
 template <int NET>
 __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
+  if constexpr (net_width(NET) != 64) {
+    for (int i = threadIdx.x; i < net_wfrag_bytes(NET) / 16; i += blockDim.x) wl[i] = M.wfrag_hot[i];
+    return;
+  }
   for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
   if constexpr (NET == NET_WIDE)
     for (int i = threadIdx.x; i < 4 * (RK_WIDE - 1) * 64; i += blockDim.x) wl[N_FRAGS * 64 + i] = M.wfrag[FRAG_R0X * 64 + i];
@@ -952,7 +965,7 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
 // length of one device atomic -- for the wave of its workgroup that is fetching the next strip.
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
-__host__ __device__ constexpr int persist_waves(int net) { return net == NET_HOT ? 16 : 12; }
+__host__ __device__ constexpr int persist_waves(int net) { return (net == NET_GENERIC || net == NET_WIDE) ? 12 : 16; }
 constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80;  // q_begin of every view + the total; the workgroup's block counter; HelpLds
 static_assert(sizeof(HelpLds) <= 80, "HelpLds lives behind the scheduler word");
 
@@ -1811,7 +1824,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     VB.class_cols = (strips_x + N - 1) / N;  // a row holds at most this many of the rank's strips
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int waves = (int)M.persist_waves;
-    const int lds = render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) +
+    const int lds = (M.hot_width ? render_persistent_lds_width_bytes((int)M.hot_width)
+                                 : render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves)) +
                     4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) +
                     (M.gen_weights_lds ? 16 + (int)M.gen_frag_bytes : 0);
     const long long tiles = (long long)P.n_local_tiles * VB.n_views;
@@ -1846,7 +1860,11 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     else NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, false);                                                                   \
   } while (0)
 #define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G), false)
-    if (M.generic) {  // (the generic instance has one march form)
+    if (M.hot_width) {  // 16 / 32 / 128 neurons in the base.json shape: the register-resident instance of that width
+      if (M.hot_width == 16) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_GENERIC); }
+      else if (M.hot_width == 32) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_GENERIC); }
+      else { if (unit) NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_GENERIC); }
+    } else if (M.generic) {  // (the generic instance has one march form)
       if (waves == 12 && M.gen_weights_lds) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12, true);
       else if (waves == 12) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12, false);
       else if (M.gen_weights_lds) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 8, true);
@@ -2092,6 +2110,12 @@ int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t 
   if (wide) return LDS_WFRAG_WIDE_BYTES + LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + LDS_RAYD_BYTES) + LDS_QUEUE_BYTES;
   return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + waves * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
 }
+// ... of the 16-wave workgroup of a width instance (NET_W16 / NET_W32 / NET_W128)
+int render_persistent_lds_width_bytes(int width) {
+  const int net = width == 16 ? NET_W16 : (width == 32 ? NET_W32 : NET_W128);
+  return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + 16 * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
+}
+int render_width_frags(int width) { return width == 16 ? MlpShape<16>::N : (width == 32 ? MlpShape<32>::N : (width == 128 ? MlpShape<128>::N : N_FRAGS)); }
 int render_persistent_waves(uint32_t generic, uint32_t wide) { return persist_waves(generic ? NET_GENERIC : (wide ? NET_WIDE : NET_HOT)); }
 int render_wide_lds_fixed_bytes() { return LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }

@@ -12,12 +12,18 @@ poses = np.stack([syn.orbit_pose(45.0 * (i % 8), 30.0) for i in range(V)])
 SHAPES = [
     ("base.json shape (register-resident)", {}),
     ("Frequency-12 directions (wide)", dict(dir_otype="Frequency", n_frequencies=12)),
-    ("32 neurons (generic)", dict(n_neurons=32)),
-    ("128 neurons (generic)", dict(n_neurons=128)),
+    ("16 neurons (width instance when persistent)", dict(n_neurons=16)),
+    ("32 neurons (width instance when persistent)", dict(n_neurons=32)),
+    ("128 neurons (width instance when persistent)", dict(n_neurons=128)),
+    ("32 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=32, _env={"NRF_WIDTH_INSTANCES": "0"})),
+    ("128 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=128, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("F = 4 x 8 levels, Smoothstep (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep")),
     ("SH degree 6 (generic)", dict(sh_degree=6)),
 ]
 for name, kw in SHAPES:
+    kw = dict(kw)
+    env = kw.pop("_env", {})
+    os.environ.update(env)
     desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128, **kw)
     res = []
     for persistent in ("0", "1"):
@@ -34,5 +40,7 @@ for name, kw in SHAPES:
         dt = (time.perf_counter() - t0) / reps
         res.append((dt / V * 1e3, samples / dt / 1e6))
         c.close()
-    print(f"{name:44s} per strip {res[0][0]:7.3f} ms/view {res[0][1]:7.0f} Msamples/s | persistent {res[1][0]:7.3f} ms/view {res[1][1]:7.0f} Msamples/s "
+    for k in env:
+        os.environ.pop(k, None)
+    print(f"{name:48s} per strip {res[0][0]:7.3f} ms/view {res[0][1]:7.0f} Msamples/s | persistent {res[1][0]:7.3f} ms/view {res[1][1]:7.0f} Msamples/s "
           f"({100 * (res[0][0] / res[1][0] - 1):+.0f} %)", flush=True)

@@ -373,3 +373,71 @@ def test_wide_and_generic_instances_shard_batch_and_group_like_the_hot_one(ctx, 
         rgba, depth = g.read_view_f32(i)
         np.testing.assert_array_equal(rgba, singles[i][0])
     g.close()
+
+
+@pytest.mark.parametrize("width", [16, 32, 128])
+def test_other_mlp_widths_render_in_a_register_resident_instance(width):
+    """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons (T/src/fully_fused_mlp.cu:700-725).  In the base.json shape the
+    other three widths have register-resident instances of the persistent kernel too (NET_W16 / NET_W32 / NET_W128: the MFMA
+    chain over MlpShape<W> fragments); stage entry points and the per-strip kernel stay generic.  Frames: against the oracle
+    at the MLP tolerance, against the generic instance of the same model (NRF_WIDTH_INSTANCES=0) likewise (the two sum in
+    different K orders), batches and host frames bit-identical to single renders, sharded too."""
+    import os
+
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, n_neurons=width)
+    o = op.Oracle(desc)
+    W, H = 120, 88
+    cam = syn.default_camera(W, H)
+    poses = [syn.orbit_pose(215, 25), syn.orbit_pose(40, -10), syn.orbit_pose(120, 60)]
+    frames = {}
+    for env in ("1", "0"):
+        os.environ["NRF_WIDTH_INSTANCES"] = env
+        try:
+            c = nh.NerfHip(0)
+        finally:
+            os.environ.pop("NRF_WIDTH_INSTANCES", None)
+        c.load_model(desc)
+        assert _instance(c) == (3 if env == "1" else 1)
+        c.set_resolution(W, H)
+        c.set_max_views(3)
+        out = []
+        for p in poses:
+            c.render(cam, p)
+            out.append(c.read_f32())
+        frames[env] = out
+        if env == "1":
+            c.render_views([cam] * 3, poses)
+            for v in range(3):
+                a, b = c.read_view_f32(v)
+                np.testing.assert_array_equal(a, out[v][0])
+                np.testing.assert_array_equal(b, out[v][1])
+            rgb, d8 = c.render_host_u8([cam] * 3, poses)
+            for v in range(3):
+                c.render(cam, poses[v])
+                r8, dd8 = c.read_u8()
+                np.testing.assert_array_equal(rgb[v], r8)
+                np.testing.assert_array_equal(d8[v], dd8)
+            # two shards + untile reproduce the frame
+            import torch as _t
+            tps = nh.tiles_per_shard(W, H, 2)
+            gathered = _t.zeros((2, tps * 64, 4), device="cuda")
+            for idx in range(2):
+                opts = nh.default_options(); opts.shard_index, opts.shard_count = idx, 2
+                c.set_options(opts)
+                f = c.render(cam, poses[0])
+                sh = np.zeros((tps * 64, 4), np.float32)
+                got_rgba = np.empty((f.n_tiles * 64, 4), np.float32); got_depth = np.empty((f.n_tiles * 64,), np.float32)
+                nh._check(c.lib.nrf_read_shard_f32(c.h, got_rgba.ctypes.data, got_depth.ctypes.data))
+                sh[:f.n_tiles * 64] = got_rgba
+                gathered[idx] = _t.from_numpy(sh).cuda()
+            c.set_options(nh.default_options())
+            np.testing.assert_array_equal(nh.untile_numpy(gathered.cpu().numpy(), W, H), out[0][0])
+        c.close()
+    for v, p in enumerate(poses):
+        want, wdepth, _ = o.render(cam, p, W, H, schedule=op.SCHED_PER_RAY)
+        for env in ("1", "0"):
+            rgba, depth = frames[env][v]
+            assert np.abs(rgba - want).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0, (width, env, v)
+            assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
+        assert np.abs(frames["1"][v][0] - frames["0"][v][0]).max() <= 2.0 / 255.0
+    assert frames["1"][0][0][..., 3].max() > 0.5  # the object is in view
