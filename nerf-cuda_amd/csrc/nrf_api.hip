@@ -202,6 +202,7 @@ struct nrf_context {
   void* d_gen = nullptr;
   void* d_wfrag_gen = nullptr;  // wide models: generic-layout fragments for the stage entry points
   uint32_t model_hot_width = 0; // the loaded model's width if it has a register-resident width instance (else 0)
+  bool model_wide_sh = false;   // ... or the NET_WIDE_SH form (SH degree 5..8)
   void* d_wfrag_hot = nullptr;  // 16 / 32 / 128-neuron models of the base.json shape: fragments of their register-resident instance
   GenModel gen{};  // host copy of the generic instance's description (valid when dm.generic)
   std::vector<float> host_grid;  // the float density grid the march tables were built from
@@ -592,18 +593,20 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   M.persist_waves = 0;
   M.n_cus = (uint32_t)c->n_cus;
   M.hot_width = c->model_hot_width;  // (decided again for every grid: nrf_generate_density_grid calls this too)
+  M.wide_sh = c->model_wide_sh ? 1u : 0u;
   bool width_instance = false;  // the model's frames come from the register-resident instance of its width (persistent kernel only)
-  if (c->allow_persistent && M.lds_coarse_words > 0 && M.hot_width) {
+  if (c->allow_persistent && M.lds_coarse_words > 0 && (M.hot_width || M.wide_sh)) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
-    if ((size_t)render_persistent_lds_width_bytes((int)M.hot_width) + tables <= 160u * 1024u) {
+    const size_t fixed = M.wide_sh ? (size_t)render_persistent_lds_widesh_bytes() : (size_t)render_persistent_lds_width_bytes((int)M.hot_width);
+    if (fixed + tables <= 160u * 1024u) {
       M.persistent = 1;
-      M.persist_waves = 16;
+      M.persist_waves = M.wide_sh ? 8 : 16;
       M.gen_weights_lds = 0;
       M.lds_dilated_words = (uint32_t)dilated.size();
       width_instance = true;
     }
   }
-  if (!width_instance) M.hot_width = 0;  // (the tables do not fit beside its workgroup: the generic instance renders)
+  if (!width_instance) M.hot_width = M.wide_sh = 0;  // (the tables do not fit beside its workgroup: the generic instance renders)
   if (c->allow_persistent && M.lds_coarse_words > 0 && !width_instance) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
     // generic instance: 12 waves with the weight fragments in LDS, 12 waves without, 8 with, 8 without -- the first that fits
@@ -863,11 +866,19 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                                     (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                                     d->sigma_activation == NRF_ACT_EXPONENTIAL;
   const uint32_t hot_width = (base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u;
+  // ... and for its direction encoding: SphericalHarmonics of degree 5..8 (32..64 padded values) keeps the register-resident
+  // MLPs in the persistent kernel's NET_WIDE_SH form (per-ray rows of coefficients in LDS)
+  const bool wide_sh = !generic_grid && F == 2 && L == 16 && Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 &&
+                       d->dir_encoding == NRF_DIR_SH && dir_w > 16 && dir_w <= 64 && d->interpolation == NRF_INTERP_LINEAR &&
+                       d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
+                       (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
+                       d->sigma_activation == NRF_ACT_EXPONENTIAL && c->allow_width_instances;
   std::vector<_Float16> frags, frags_gen, frags_hot;
   GenModel G;
   std::memset(&G, 0, sizeof(G));
   if (!generic) pack_fragments(w16, rgb_in, frags);
   if (hot_width) pack_fragments_width(w16, (int)hot_width, frags_hot);
+  if (wide_sh) pack_fragments(w16, rgb_in, frags_hot);  // the wide layout: first rgb layer in RK_WIDE K steps
   // the generic description + fragments: the generic instance's model, and -- for a wide model -- what the stage
   // entry points nrf_encode_dir / nrf_mlp_forward run on (rows of the padded widths)
   if (generic || wide) {
@@ -931,7 +942,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   if (generic || wide) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
   if (wide) HIP_TRY(upload(&c->d_wfrag_gen, frags_gen.data(), frags_gen.size() * 2));
-  if (hot_width) HIP_TRY(upload(&c->d_wfrag_hot, frags_hot.data(), frags_hot.size() * 2));
+  if (hot_width || wide_sh) HIP_TRY(upload(&c->d_wfrag_hot, frags_hot.data(), frags_hot.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -982,6 +993,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.hot_width = hot_width;
   M.wfrag_hot = (const uint4*)c->d_wfrag_hot;
   c->model_hot_width = hot_width;
+  c->model_wide_sh = wide_sh;
+  M.wide_sh = wide_sh ? 1u : 0u;
+  M.dir_w = dir_w;
   c->gen = G;
   // the density grid of the snapshot (nerf_render.cu:447-466) -- or none yet: nrf_generate_density_grid evaluates it
   // from the network (NerfRender::generate_density_grid); until then the model cannot be rendered
@@ -1479,10 +1493,10 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
 }
 
 // Diagnostic (not part of include/nerfhip.h): which kernel instance renders the loaded model -- 0 register-resident,
-// 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons); + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
+// 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons), 4 its wide form for SH degree 5..8; + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
 extern "C" int nrf_debug_instance(nrf_context* c) {
   if (!c || !c->model_loaded) return -1;
-  return (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0))) + (c->dm.persistent ? 16 : 0);
+  return (c->dm.wide_sh ? 4 : (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0)))) + (c->dm.persistent ? 16 : 0);
 }
 
 // Diagnostic build: entry / exit stamps (s_memtime) of the persistent kernel's waves, 2 x n values.

@@ -139,7 +139,9 @@ struct DevModel {
   // the density-grid generation run the generic instance), but its frames are rendered by a register-resident instance of
   // the persistent kernel of that width, from fragments in the MlpShape<width> order
   uint32_t hot_width;       // 0, 16, 32 or 128
-  const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4
+  const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4; wide_sh: the wide layout (N_FRAGS_WIDE_ALL fragments)
+  uint32_t wide_sh;         // SphericalHarmonics of degree 5..8 on the base.json shape: NET_WIDE_SH renders the frames (persistent kernel)
+  uint32_t dir_w;           // padded width of the direction encoding (16 .. 80)
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.

@@ -43,10 +43,14 @@ static_assert(sizeof(WaveLds) == 2048 + 24 * SLOTS, "WaveLds layout");
 constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // network instances of the kernels below
 // NET_W16 / NET_W32 / NET_W128: the register-resident instance for the other widths of tcnn's FullyFusedMLP (persistent kernel only)
-enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5 };
+// NET_WIDE_SH: the wide form for SphericalHarmonics of degree 5..8 (32..64 direction values): the entries beyond the first sixteen
+// are computed once per ray into an LDS row (not per sample in-lane as for Frequency) -- persistent kernel only
+enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6 };
+constexpr int SH_ROW_HALVES = 72;                     // a ray's row: up to 64 direction values + 8 halves of padding (rows 4 banks apart)
+constexpr int LDS_SHROW_BYTES = 64 * SH_ROW_HALVES * 2;  // 9216 per wave
 __host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 16 : (net == NET_W32 ? 32 : (net == NET_W128 ? 128 : 64)); }
 __host__ __device__ constexpr int net_wfrag_bytes(int net) {  // weight fragments a workgroup keeps in LDS
-  return net == NET_WIDE ? (N_FRAGS + 4 * (RK_WIDE - 1)) * 1024
+  return (net == NET_WIDE || net == NET_WIDE_SH) ? (N_FRAGS + 4 * (RK_WIDE - 1)) * 1024
        : net == NET_W16 ? MlpShape<16>::N * 1024 : net == NET_W32 ? MlpShape<32>::N * 1024 : net == NET_W128 ? MlpShape<128>::N * 1024 : N_FRAGS * 1024;
 }
 constexpr int LDS_WFRAG_WIDE_BYTES = (N_FRAGS + 4 * (RK_WIDE - 1)) * 64 * 16;  // 28672: + the extra K steps of the first rgb layer
@@ -98,9 +102,11 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // hash levels {g, 4+g, 8+g, 12+g}, direction entries 4g..4g+3.
 // RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
 // evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
-template <int NT, int RK = 1, bool FAST = false, int WD = 64>
+// SHROWS (NET_WIDE_SH): those entries come from the ray's LDS row instead (rows = the wave's rows, SH_ROW_HALVES apart).
+template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
-                                                 const float* rayd, int S, int base, int lane, float density_scale) {
+                                                 const float* rayd, int S, int base, int lane, float density_scale,
+                                                 const half_t* rows = nullptr) {
   const int g = lane >> 4, c = lane & 15;
   half8_t feat[NT];
   half4_t dirf[NT];
@@ -141,7 +147,14 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp<FAST>(gv[jl], gf[jl]);
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
-      if constexpr (RK > 1) {
+      if constexpr (RK > 1 && SHROWS) {
+        const half8_t z8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+        for (int s = 1; s < RK; ++s) {
+          const uint32_t e0 = 32u * s - 16u + 8u * (uint32_t)g;  // first direction entry of this lane's B fragment
+          dirx[n][s - 1] = e0 < M.dir_w ? *reinterpret_cast<const half8_t*>(rows + (size_t)ray * SH_ROW_HALVES + e0) : z8;  // (zero weights beyond)
+        }
+      } else if constexpr (RK > 1) {
         const float dx = rayd[3 * ray], dy = rayd[3 * ray + 1], dz = rayd[3 * ray + 2];
 #pragma unroll
         for (int s = 1; s < RK; ++s) dirx[n][s - 1] = dir_entries8(M.n_frequencies, 32u * s - 16u + 8u * (uint32_t)g, dx, dy, dz);
@@ -230,7 +243,8 @@ __device__ __forceinline__ void gen_network_from_lds(const DevModel& M, const Ge
 template <int NET, bool FAST = false>
 __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const GenLds& Lw, int S, int lane, float density_scale) {
-  constexpr int RK = NET == NET_WIDE ? RK_WIDE : 1;
+  constexpr int RK = (NET == NET_WIDE || NET == NET_WIDE_SH) ? RK_WIDE : 1;
+  constexpr bool SHR = NET == NET_WIDE_SH;
   if constexpr (NET == NET_GENERIC) {
     const GenModel& G = *M.gen;
     for (int base = 0; base < S; base += GEN_SAMPLES)  // wave-uniform
@@ -240,8 +254,8 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
     constexpr int NTM = WD == 128 ? 1 : NT_MAX;  // 128 neurons: eight accumulator fragments per tile -- one tile per pass
     for (int base = 0; base < S; base += 16 * NTM) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
-      else network_from_lds<NTM, RK, FAST, WD>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale);
+      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
+      else network_from_lds<NTM, RK, FAST, WD, SHR>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
     }
   }
 }
@@ -286,7 +300,8 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
     m.gen.wfrag = nullptr;
     unsigned char* after = smem + WF + LDS_LEVEL_BYTES + n_waves * (int)sizeof(WaveLds);
     m.gen.rayd = NET == NET_WIDE ? reinterpret_cast<float*>(after + wave * LDS_RAYD_BYTES) : nullptr;
-    m.tables = after + (NET == NET_WIDE ? n_waves * LDS_RAYD_BYTES : 0);
+    if constexpr (NET == NET_WIDE_SH) m.gen.dir = reinterpret_cast<half_t*>(after + wave * LDS_SHROW_BYTES);  // the wave's per-ray SH rows
+    m.tables = after + (NET == NET_WIDE ? n_waves * LDS_RAYD_BYTES : (NET == NET_WIDE_SH ? n_waves * LDS_SHROW_BYTES : 0));
   }
   return m;
 }
@@ -296,6 +311,11 @@ template <int NET>
 __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
   if constexpr (net_width(NET) != 64) {
     for (int i = threadIdx.x; i < net_wfrag_bytes(NET) / 16; i += blockDim.x) wl[i] = M.wfrag_hot[i];
+    return;
+  }
+  if constexpr (NET == NET_WIDE_SH) {  // the wide layout (fragments 0 .. 19, then FRAG_R0X ..) of a model whose other kernels are generic
+    for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag_hot[i];
+    for (int i = threadIdx.x; i < 4 * (RK_WIDE - 1) * 64; i += blockDim.x) wl[N_FRAGS * 64 + i] = M.wfrag_hot[FRAG_R0X * 64 + i];
     return;
   }
   for (int i = threadIdx.x; i < N_FRAGS * 64; i += blockDim.x) wl[i] = M.wfrag[i];
@@ -932,6 +952,14 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
     lm.gen.rayd[3 * lane] = u0;  // encoded per pass, for the pass's samples (gen_network_from_lds)
     lm.gen.rayd[3 * lane + 1] = u1;
     lm.gen.rayd[3 * lane + 2] = u2;
+  } else if constexpr (NET == NET_WIDE_SH) {
+    // every SH coefficient of the ray, once (tcnn's padded row: leading ones, then degree^2 values: gen_encode_dir); the
+    // first sixteen entries are also what K step 0 of the first rgb layer reads from dirf, as in every other instance
+    half_t* row = lm.gen.dir + (size_t)lane * SH_ROW_HALVES;
+    gen_encode_dir(M, *M.gen, u0, u1, u2, row);
+    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(row);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lm.W->dirf[lane][j] = r32[j];
   } else {
     half_t e[16];
     encode_dir16(M, u0, u1, u2, e);
@@ -965,7 +993,7 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
 // length of one device atomic -- for the wave of its workgroup that is fetching the next strip.
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
-__host__ __device__ constexpr int persist_waves(int net) { return (net == NET_GENERIC || net == NET_WIDE) ? 12 : 16; }
+__host__ __device__ constexpr int persist_waves(int net) { return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE) ? 12 : 16); }
 constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80;  // q_begin of every view + the total; the workgroup's block counter; HelpLds
 static_assert(sizeof(HelpLds) <= 80, "HelpLds lives behind the scheduler word");
 
@@ -1824,7 +1852,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     VB.class_cols = (strips_x + N - 1) / N;  // a row holds at most this many of the rank's strips
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int waves = (int)M.persist_waves;
-    const int lds = (M.hot_width ? render_persistent_lds_width_bytes((int)M.hot_width)
+    const int lds = (M.wide_sh ? render_persistent_lds_widesh_bytes() : M.hot_width ? render_persistent_lds_width_bytes((int)M.hot_width)
                                  : render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves)) +
                     4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) +
                     (M.gen_weights_lds ? 16 + (int)M.gen_frag_bytes : 0);
@@ -1860,7 +1888,9 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     else NRF_LAUNCH_PERSISTENT_O(G, U, WV, WL, false);                                                                   \
   } while (0)
 #define NRF_LAUNCH_PERSISTENT(G, U) NRF_LAUNCH_PERSISTENT_W(G, U, persist_waves(G), false)
-    if (M.hot_width) {  // 16 / 32 / 128 neurons in the base.json shape: the register-resident instance of that width
+    if (M.wide_sh) {    // SH degree 5..8 on the base.json shape: the wide form with per-ray rows
+      if (unit) NRF_LAUNCH_PERSISTENT(NET_WIDE_SH, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_WIDE_SH, MARCH_GENERIC);
+    } else if (M.hot_width) {  // 16 / 32 / 128 neurons in the base.json shape: the register-resident instance of that width
       if (M.hot_width == 16) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_GENERIC); }
       else if (M.hot_width == 32) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_GENERIC); }
       else { if (unit) NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_GENERIC); }
@@ -2114,6 +2144,9 @@ int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t 
 int render_persistent_lds_width_bytes(int width) {
   const int net = width == 16 ? NET_W16 : (width == 32 ? NET_W32 : NET_W128);
   return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + 16 * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
+}
+int render_persistent_lds_widesh_bytes() {  // the 8-wave workgroup of NET_WIDE_SH without its march tables
+  return net_wfrag_bytes(NET_WIDE_SH) + LDS_LEVEL_BYTES + persist_waves(NET_WIDE_SH) * ((int)sizeof(WaveLds) + LDS_SHROW_BYTES) + LDS_QUEUE_BYTES;
 }
 int render_width_frags(int width) { return width == 16 ? MlpShape<16>::N : (width == 32 ? MlpShape<32>::N : (width == 128 ? MlpShape<128>::N : N_FRAGS)); }
 int render_persistent_waves(uint32_t generic, uint32_t wide) { return persist_waves(generic ? NET_GENERIC : (wide ? NET_WIDE : NET_HOT)); }

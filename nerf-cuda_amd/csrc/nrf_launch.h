@@ -37,6 +37,7 @@ int render_lds_bytes();
 int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t gen_wave_bytes, int waves);
 int render_persistent_waves(uint32_t generic, uint32_t wide);
 int render_persistent_lds_width_bytes(int width);  // LDS of a width instance's persistent workgroup (16 waves) without its march tables
+int render_persistent_lds_widesh_bytes();
 int render_width_frags(int width);                 // weight fragments of MlpShape<width>
 int render_lds_table_max_bytes();
 int render_wide_lds_fixed_bytes();  // wide instance: LDS of render_kernel without the march tables

@@ -18,7 +18,9 @@ SHAPES = [
     ("32 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=32, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("128 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=128, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("F = 4 x 8 levels, Smoothstep (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep")),
-    ("SH degree 6 (generic)", dict(sh_degree=6)),
+    ("SH degree 6 (wide-SH form when persistent)", dict(sh_degree=6)),
+    ("SH degree 8 (wide-SH form when persistent)", dict(sh_degree=8)),
+    ("SH degree 6, NRF_WIDTH_INSTANCES=0 (generic)", dict(sh_degree=6, _env={"NRF_WIDTH_INSTANCES": "0"})),
 ]
 for name, kw in SHAPES:
     kw = dict(kw)

@@ -375,16 +375,21 @@ def test_wide_and_generic_instances_shard_batch_and_group_like_the_hot_one(ctx, 
     g.close()
 
 
-@pytest.mark.parametrize("width", [16, 32, 128])
-def test_other_mlp_widths_render_in_a_register_resident_instance(width):
+@pytest.mark.parametrize("shape", ["w16", "w32", "w128", "sh5", "sh6", "sh7", "sh8"])
+def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shape):
     """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons (T/src/fully_fused_mlp.cu:700-725).  In the base.json shape the
     other three widths have register-resident instances of the persistent kernel too (NET_W16 / NET_W32 / NET_W128: the MFMA
     chain over MlpShape<W> fragments); stage entry points and the per-strip kernel stay generic.  Frames: against the oracle
     at the MLP tolerance, against the generic instance of the same model (NRF_WIDTH_INSTANCES=0) likewise (the two sum in
-    different K orders), batches and host frames bit-identical to single renders, sharded too."""
+    different K orders), batches and host frames bit-identical to single renders, sharded too.
+    SphericalHarmonics of degree 5..8 (32..64 padded direction values) likewise keep the register-resident MLPs: NET_WIDE_SH,
+    the wide form with every coefficient of a ray computed once into an LDS row (instance 4)."""
     import os
 
-    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, n_neurons=width)
+    kw = dict(n_neurons=int(shape[1:])) if shape[0] == "w" else dict(sh_degree=int(shape[2:]))
+    width = shape
+    want_instance = 3 if shape[0] == "w" else 4
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, **kw)
     o = op.Oracle(desc)
     W, H = 120, 88
     cam = syn.default_camera(W, H)
@@ -397,7 +402,7 @@ def test_other_mlp_widths_render_in_a_register_resident_instance(width):
         finally:
             os.environ.pop("NRF_WIDTH_INSTANCES", None)
         c.load_model(desc)
-        assert _instance(c) == (3 if env == "1" else 1)
+        assert _instance(c) == (want_instance if env == "1" else 1)
         c.set_resolution(W, H)
         c.set_max_views(3)
         out = []
