@@ -222,6 +222,8 @@ struct nrf_context {
   size_t n_alloc_px = 0;
   void* d_rgba = nullptr;
   void* d_depth = nullptr;
+  void* d_plan = nullptr;      // CALL_RING plan buffers (plan_price_kernel / plan_sort_kernel: the queue order of a launch), PLAN_BYTES each
+  int plan_max_pos = 1 << 14;  // launches of up to this many strips are planned (NRF_PLAN_MAX_POS; 0: never) -- one or two 1080p views
   void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
   int call_index = 0;          // ring position of the last render call
   int tail_split = 1;          // NRF_TAIL_SPLIT=0: no tail splitting in the persistent kernel (A/B runs)
@@ -735,6 +737,9 @@ int nrf_create(int device, nrf_context** out) {
   if (const char* e = std::getenv("NRF_TAIL_SPLIT")) c->tail_split = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
   HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
+  if (const char* e = std::getenv("NRF_PLAN_MAX_POS")) c->plan_max_pos = std::max(0, std::min(std::atoi(e), (int)PLAN_CAP));
+  HIP_TRY(hipMalloc(&c->d_plan, CALL_RING * PLAN_BYTES));
+  HIP_TRY(hipMemset(c->d_plan, 0, CALL_RING * PLAN_BYTES));
   *out = c;
   return NRF_OK;
 }
@@ -753,6 +758,7 @@ int nrf_destroy(nrf_context* c) {
   }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_plan) (void)hipFree(c->d_plan);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1127,8 +1133,8 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
   P.skip_outside = skip_outside;
   c->call_index = (c->call_index + 1) % CALL_RING;
   char* counters = call_slot(c, c->call_index);
-  HIP_TRY(hipMemsetAsync(counters, 0, COUNTER_BYTES + RENDER_QUEUE_BYTES, st));  // statistics + the first launch's work queues
-  HIP_TRY(hipEventRecord(c->ev0, st));
+  unsigned* plan = c->plan_max_pos > 0 ? (unsigned*)((char*)c->d_plan + (size_t)c->call_index * PLAN_BYTES) : nullptr;
+  HIP_TRY(hipEventRecord(c->ev0, st));  // (render_ms covers the clearing of the call's counters and the planning of its queues)
   // views per launch: NRF_MAX_VIEWS, fewer when the frames are so large that the persistent kernel's 24-bit queue positions
   // (strip rows of all views x strips per row) would not hold the launch (8K frames: 64 views)
   int per_launch = MAX_VIEWS;
@@ -1154,7 +1160,8 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
       P.prog_epoch = (int)prog->epoch;
     }
     HIP_TRY(launch_render(c->dm, P, VB, rgba ? (char*)rgba + (size_t)first * stride_px * px_bytes_a : nullptr,
-                          (char*)depth + (size_t)first * stride_px * px_bytes_b, counters, st, first == 0));
+                          (char*)depth + (size_t)first * stride_px * px_bytes_b, counters, st, first == 0, plan,
+                          (unsigned)c->plan_max_pos));
   }
   c->last_views = n_views;
   HIP_TRY(hipEventRecord(c->ev1, st));

@@ -201,6 +201,9 @@ struct FrameParams {
                     // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   unsigned* prog_done;
   unsigned* prog_flags;
+  // persistent kernel: the launch's queue order (plan_sort_kernel): entry [class offset + i] = the queue position the i-th pull of
+  // that class renders -- a permutation of each class's positions, heaviest strips first.  nullptr: positions in order.
+  const unsigned* plan_order;
 };
 
 // ------------------------------------------------------------------ misc ----

@@ -1104,6 +1104,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
           if (got < total) { nb = got; break; }
         }
         if (nb == POS_DONE) moved = 0u;
+        else if (P0.plan_order != nullptr) {  // the launch was planned: the class's nb-th pull renders this position
+          unsigned off = 0u;
+          const unsigned cls = (cls0 + moved) % n_cls;
+          for (unsigned c2 = 0; c2 < cls; ++c2) off += n_units * ((cls_cols - c2 + n_cls - 1u) / n_cls);
+          nb = P0.plan_order[off + nb];
+        }
         if (lane == 0) __hip_atomic_store(sched, (moved << 29) | (nb << 5) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         pos = nb;
         bt = 0u;
@@ -1797,6 +1803,179 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict_
   }
 }
 
+// ------------------------------------------------------------ queue planning ----
+// One view (a render_frame call) is ~8 strips per wave of the persistent kernel, and a heavy 8x8 tile alone is longer than a
+// wave's fair share of the frame: in which ORDER the queues hand the strips out decides how long the launch's tail is.
+// Two small kernels ahead of the render price and sort the launch's strips:
+//   plan_price_kernel  one thread per tile: its centre ray is sampled at PLAN_SAMPLES points between its entry into and its
+//                      exit from the box of occupied cells, against the dilated coarse occupancy table (LDS); the points in
+//                      set cells, times their spacing over the march's step there, estimate the ray's march steps.  A strip
+//                      takes the maximum of its four tiles.  (It also zeroes the call's statistics counters and queue words:
+//                      the memset that used to precede the render.)
+//   plan_sort_kernel   one workgroup: counting sort of every class's queue positions by that price, dearest first
+//                      (PLAN_BINS bins relative to the launch's dearest strip; a bin roughly keeps the centre-out order).
+// The render kernel then reads position i of a class through this permutation.  Only the ORDER of the work depends on the
+// estimate: every strip is rendered exactly as before, and the frames are bit-identical with and without a plan
+// (tests/test_persistent_gpu.py).
+//   plan buffer (unsigned words): [1] max price (float bits; reset by the sort), [4 .. 4 + cap) price per position
+//   (class-major: class c's positions follow those of the classes before it), [4 + cap .. 4 + 2 cap) the order
+constexpr int PLAN_BINS = 64, PLAN_THREADS = 256, PLAN_SORT_THREADS = 1024, PLAN_SAMPLES = 32;
+struct PlanClasses {
+  unsigned off[9];  // where each class's positions begin (class-major numbering); [8] = all positions
+  unsigned n_cls;
+  __device__ void init(const ViewBatch& VB) {
+    n_cls = (unsigned)VB.n_classes;
+    const unsigned cls_cols = (unsigned)VB.class_cols, n_units = (unsigned)VB.q_total;
+    unsigned o = 0u;
+    for (unsigned c = 0; c < 8u; ++c) {
+      off[c] = o;
+      if (c < n_cls) o += n_units * ((cls_cols - c + n_cls - 1u) / n_cls);
+    }
+    off[8] = o;
+  }
+  __device__ __forceinline__ unsigned class_of(unsigned g, unsigned& begin) const {
+    unsigned cls = 0;
+#pragma unroll
+    for (unsigned c = 1; c < 8u; ++c) cls += (c < n_cls && g >= off[c]) ? 1u : 0u;  // (an empty class shares its successor's offset)
+    begin = off[cls];
+    return cls;
+  }
+};
+
+__global__ __launch_bounds__(PLAN_THREADS) void plan_price_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
+                                                                  unsigned* __restrict__ plan, unsigned* __restrict__ zero, unsigned zero_words) {
+  __shared__ PlanClasses pc;
+  __shared__ float s_max[PLAN_THREADS / 64];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dil[];  // the dilated table, every cascade
+  const unsigned T = blockIdx.x * PLAN_THREADS + threadIdx.x, n_threads = gridDim.x * PLAN_THREADS;
+  for (unsigned i = T; i < zero_words; i += n_threads) zero[i] = 0u;
+  const unsigned dil_words = M.dilated_level_words * M.cascade;
+  for (unsigned i = threadIdx.x; i < dil_words; i += PLAN_THREADS) s_dil[i] = M.occ_dilated[i];
+  if (threadIdx.x == 0) pc.init(VB);
+  __syncthreads();
+  const unsigned n_cls = pc.n_cls, cls_cols = (unsigned)VB.class_cols, n_pos = pc.off[8];
+  float* est = reinterpret_cast<float*>(plan + 4);
+  const unsigned g = T >> 2, bt = T & 3u;
+  float cost = 0.0f;
+  if (g < n_pos) {
+    unsigned begin;
+    const unsigned cls = pc.class_of(g, begin);
+    const unsigned pos = g - begin, ncols = (cls_cols - cls + n_cls - 1u) / n_cls;
+    const int u = (int)(pos / ncols), j = (int)(pos - (unsigned)u * ncols);
+    int lo = 0, hi = VB.n_views - 1;  // the last view whose first unit is <= u (render_persistent_kernel's ballot count)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (VB.v[mid].q_begin <= u) lo = mid; else hi = mid - 1;
+    }
+    const ViewParams& V = VB.v[lo];
+    // position -> tile, as render_persistent_kernel maps it
+    const int ul = u - V.q_begin;
+    const int off2 = (ul + 1) >> 1;
+    const int row = V.q_row0 + (P.centre_out != 0 ? (V.q_rows - 1) / 2 + ((ul & 1) ? off2 : -off2) : ul);
+    const int sxn = (P.tiles_x + 3) >> 2, N = P.shard_count;
+    const int s_row = row * sxn;
+    const int ls_first = s_row > P.shard_index ? (s_row - P.shard_index + N - 1) / N : 0;
+    const int ls = ls_first + (int)cls + (int)n_cls * j;
+    const int k_local = ls * 4 + (int)bt;
+    bool valid = ul < V.q_rows && ls * N + P.shard_index < s_row + sxn && k_local < V.k_hi && k_local < P.n_local_tiles;
+    const int strip = (k_local >> 2) * N + P.shard_index;
+    const int tx = (strip % sxn) * 4 + (k_local & 3), ty = strip / sxn;
+    valid = valid && !(tx * 8 > V.roi[2] || tx * 8 + 7 < V.roi[0] || ty * 8 > V.roi[3] || ty * 8 + 7 < V.roi[1]) && tx < P.tiles_x;
+    if (valid) {
+      const int px = min(tx * 8 + 4, P.W - 1), py = min(ty * 8 + 4, P.H - 1);
+      const float o[3] = {V.org[0], V.org[1], V.org[2]};
+      float d[3], near, far, t_in, t_out;
+      ray_dir(V.R, V.cam, px, py, d);
+      near_far(M.aabb, o, d, P.min_near, near, far);
+      box_interval(M.occ_box, o, 1 / d[0], 1 / d[1], 1 / d[2], t_in, t_out);
+      const float t0 = fmaxf(t_in, near), t1 = fminf(far, t_out);
+      if (near < far && M.occ_box[0] <= M.occ_box[3] && t0 < t1) {
+        const int Hc = (int)(M.H >> 2);
+        const float dt_min = 2 * 1.7320508075688772f / 1024, dt_max = 2 * M.bound / (float)M.H;
+        const float seg = (t1 - t0) * (1.0f / PLAN_SAMPLES);
+        for (int i = 0; i < PLAN_SAMPLES; ++i) {  // (independent of each other: the table lookups overlap)
+          const float t = t0 + ((float)i + 0.5f) * seg;
+          const float x = o[0] + t * d[0], y = o[1] + t * d[1], z = o[2] + t * d[2];
+          const float m = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+          int e = 0;
+          (void)frexpf(m, &e);  // m in [2^(e-1), 2^e): the cascade whose cube first holds the point
+          const int k = min(max(e, 0), (int)M.cascade - 1);
+          const float mb = M.cascade > 1 ? fminf(ldexpf(1.0f, k), M.bound) : fminf(1.0f, M.bound);
+          const float rcs = (float)Hc / (2.0f * mb);
+          const int cx = (int)floorf((x + mb) * rcs), cy = (int)floorf((y + mb) * rcs), cz = (int)floorf((z + mb) * rcs);
+          if ((unsigned)cx < (unsigned)Hc && (unsigned)cy < (unsigned)Hc && (unsigned)cz < (unsigned)Hc) {
+            const uint32_t cc = ((uint32_t)cx * Hc + (uint32_t)cy) * Hc + (uint32_t)cz;
+            if ((s_dil[(size_t)k * M.dilated_level_words + (cc >> 5)] >> (cc & 31u)) & 1u) cost += seg / clampf(t * P.dt_gamma, dt_min, dt_max);
+          }
+        }
+      }
+    }
+    if (!(cost >= 0.0f) || cost > 1.0e6f) cost = cost > 1.0e6f ? 1.0e6f : 0.0f;  // (NaN: a degenerate camera -- any order is a valid order)
+  }
+  cost = fmaxf(cost, __shfl_xor(cost, 1));
+  cost = fmaxf(cost, __shfl_xor(cost, 2));  // the strip's price: its dearest tile
+  if (bt == 0u && g < n_pos) est[g] = cost;
+  float wmax = cost;
+  for (int sh = 4; sh < 64; sh <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, sh));
+  if ((threadIdx.x & 63u) == 0u) s_max[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = s_max[0];
+    for (int w = 1; w < PLAN_THREADS / 64; ++w) m = fmaxf(m, s_max[w]);
+    if (m > 0.0f) atomicMax(plan + 1, __float_as_uint(m));  // (prices are >= 0: their bit patterns order like the values)
+  }
+}
+
+__global__ __launch_bounds__(PLAN_SORT_THREADS) void plan_sort_kernel(const ViewBatch VB, unsigned* __restrict__ plan, unsigned cap) {
+  __shared__ PlanClasses pc;
+  __shared__ unsigned s_bins[8 * PLAN_BINS];
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_bin[];  // a bin per position
+  if (threadIdx.x == 0) pc.init(VB);
+  for (unsigned i = threadIdx.x; i < 8u * PLAN_BINS; i += PLAN_SORT_THREADS) s_bins[i] = 0u;
+  __syncthreads();
+  const unsigned n_pos = pc.off[8];
+  const float* est = reinterpret_cast<const float*>(plan + 4);
+  unsigned* order = plan + 4 + cap;
+  const float top = __uint_as_float(plan[1]);
+  const float scale = top > 0.0f ? (float)PLAN_BINS / top : 0.0f;
+  const float4* est4 = reinterpret_cast<const float4*>(est);
+  for (unsigned q4 = threadIdx.x; q4 * 4u < n_pos; q4 += PLAN_SORT_THREADS) {
+    const float4 v = est4[q4];
+    const float c4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned i = q4 * 4u + (unsigned)e;
+      if (i < n_pos) {
+        unsigned begin;
+        const unsigned cls = pc.class_of(i, begin);
+        const int q = (int)(c4[e] * scale);
+        const unsigned b = (unsigned)(PLAN_BINS - 1 - (q < 0 ? 0 : (q > PLAN_BINS - 1 ? PLAN_BINS - 1 : q)));  // dearest: bin 0
+        s_bin[i] = (uint8_t)b;
+        atomicAdd(&s_bins[cls * PLAN_BINS + b], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  static_assert(PLAN_BINS == 64 && PLAN_SORT_THREADS >= 8 * 64, "one wave scans one class's bins");
+  if (threadIdx.x < 8u * PLAN_BINS) {  // exclusive prefix inside each class: wave w = class w, lane = bin
+    const unsigned n = s_bins[threadIdx.x];
+    unsigned run = n;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const unsigned up = __shfl_up(run, sh);
+      if ((int)(threadIdx.x & 63u) >= sh) run += up;
+    }
+    s_bins[threadIdx.x] = run - n;
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n_pos; i += PLAN_SORT_THREADS) {  // a thread's positions in queue order: a bin roughly keeps its strips' order
+    unsigned begin;
+    const unsigned cls = pc.class_of(i, begin);
+    const unsigned slot = atomicAdd(&s_bins[cls * PLAN_BINS + s_bin[i]], 1u);
+    order[begin + slot] = i - begin;
+  }
+  if (threadIdx.x == 0) plan[1] = 0u;  // ready for the next call that uses this buffer
+}
+
 // ---------------------------------------------------------------- launchers ----
 static inline int grid_for(uint64_t n, int block = 256, int cap = 256 * 8) {
   uint64_t g = (n + block - 1) / block;
@@ -1814,11 +1993,15 @@ static hipError_t allow_lds(K kernel, int bytes) {
 }
 static int gen_lds_bytes(const DevModel& M, int waves) { return LDS_LEVEL_BYTES + waves * ((int)sizeof(WaveLds) + (int)M.gen_wave_bytes); }
 
-hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
-                         hipStream_t st, bool queues_are_zero) {
+hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBatch& VBin, void* rgba, void* depth, void* counters,
+                         hipStream_t st, bool first_launch, unsigned* plan, unsigned plan_cap) {
   ViewBatch VB = VBin;
+  FrameParams P = Pin;
+  P.plan_order = nullptr;
+  // the call's statistics counters and queue words are zero before its first launch (plan_price_kernel does it for a planned launch)
+  auto clear_for_first = [&]() { return first_launch ? hipMemsetAsync(counters, 0, COUNTER_BYTES + RENDER_QUEUE_BYTES, st) : hipSuccess; };
   VB.blocks_per_view = (P.n_local_tiles + RENDER_WAVES - 1) / RENDER_WAVES;
-  if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return hipSuccess;  // a shard without a strip (tiny frames, many ranks)
+  if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return clear_for_first();  // a shard without a strip (tiny frames, many ranks)
   if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
   const bool lds_tab = M.lds_coarse_words > 0;
@@ -1860,7 +2043,18 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
     const int wgs = (int)std::max(1LL, std::min((long long)M.n_cus, (tiles + waves - 1) / waves));
     unsigned* queue = reinterpret_cast<unsigned*>((unsigned long long*)counters + COUNTER_SLOTS * 16);
     hipError_t e = hipSuccess;
-    if (!queues_are_zero) e = hipMemsetAsync(queue, 0, RENDER_QUEUE_BYTES, st);  // (the caller's statistics memset covered them)
+    const long long n_pos = (long long)q * VB.class_cols;
+    const size_t dil_bytes = (size_t)4 * M.dilated_level_words * M.cascade;
+    if (first_launch && plan != nullptr && M.occ_dilated != nullptr && n_pos > 0 && n_pos <= (long long)plan_cap && n_pos <= 60 * 1024 &&
+        dil_bytes <= 60 * 1024) {
+      const int blocks = (int)((n_pos * 4 + PLAN_THREADS - 1) / PLAN_THREADS);
+      hipLaunchKernelGGL(plan_price_kernel, dim3(blocks), dim3(PLAN_THREADS), (dil_bytes + 15) & ~(size_t)15, st, M, P, VB, plan,
+                         (unsigned*)counters, (unsigned)((COUNTER_BYTES + RENDER_QUEUE_BYTES) / 4));
+      hipLaunchKernelGGL(plan_sort_kernel, dim3(1), dim3(PLAN_SORT_THREADS), ((size_t)n_pos + 15) & ~(size_t)15, st, VB, plan, plan_cap);
+      P.plan_order = plan + 4 + plan_cap;
+    } else {
+      e = first_launch ? clear_for_first() : hipMemsetAsync(queue, 0, RENDER_QUEUE_BYTES, st);
+    }
     if (e != hipSuccess) return e;
     const bool pow2_h = (M.H & (M.H - 1)) == 0;
     int eb = 0;
@@ -1913,6 +2107,10 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 #undef NRF_LAUNCH_PERSISTENT_O
 #undef NRF_LAUNCH_PERSISTENT_F
     return hipGetLastError();
+  }
+  {
+    const hipError_t e0 = clear_for_first();
+    if (e0 != hipSuccess) return e0;
   }
   const int fixed = M.generic ? gen_lds_bytes(M, RENDER_WAVES)
                               : (M.wide ? LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES

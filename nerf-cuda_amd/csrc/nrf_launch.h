@@ -13,7 +13,10 @@ struct ViewBatch;
 // the caller has just cleared them together with the statistics
 constexpr int RENDER_QUEUE_BYTES = 8 * 4;
 hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VB, void* rgba, void* depth, void* counters,
-                         hipStream_t st, bool queues_are_zero);
+                         hipStream_t st, bool first_launch, unsigned* plan = nullptr, unsigned plan_cap = 0);
+// a call's plan buffer (plan_price_kernel / plan_sort_kernel): 4 header words + a price and an order entry per queue position
+constexpr unsigned PLAN_CAP = 60u * 1024u;  // queue positions (strips) of a launch that may be planned (its last workgroup keeps a byte per position in LDS)
+constexpr size_t PLAN_BYTES = (4 + 2 * (size_t)PLAN_CAP) * 4;
 hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st, bool fast_interp = false);
 hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st);
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,

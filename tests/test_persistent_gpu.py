@@ -130,6 +130,19 @@ def test_queue_settings_do_not_change_the_picture(model):
         _same(_render(desc, 400, 300, poses, dict(PERSISTENT, **env)), ref, env)
 
 
+@pytest.mark.parametrize("W,H,kind,n,shard", [(1920, 1080, "orbit", 1, (0, 1)), (800, 800, "inside", 1, (0, 1)), (640, 360, "orbit", 6, (0, 1)),
+                                                (1280, 720, "orbit", 2, (1, 3)), (1000, 24, "far", 3, (0, 1))])
+def test_planned_queue_order_does_not_change_the_picture(model, W, H, kind, n, shard):
+    """plan_price_kernel / plan_sort_kernel permute the order in which the queues hand the strips out (dearest estimated strip
+    first); with NRF_PLAN_MAX_POS=0 the positions come in order.  A strip the permutation lost would leave its pixels
+    poisoned, one it held twice would count its rays twice."""
+    desc, _ = model
+    poses = _poses(kind, n)
+    ref = _render(desc, W, H, poses, dict(PERSISTENT, NRF_PLAN_MAX_POS="0"), shard=shard)
+    _same(_render(desc, W, H, poses, PERSISTENT, shard=shard), ref, (W, H, kind, "planned"))
+    _same(_render(desc, W, H, poses, dict(PERSISTENT, NRF_QUEUE_CLASSES="3"), shard=shard), ref, (W, H, kind, "planned, 3 classes"))
+
+
 def test_persistent_kernel_with_cascades_and_sample_cap():
     """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
     dilated table, 44 KB of march tables in LDS) and a small max_steps."""
