@@ -226,6 +226,7 @@ struct nrf_context {
   int plan_max_pos = 1 << 14;  // launches of up to this many strips are planned (NRF_PLAN_MAX_POS; 0: never) -- one or two 1080p views
   void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
   int call_index = 0;          // ring position of the last render call
+  int march_ff = 1;            // NRF_MARCH_FF=0: no barrier fast-forward ahead of t_skip (A/B runs, equality tests)
   int tail_split = 1;          // NRF_TAIL_SPLIT=0: no tail splitting in the persistent kernel (A/B runs)
   void* d_rgb8 = nullptr;
   void* d_depth8 = nullptr;
@@ -241,6 +242,7 @@ struct nrf_context {
     uint8_t* h_buf = nullptr;  // pinned host, same layout
     size_t views = 0, px = 0;  // capacity
     hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;  // done: the call's last copy; t0 / t1: around its render launches
+    hipEvent_t grp[2] = {nullptr, nullptr};                 // the two copy groups a progressive call keeps in flight (progressive_copies)
     std::vector<int> row_lo, row_hi;  // per view: the rows of the pinned planes that do not hold the background value
     int bg = -1;               // the 8-bit background value the other rows hold (-1: nothing filled yet)
     int n_views = 0, W = 0, H = 0;
@@ -256,6 +258,7 @@ struct nrf_context {
   } hs[2];
   int hs_next = 0;
   hipStream_t copy_stream = nullptr;
+  bool host_merge = true;        // NRF_HOST_MERGE=0: every ready band is copied by itself, at once (A/B runs)
   bool host_progressive = true;  // NRF_HOST_PROGRESSIVE=0: every copy of a host frame waits for the end of its render (A/B runs)
   bool host_skip_outside = true; // NRF_HOST_SKIP_OUTSIDE=0: the kernel writes the background rows of a host frame as well (A/B runs)
   void* last_rgba = nullptr;
@@ -371,6 +374,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.prog_done = P.prog_flags = nullptr;
   P.prog_epoch = 0;
   P.tail_split = c->tail_split;
+  P.march_ff = c->march_ff;
   P.fast_interp = c->opt.fast_interp ? 1 : 0;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
@@ -718,6 +722,7 @@ int nrf_create(int device, nrf_context** out) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   if (const char* e = std::getenv("NRF_HOST_PROGRESSIVE")) c->host_progressive = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_HOST_MERGE")) c->host_merge = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_HOST_SKIP_OUTSIDE")) c->host_skip_outside = std::atoi(e) != 0;
   // The copy stream gets a hardware queue of its own.  HIP maps streams onto a few hardware queues (4 by default) and a
   // device-to-host copy issued while a render is resident on a queue it shares does not start before that render has
@@ -731,10 +736,12 @@ int nrf_create(int device, nrf_context** out) {
   }
   for (auto& h : c->hs) {
     HIP_TRY(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    for (hipEvent_t& g : h.grp) HIP_TRY(hipEventCreateWithFlags(&g, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&h.t0));
     HIP_TRY(hipEventCreate(&h.t1));
   }
   if (const char* e = std::getenv("NRF_TAIL_SPLIT")) c->tail_split = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("NRF_MARCH_FF")) c->march_ff = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
   HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
   if (const char* e = std::getenv("NRF_PLAN_MAX_POS")) c->plan_max_pos = std::max(0, std::min(std::atoi(e), (int)PLAN_CAP));
@@ -753,6 +760,7 @@ int nrf_destroy(nrf_context* c) {
   free_host_slots(c);
   for (auto& h : c->hs) {
     if (h.done) (void)hipEventDestroy(h.done);
+    for (hipEvent_t g : h.grp) if (g) (void)hipEventDestroy(g);
     if (h.t0) (void)hipEventDestroy(h.t0);
     if (h.t1) (void)hipEventDestroy(h.t1);
   }
@@ -1282,6 +1290,10 @@ int progressive_copies(nrf_context* c, nrf_context::HostSlot& h) {
       bands.push_back({v, std::max(lo, 8 * s0), std::min(hi, 8 * s1), s0, s1});
     }
   }
+  // A copy costs the engine ~12 us before its first byte moves (a 550 KB band: 34 us for 10 us of link time), and the rows of
+  // a frame rendered alone complete within the last tenth of its render: band by band the copies ran for 0.3 ms after the
+  // kernel's end.  So ready bands are issued in GROUPS: adjacent ones merged into one copy per plane, at most two groups in
+  // flight -- while the engine is busy the ready bands collect, and what completes together leaves as one copy.
   size_t remaining = bands.size();
   bool kernel_done = false;
   unsigned spins = 0;
@@ -1289,29 +1301,53 @@ int progressive_copies(nrf_context* c, nrf_context::HostSlot& h) {
   std::vector<hipEvent_t> dbg_events;
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  std::vector<char> ready(bands.size(), 0);
+  size_t n_ready = 0;     // ready, not yet issued
+  int in_flight = 0;      // groups whose event has not been seen done (oldest: grp[(grp_next + 2 - in_flight) % 2])
+  int grp_next = 0;
+  const int max_groups = c->host_merge ? 2 : 1 << 30;
   while (remaining) {
-    bool progress = false;
-    for (Band& b : bands) {
-      if (b.view < 0) continue;
-      bool ready = kernel_done;
-      if (!ready) {
-        ready = true;
+    if (!kernel_done) {
+      for (size_t i = 0; i < bands.size(); ++i) {
+        const Band& b = bands[i];
+        if (b.view < 0 || ready[i]) continue;
+        bool ok = true;
         const unsigned* f = h.h_flags + (size_t)b.view * tiles_y;
-        for (int r = b.s0; r < b.s1 && ready; ++r) ready = __atomic_load_n(f + r, __ATOMIC_ACQUIRE) == h.epoch;
+        for (int r = b.s0; r < b.s1 && ok; ++r) ok = __atomic_load_n(f + r, __ATOMIC_ACQUIRE) == h.epoch;
+        if (ok) { ready[i] = 1; ++n_ready; }
       }
-      if (!ready) continue;
-      if (debug) std::fprintf(stderr, "[host frame] +%.3f ms: band view %d rows %d..%d%s\n", since(), b.view, b.lo, b.hi, kernel_done ? " (kernel done)" : "");
-      hipEvent_t d0 = nullptr, d1 = nullptr;
-      if (debug) { (void)hipEventCreate(&d0); (void)hipEventCreate(&d1); (void)hipEventRecord(d0, c->copy_stream); }
-      int rc = copy_rows(c, h, b.view, b.lo, b.hi);
-      if (rc) return rc;
-      if (debug) { (void)hipEventRecord(d1, c->copy_stream); dbg_events.push_back(d0); dbg_events.push_back(d1); }
-      b.view = -1;
-      --remaining;
-      progress = true;
+    } else if (n_ready < remaining) {
+      for (size_t i = 0; i < bands.size(); ++i) if (bands[i].view >= 0 && !ready[i]) { ready[i] = 1; ++n_ready; }
     }
-    if (!remaining || progress) continue;
-    if ((++spins & 31u) == 0u) {
+    while (in_flight > 0 && c->host_merge) {
+      const hipError_t e = hipEventQuery(h.grp[(grp_next + 2 - in_flight) % 2]);
+      if (e == hipSuccess) --in_flight;
+      else if (e == hipErrorNotReady) break;
+      else return hip_fail(e, "hipEventQuery");
+    }
+    if (n_ready && in_flight < max_groups) {
+      for (size_t i = 0; i < bands.size();) {
+        if (bands[i].view < 0 || !ready[i]) { ++i; continue; }
+        size_t j = i;  // [i, j]: ready bands of one view whose rows follow each other
+        while (c->host_merge && j + 1 < bands.size() && bands[j + 1].view == bands[i].view && ready[j + 1] && bands[j + 1].s0 == bands[j].s1) ++j;
+        if (debug) std::fprintf(stderr, "[host frame] +%.3f ms: view %d rows %d..%d (%zu band(s))%s\n", since(), bands[i].view, bands[i].lo, bands[j].hi, j - i + 1, kernel_done ? " (kernel done)" : "");
+        hipEvent_t d0 = nullptr, d1 = nullptr;
+        if (debug) { (void)hipEventCreate(&d0); (void)hipEventCreate(&d1); (void)hipEventRecord(d0, c->copy_stream); }
+        int rc = copy_rows(c, h, bands[i].view, bands[i].lo, bands[j].hi);
+        if (rc) return rc;
+        if (debug) { (void)hipEventRecord(d1, c->copy_stream); dbg_events.push_back(d0); dbg_events.push_back(d1); }
+        for (size_t k = i; k <= j; ++k) { bands[k].view = -1; ready[k] = 0; --remaining; --n_ready; }
+        i = j + 1;
+      }
+      if (c->host_merge && remaining) {
+        HIP_TRY(hipEventRecord(h.grp[grp_next], c->copy_stream));
+        grp_next ^= 1;
+        ++in_flight;
+      }
+      continue;
+    }
+    if (!remaining) break;
+    if (!kernel_done && (++spins & 31u) == 0u) {
       const hipError_t e = hipEventQuery(h.t1);
       if (e == hipSuccess) kernel_done = true;
       else if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");

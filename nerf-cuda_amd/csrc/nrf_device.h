@@ -199,6 +199,8 @@ struct FrameParams {
   int fast_interp;  // nrf_options::fast_interp: the FAST instances of the persistent register-resident kernel / encode_grid_kernel
   int tail_split;   // persistent kernel: 1 = waves that find the queues empty take rays off the rendering waves of their
                     // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
+  int march_ff;     // 1 = a ray steps straight to its last barrier plane ahead of t_skip (fast_forward_to_barrier); 0 = every
+                    // trip of that stretch is simulated (A/B runs and the equality tests: NRF_MARCH_FF=0)
   unsigned* prog_done;
   unsigned* prog_flags;
   // persistent kernel: the launch's queue order (plan_sort_kernel): entry [class offset + i] = the queue position the i-th pull of
@@ -425,6 +427,16 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
       asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sink) : "v"(t), "v"(dx));
     }
 #endif
+#ifdef NRF_DIAG_FF_UPPER
+    // diagnostic build (never shipped; WRONG pictures): every trip before t_skip is a bare step -- the upper bound of what an
+    // exact fast-forward through the empty stretch ahead of the object could return
+    if (t < t_skip) {
+      do {
+        t += clamp3(t * c.dt_gamma, c.dt_min, c.dt_max);
+      } while (t < t_skip && t < far);
+      continue;
+    }
+#endif
     x = clamp3(ox + t * dx, -c.bound, c.bound);
     y = clamp3(oy + t * dy, -c.bound, c.bound);
     z = clamp3(oz + t * dz, -c.bound, c.bound);
@@ -494,6 +506,59 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
     } while (t < tt);
   }
   return MARCH_EXHAUSTED;
+}
+
+#ifndef NRF_MARCH_FF
+#define NRF_MARCH_FF 1
+#endif
+// ------------------------------------------------- barrier fast-forward ----
+// The stretch of a ray between its entry into the aabb and t_skip (the first coarse cell that can hold a sample) used to be
+// simulated trip by trip -- ~100-200 trips of ~45 vector instructions per ray that test nothing (DESIGN.md "March").  It
+// cannot simply be skipped: which of the steps t_{k+1} = t_k + dt(t_k) are trip STARTS (= tested positions) beyond t_skip
+// depends on the hops before.  But every trip start is a member of that step sequence, and the hop of
+// render_utils.h:641-651 has a structure that makes some members certain trip starts:
+//   for an axis a with d_a < 0 the hop target of a trip in slab n (cell index n along a) is at most the time the ray
+//   reaches the plane b_a(n) = ((n / (H-1)) * 2 - 1) -- the `/(H-1)` boundary, which lies INSIDE slab n;
+//   * a trip that starts above the plane (slab n' >= n: its own plane b_a(n') comes earlier) ends at or before the first
+//     member behind the plane:    tt = t + max(0, min(tx, ty, tz)) <= t + tx = T_a(n) (+- rounding);
+//   * a trip that starts below the plane, still in slab n, has tx <= 0: tt = t, exactly one step;
+//   * a trip that starts within rounding of the plane has a hop of rounding size: one step.
+//   Hence no trip jumps over e = the first member >= T_a(n) + eps (eps > the rounding of tt, see below): whatever the trips
+//   before did, one of them ENDS at e, so e is a trip start (if the member before e lies above the plane its trip ends at
+//   the first member >= tt, tt in (it, T + rounding]: e; if it lies within eps of, or below, the plane: one step: e).
+// All members before e start before T + eps <= t_skip, where no trip can find a sample: the reference's state at e is
+// (t = e, last_t and the sample count untouched) -- the same as after stepping through the members without any trip.
+// So: take the LAST such plane ahead of t_skip over the ray's negative axes and step to it.  Rays without a negative
+// direction component, or whose last plane lies before their start, keep their trips.
+//   eps: tt is computed as fl(t + fl(fl(b - x) * rd)) with x = fl(o + fl(t d)): x is within ~2 ulp(|o| + |t d|) of the
+//   true position, the products / sums add ~3 more relative roundings of a value <= t: |tt - T| <= ~1e-6 (1 + |rd_a|) for
+//   magnitudes up to ~8; eps = 4e-6 (t_skip + 2) (1 + |rd_a|) leaves a factor of four and scales with the magnitudes.
+// MARCH_UNIT only (one cascade, mip_bound 1): with several cascades the planes of different levels are not ordered along a ray.
+__device__ __forceinline__ float barrier_before(const float* ctab, int H, float o, float d, float rd, float t_skip) {
+  // the last plane of a NEGATIVE axis the ray passes before t_skip: returns T + eps, or -inf when there is none
+  const float NONE = -3.402823466e+38f;
+  if (!(d < 0.0f) || !(rd > -3.0e38f)) return NONE;
+  const float xs = o + t_skip * d;                               // (approximate) position at t_skip
+  float v = ceilf((xs + 1.0f) * (0.5f * (float)(H - 1)));        // first plane index at or above it
+  v = clamp3(v, 0.0f, (float)H);
+  int n = (int)v;
+  const float eps = 4.0e-6f * (t_skip + 2.0f) * (1.0f + fabsf(rd));
+  float e = (ctab[n] - o) * rd + eps;
+  if (!(e <= t_skip)) {  // the approximate position put the plane a hair behind t_skip: the one before it
+    n = min(n + 1, H);
+    e = (ctab[n] - o) * rd + eps;
+  }
+  return e <= t_skip ? e : NONE;
+}
+
+__device__ __forceinline__ float fast_forward_to_barrier(const MarchConst& c, const float* ctab, const float o[3], const float d[3],
+                                                         float rdx, float rdy, float rdz, float t, float t_skip, float far) {
+  const float tb = fminf(fmaxf(barrier_before(ctab, (int)c.H, o[0], d[0], rdx, t_skip),
+                               fmaxf(barrier_before(ctab, (int)c.H, o[1], d[1], rdy, t_skip),
+                                     barrier_before(ctab, (int)c.H, o[2], d[2], rdz, t_skip))), far);
+  // every step below is a member before e: t < tb <= T + eps <= t_skip, and t < far as in `while (t < far ...)`
+  while (t < tb) t += clamp3(t * c.dt_gamma, c.dt_min, c.dt_max);
+  return t;
 }
 
 // ------------------------------------------------------------- hash grid ----

@@ -849,6 +849,9 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
       alive = any;
       if (last < far_m) far_m = last;
       if (any) t_skip = first;
+#if NRF_MARCH_FF
+      if (MARCH == MARCH_UNIT && COARSE_LDS && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+#endif
     }
     if (alive) {  // direction encoding: only rays that will evaluate the network need it
       float u0 = 0.5f * d[0]; u0 = u0 + 0.5f;  // linear_transformer(0.5, 0.5), nerf_render.cu:313-314
@@ -1216,6 +1219,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       alive = any;
       if (last < far_m) far_m = last;
       if (any) t_skip = first;
+#if NRF_MARCH_FF
+      if (MARCH == MARCH_UNIT && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+#endif
     }
     TileAcc acc;
     bool given = false;  // tail splitting: this lane's ray went to a helper wave, which stores its pixel

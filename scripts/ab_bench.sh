@@ -10,7 +10,7 @@ for rep in 1 2 3; do
     python3 bench.py --no-cpu-baseline --lib "$lib" "$@" 2>> gpurun_out/ab.err | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$lib', 'Msamples_s', d['value'], 'ms_per_step', d['ms_per_step'], 'isolated_ms', r['isolated_kernel_ms'], 'mlp_tflops', d['mlp_kernel']['achieved'])" >> gpurun_out/ab.txt
+print('$lib', 'Msamples_s', d['value'], 'ms_per_step', d['ms_per_step'], 'isolated_ms', r['isolated_kernel_ms'], 'single_view_ms', d['single_view_ms'], 'mlp_tflops', d.get('mlp_kernel', {}).get('achieved'))" >> gpurun_out/ab.txt
   done
 done
 cat gpurun_out/ab.txt

@@ -263,7 +263,8 @@ def test_render_frame_matches_oracle(ctx, small, W, H, az, el):
     assert models.psnr(rgba, want) >= 45.0
     # the kernel batches up to 8 samples per ray and round, so it may evaluate a few samples past a
     # ray's termination that the one-sample-at-a-time oracle never emits
-    assert wst.n_samples * 0.995 - 8 <= st.n_samples <= wst.n_samples * 1.5 + 64
+    # (how many depends on timing since tail splitting: the deterministic bound is 7 per ray)
+    assert wst.n_samples * 0.995 - 8 <= st.n_samples <= wst.n_samples + 7 * W * H
     # ... while the samples that reach a ray's compositing sum are the oracle's own (per-ray schedule), up to the rays whose
     # termination test falls the other way within the MLP tolerance
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.002 * wst.n_composited + 8 and wst.n_composited == wst.n_samples

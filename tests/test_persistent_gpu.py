@@ -143,6 +143,26 @@ def test_planned_queue_order_does_not_change_the_picture(model, W, H, kind, n, s
     _same(_render(desc, W, H, poses, dict(PERSISTENT, NRF_QUEUE_CLASSES="3"), shard=shard), ref, (W, H, kind, "planned, 3 classes"))
 
 
+def _octant_poses(radius=4.0311):
+    """Cameras above, below and level with the object from all sides: every sign pattern of the ray direction."""
+    return [syn.orbit_pose(az, el, radius=radius) for el in (55.0, 12.0, -35.0, -70.0) for az in (10.0, 100.0, 190.0, 280.0)]
+
+
+@pytest.mark.parametrize("sched", [PERSISTENT, STRIP])
+@pytest.mark.parametrize("W,H,dt_gamma,hash_log2,grid_H", [(333, 211, 1.0 / 128.0, 15, 64), (256, 192, 0.0, 15, 64), (200, 160, 1.0 / 64.0, 15, 64),
+                                                            (320, 200, 1.0 / 128.0, 14, 128), (160, 120, 1.0 / 256.0, 14, 32)])
+def test_barrier_fast_forward_does_not_change_the_picture(sched, W, H, dt_gamma, hash_log2, grid_H):
+    """fast_forward_to_barrier steps a ray from its start to the last barrier plane ahead of t_skip without simulating the
+    trips in between (nrf_device.h).  With NRF_MARCH_FF=0 every trip is simulated: frames, composited samples and ray counts
+    must be identical -- for every sign pattern of the direction (negative axes carry the barriers, rays without one keep
+    their trips), step sizes at dt_min / growing / at dt_max, cameras near and far, three grid resolutions."""
+    desc, _ = models.build_model(log2_hashmap_size=hash_log2, H=grid_H)[:2]
+    poses = _octant_poses() + _octant_poses(radius=1.9)[::3] + _poses("inside", 2) + _poses("far", 1)
+    kw = {"dt_gamma": dt_gamma}
+    ref = _render(desc, W, H, poses, dict(sched, NRF_MARCH_FF="0"), opts_kw=kw)
+    _same(_render(desc, W, H, poses, sched, opts_kw=kw), ref, (W, H, dt_gamma, grid_H, "fast-forward"))
+
+
 def test_persistent_kernel_with_cascades_and_sample_cap():
     """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
     dilated table, 44 KB of march tables in LDS) and a small max_steps."""
