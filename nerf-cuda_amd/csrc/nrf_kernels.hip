@@ -851,6 +851,7 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
       if (any) t_skip = first;
 #if NRF_MARCH_FF
       if (MARCH == MARCH_UNIT && COARSE_LDS && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      if (MARCH == MARCH_POW2 && COARSE_LDS && any && P.march_ff != 0) t = fast_forward_to_barrier_pow2(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
 #endif
     }
     if (alive) {  // direction encoding: only rays that will evaluate the network need it
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       if (any) t_skip = first;
 #if NRF_MARCH_FF
       if (MARCH == MARCH_UNIT && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      if (MARCH == MARCH_POW2 && any && P.march_ff != 0) t = fast_forward_to_barrier_pow2(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
 #endif
     }
     TileAcc acc;

@@ -163,6 +163,22 @@ def test_barrier_fast_forward_does_not_change_the_picture(sched, W, H, dt_gamma,
     _same(_render(desc, W, H, poses, sched, opts_kw=kw), ref, (W, H, dt_gamma, grid_H, "fast-forward"))
 
 
+@pytest.mark.parametrize("sched", [PERSISTENT, STRIP])
+@pytest.mark.parametrize("cascade,bound,grid_H,dt_gamma", [(5, 16.0, 64, 1.0 / 128.0), (3, 4.0, 128, 1.0 / 128.0), (2, 2.0, 32, 0.0), (5, 16.0, 32, 1.0 / 32.0)])
+def test_barrier_fast_forward_with_cascades(sched, cascade, bound, grid_H, dt_gamma):
+    """Several cascades (fast_forward_to_barrier_pow2): a level-L plane is a barrier only while no trip of another level can
+    reach past it.  Cameras outside the aabb, in the outer shells, close to shell boundaries and inside the innermost cube,
+    looking in every octant; identical frames with and without the fast-forward."""
+    desc, _ = models.build_model(log2_hashmap_size=14, H=grid_H, cascade=cascade, bound=bound)[:2]
+    poses = []
+    for radius in (1.2, 2.05, 3.9, 8.3, 17.0, 40.0):
+        poses += [syn.orbit_pose(az, el, radius=radius / 0.33) for az, el in ((15.0, 40.0), (140.0, -25.0), (250.0, 8.0), (320.0, -60.0))]
+    poses += _poses("inside", 2)
+    kw = {"dt_gamma": dt_gamma, "max_steps": 1024}
+    ref = _render(desc, 240, 160, poses, dict(sched, NRF_MARCH_FF="0"), opts_kw=kw)
+    _same(_render(desc, 240, 160, poses, sched, opts_kw=kw), ref, (cascade, bound, grid_H, dt_gamma, "fast-forward, cascades"))
+
+
 def test_persistent_kernel_with_cascades_and_sample_cap():
     """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
     dilated table, 44 KB of march tables in LDS) and a small max_steps."""
