@@ -99,10 +99,11 @@ doc = {
         "binding_unit": "VALU issue port and texture-address (gather) path, co-limiting",
         # the in-situ check of that attribution (round 3): instructions of a KNOWN count added to / taken from the two big phases
         "marginal_cost_in_situ": marginal,
-        "marginal_cost_reading": "an added half-rate instruction in the interpolation costs 2.5-2.6 of its 4.1 nominal cycles, an added v_mul_f32 per march "
-                                 "trip 1.5-1.75 of 2.25: the issue port is a real limiter in BOTH phases (the march's instruction count IS a lever, "
-                                 "against round 2's reading) -- but removing interpolation instructions returns only 0.7 cycles each (nocvt) and the "
-                                 "opt-in fast_interp (half of them gone) < 1 %: with less vector work the gather path binds at once",
+        "marginal_cost_reading": "after the barrier fast-forward (the march lost ~90 % of its trips) the texture-address path leads (0.87-0.88 busy) and "
+                                 "the issue port follows (0.80): an added half-rate instruction in the interpolation still costs 2.1-2.4 of its 4.1 "
+                                 "nominal cycles and an added v_mul_f32 per march trip 1.6-2.0 of 2.25, removing interpolation instructions returns "
+                                 "0.6 cycles each (nocvt), the opt-in fast_interp < 1 %: both units are within a tenth of each other, trading work "
+                                 "between them returns little",
         "note": "The VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max / "
                 "med3, conversions, shifts, v_mul_lo_u32, packed fp16, v_fma_mix); transcendentals 8; an MFMA holds the issue port for 8 "
                 "(scripts/issue_rate/issue_rate.hip, profiles/r02/issue_rate.txt: 34 opcodes; the int32 and remainder counter classes are "
