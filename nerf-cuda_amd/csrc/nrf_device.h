@@ -749,6 +749,20 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
     }
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+#ifdef NRF_DIAG_HASH_PAIRS
+  // diagnostic build (never shipped; WRONG values for odd x): every (x, x + 1) corner pair of a hashed level as ONE aligned
+  // 8-byte gather -- the upper bound of what pairing the corners of hashed levels could return
+  if (UNI == 2) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off[2 * q] & ~4u, 0, 0);
+      v[2 * q] = w.x;
+      v[2 * q + 1] = w.y;
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int c = 0; c < 8; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[c], 0, 0);
 }
