@@ -233,7 +233,11 @@ int nrf_set_options(nrf_context* ctx, const nrf_options* o);
  * cam = {fl_x, fl_y, cx, cy} (common.h:68-74); pose = row-major 4x4
  * camera-to-world in the NeRF/Blender convention (converted with
  * nerf_matrix_to_ngp, render_utils.h:68-77).  Asynchronous on `stream`
- * unless stream==NULL, in which case the call returns after completion.      */
+ * unless stream==NULL, in which case the call returns after completion.
+ * A camera more than 4096 units (the reference's ngp units: 0.33 x the pose's
+ * translation + 0.5) from the origin renders as background: out there t + dt
+ * stops changing t in fp32, and the march of render_utils.h:593-653 -- the
+ * reference's as well as this one -- would never end.                         */
 int nrf_render(nrf_context* ctx, const float cam[4], const float pose[16],
                void* stream, nrf_frame* out);
 /* Batched multi-view render: n_views cameras (cams [n][4], poses [n][16], same

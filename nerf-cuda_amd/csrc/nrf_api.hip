@@ -1128,6 +1128,7 @@ void roi_rows(const int roi[4], int H, int& lo, int& hi) {
 // next slot of the context's ring of statistics counters + work queues (cleared on the call's own stream), so calls of
 // one context that overlap on different streams never share a queue.
 // rows_out (optional): per view the rows [lo, hi) its region of interest covers.
+constexpr float MAX_CAMERA_DISTANCE = 4096.0f;  // in the reference's ngp units (0.33 x the nerf pose's + 0.5), see render_views_impl
 struct ProgressArgs {
   unsigned* done;   // device [n_views][tiles_y], zeroed on the stream before the launches
   unsigned* flags;  // pinned host [n_views][tiles_y]
@@ -1160,6 +1161,17 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
       nerf_matrix_to_ngp(poses + 16 * (size_t)(first + v), c->desc.scale, VB.v[v].R, VB.v[v].org);
       for (int i = 0; i < 4; ++i) VB.v[v].cam[i] = cams[4 * (size_t)(first + v) + i];
       view_roi(VB.v[v].R, VB.v[v].org, VB.v[v].cam, c->dm.occ_box, c->W, c->H, VB.v[v].roi);
+      {
+        // A camera thousands of scene sizes away: t + dt == t in fp32 once t passes ~2^24 dt (dt_min = 0.0034: t ~ 5.7e4), the
+        // march of render_utils.h:593-653 stops advancing and never ends (the reference hangs there; so would this kernel).
+        // Long before that the object is far below a pixel: such a view is background (an empty region of interest).
+        const float* o = VB.v[v].org;
+        const float far2 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+        if (!(far2 <= MAX_CAMERA_DISTANCE * MAX_CAMERA_DISTANCE)) {
+          VB.v[v].roi[0] = VB.v[v].roi[1] = 0;
+          VB.v[v].roi[2] = VB.v[v].roi[3] = -1;
+        }
+      }
       if (rows_out) roi_rows(VB.v[v].roi, c->H, rows_out[2 * (first + v)], rows_out[2 * (first + v) + 1]);
     }
     if (prog) {  // (the kernel indexes its progress arrays by the launch's own view numbers)

@@ -659,6 +659,12 @@ def test_unusual_inputs_terminate_and_stay_finite(ctx):
     assert go(7, 5, syn.default_camera(7, 5), pose)[1] > 0
     rgba, n = go(64, 48, cam, np.eye(4, dtype=np.float32))
     assert n > 0 and rgba[..., 3].max() <= 1.0 + 1e-5
+    # a camera thousands of scene sizes away (t + dt == t in fp32 far enough out: the reference's march never ends): beyond
+    # 4096 ngp units a view is background.  Tested where the march would still advance first, then where it would not.
+    for radius in (2000.0 / 0.33, 5000.0 / 0.33, 3.0e6, 1.0e12):
+        rgba, n = go(64, 48, cam, syn.orbit_pose(30, 30, radius=radius))
+        if radius > 4500.0 / 0.33:
+            assert n == 0 and np.all(rgba[..., :3] == 1.0) and np.all(rgba[..., 3] == 0.0), radius
 
 
 @pytest.mark.parametrize("H,bound,cascade,dt_gamma", [(30, 1.0, 1, 1.0 / 128), (96, 1.0, 1, 1.0 / 128), (64, 1.5, 2, 0.0),
