@@ -829,6 +829,45 @@ int nrfo_march(const nrfo_model* m, const nrf_options* o, const float* rays_o, c
   return NRF_OK;
 }
 
+// The trip STARTS of kernel_march_rays (render_utils.h:593-653) along one ray of an EMPTY volume: every trip takes the
+// `else` branch (hop to the next voxel, :639-651), and the t at which each trip begins is recorded.  This is what decides
+// where the march tests the occupancy grid; tests/test_barrier_lemma.py checks the HIP path's barrier fast-forward
+// (nerf-cuda_amd/csrc/nrf_device.h) against it.  Returns the number of trips (the first `cap` starts are stored).
+uint32_t nrfo_march_trip_starts(float bound, uint32_t C, uint32_t H, float dt_gamma, const float o[3], const float d[3], float t,
+                                float far, float* starts, uint32_t cap) {
+  const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+  const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+  const float dt_min = 2 * 1.7320508075688772f / 1024;
+  const float dt_max = 2 * bound / (float)H;
+  const float Hm1 = (float)(H - 1);
+  uint32_t n = 0;
+  while (t < far) {
+    if (n < cap) starts[n] = t;
+    ++n;
+    const float x = clampf(ox + t * dx, -bound, bound);
+    const float y = clampf(oy + t * dy, -bound, bound);
+    const float z = clampf(oz + t * dz, -bound, bound);
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    const int level = (int)fminf((float)C - 1, fmaxf(0, (float)exponent));
+    const float mip_bound = fminf(exp2f((float)level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / Hm1 * 2 - 1) * mip_bound - x) * rdx;
+    const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / Hm1 * 2 - 1) * mip_bound - y) * rdy;
+    const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / Hm1 * 2 - 1) * mip_bound - z) * rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+      const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+      t += dt;
+    } while (t < tt);
+  }
+  return n;
+}
+
 int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, uint32_t n,
                    uint32_t n_step, float* rays_t, float* state) {
   for (uint32_t i = 0; i < n; ++i)

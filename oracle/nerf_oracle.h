@@ -75,6 +75,10 @@ int nrfo_march(const nrfo_model* m, const nrf_options* o, const float* rays_o,
                uint32_t n_step, float* xyzs, float* dirs, float* deltas);
 int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, uint32_t n,
                    uint32_t n_step, float* rays_t, float* state);
+/* the t at which every trip of kernel_march_rays begins, along one ray of an EMPTY volume (the hop arithmetic of
+ * render_utils.h:639-651 alone decides them); returns the trip count, stores the first `cap` starts                   */
+uint32_t nrfo_march_trip_starts(float bound, uint32_t cascade, uint32_t H, float dt_gamma, const float o[3],
+                                const float d[3], float t, float far, float* starts, uint32_t cap);
 
 /* NerfRender::render_frame.  rgba [H][W][4], depth [H][W] row-major.
  * n_threads <= 0 -> all cores.                                              */
