@@ -502,6 +502,7 @@ def main():
         if not replica and not args.no_extras:
             out["api"] = api_bench(nh, torch, dev, desc, cam, poses, W, H)
             out["fast_interp"] = fast_interp_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V, ms_per_step / V_step)
+            out["march_fast_forward"] = march_ff_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V)
             with torch.cuda.stream(stream):
                 out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
             if not args.no_cpu_baseline:
@@ -632,6 +633,46 @@ def fast_interp_bench(nh, torch, dev, desc, cams, poses, W, H, V, base_ms_per_fr
             "psnr_db_vs_default_frame": round(99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse), 2),
             "max_abs_vs_default_frame": float(np.abs(res[1][2] - res[0][2]).max()),
             "tolerance": "features within 4 x 2^-11 of the bit-exact ones, frames <= 2/255 (tests/test_parity_gpu.py)"}
+
+
+def march_ff_bench(nh, torch, dev, desc, cams, poses, W, H, V):
+    """The barrier fast-forward of the march (nrf_device.h; on by default, part of the headline) against a context created
+    with NRF_MARCH_FF=0, which simulates every trip ahead of a ray's first possible sample as rounds 1-2 did: the same
+    launch as the headline step, device time, and whether the frames are the same bits."""
+    import os
+
+    import numpy as np
+
+    res = {}
+    for ff in ("0", "1"):
+        saved = os.environ.get("NRF_MARCH_FF")
+        os.environ["NRF_MARCH_FF"] = ff
+        try:
+            g = nh.NerfHip(dev.index)  # (the switch is read at nrf_create)
+        finally:
+            if saved is None:
+                os.environ.pop("NRF_MARCH_FF", None)
+            else:
+                os.environ["NRF_MARCH_FF"] = saved
+        g.load_model(desc)
+        g.set_resolution(W, H)
+        g.set_max_views(V)
+        st = torch.cuda.Stream(dev)
+        ms = []
+        for i in range(6):
+            g.render_views(cams, poses, stream=st.cuda_stream)
+            torch.cuda.synchronize(dev)
+            ms.append(float(g.stats().render_ms))
+        frames = [g.read_view_f32(v) for v in (0, V - 1)]
+        res[ff] = (float(np.mean(ms[2:])), int(g.stats().n_composited), frames)
+        g.close()
+    same = res["0"][1] == res["1"][1] and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(res["0"][2], res["1"][2]))
+    return {"what": "exact shortcut of the march, default ON (the headline includes it): a ray steps straight to its last barrier plane "
+                    "ahead of its first possible sample instead of simulating the reference's cell trips there; against NRF_MARCH_FF=0 "
+                    "on the same launch",
+            "ms_per_frame": round(res["1"][0] / V, 4), "ms_per_frame_every_trip_simulated": round(res["0"][0] / V, 4),
+            "speedup": round(res["0"][0] / res["1"][0], 4), "frames_bit_identical": bool(same),
+            "tests": "tests/test_persistent_gpu.py (both schedulings, 1-5 cascades), tests/test_barrier_lemma.py (CPU, against the reference's trip loop)"}
 
 
 def mlp_microbench(ctx, torch, dev):

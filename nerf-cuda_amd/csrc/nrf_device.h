@@ -533,29 +533,33 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
 //   eps: tt is computed as fl(t + fl(fl(b - x) * rd)) with x = fl(o + fl(t d)): x is within ~2 ulp(|o| + |t d|) of the
 //   true position, the products / sums add ~3 more relative roundings of a value <= t: |tt - T| <= ~1e-6 (1 + |rd_a|) for
 //   magnitudes up to ~8; eps = 4e-6 (t_skip + 2) (1 + |rd_a|) leaves a factor of four and scales with the magnitudes.
-// MARCH_UNIT only (one cascade, mip_bound 1): with several cascades the planes of different levels are not ordered along a ray.
-__device__ __forceinline__ float barrier_before(const float* ctab, int H, float o, float d, float rd, float t_skip) {
-  // the last plane of a NEGATIVE axis the ray passes before t_skip: returns T + eps, or -inf when there is none
+// One cascade (mip_bound = min(1, bound)); with several cascades the planes of different levels are not ordered along a ray:
+// fast_forward_to_barrier_pow2 below.
+__device__ __forceinline__ float barrier_before(const float* ctab, int H, float mb, float o, float d, float rd, float t_skip) {
+  // the last plane of a NEGATIVE axis the ray passes before t_skip: returns T + eps, or -inf when there is none.
+  // mb = the level's mip_bound.  Slab n's plane is ctab[n], n = 0 .. H-1; a position beyond the grid (one cascade with
+  // bound > 1) clamps into slab H-1, whose plane it has not passed yet -- ctab[H] is no slab's plane.
   const float NONE = -3.402823466e+38f;
   if (!(d < 0.0f) || !(rd > -3.0e38f)) return NONE;
-  const float xs = o + t_skip * d;                               // (approximate) position at t_skip
-  float v = ceilf((xs + 1.0f) * (0.5f * (float)(H - 1)));        // first plane index at or above it
-  v = clamp3(v, 0.0f, (float)H);
+  const float xs = o + t_skip * d;                                    // (approximate) position at t_skip
+  const float v = clamp3(ceilf((xs / mb + 1.0f) * (0.5f * (float)(H - 1))), 0.0f, (float)H);  // first plane index at or above it
   int n = (int)v;
+  if (n > H - 1) return NONE;
   const float eps = 4.0e-6f * (t_skip + 2.0f) * (1.0f + fabsf(rd));
   float e = (ctab[n] - o) * rd + eps;
   if (!(e <= t_skip)) {  // the approximate position put the plane a hair behind t_skip: the one before it
-    n = min(n + 1, H);
+    if (++n > H - 1) return NONE;
     e = (ctab[n] - o) * rd + eps;
   }
   return e <= t_skip ? e : NONE;
 }
 
-__device__ __forceinline__ float fast_forward_to_barrier(const MarchConst& c, const float* ctab, const float o[3], const float d[3],
+// mb: the mip_bound of the only level, min(1, bound)
+__device__ __forceinline__ float fast_forward_to_barrier(const MarchConst& c, const float* ctab, float mb, const float o[3], const float d[3],
                                                          float rdx, float rdy, float rdz, float t, float t_skip, float far) {
-  const float tb = fminf(fmaxf(barrier_before(ctab, (int)c.H, o[0], d[0], rdx, t_skip),
-                               fmaxf(barrier_before(ctab, (int)c.H, o[1], d[1], rdy, t_skip),
-                                     barrier_before(ctab, (int)c.H, o[2], d[2], rdz, t_skip))), far);
+  const float tb = fminf(fmaxf(barrier_before(ctab, (int)c.H, mb, o[0], d[0], rdx, t_skip),
+                               fmaxf(barrier_before(ctab, (int)c.H, mb, o[1], d[1], rdy, t_skip),
+                                     barrier_before(ctab, (int)c.H, mb, o[2], d[2], rdz, t_skip))), far);
   // every step below is a member before e: t < tb <= T + eps <= t_skip, and t < far as in `while (t < far ...)`
   // (an exact k-step jump -- t + k dt_max is one exact fma while t stays in its binade and dt_max is a multiple of its ulp --
   //  was built and measured: 0.4 % SLOWER than this four-instruction loop; the division and frexp per binade cost more)
@@ -563,7 +567,7 @@ __device__ __forceinline__ float fast_forward_to_barrier(const MarchConst& c, co
   return t;
 }
 
-// Several cascades (MARCH_POW2: H = 2^k, bound = 2^b).  A trip's level follows its position: level L where the max-norm m of
+// Several cascades (any H, any bound).  A trip's level follows its position: level L where the max-norm m of
 // the position lies in [2^(L-1), 2^L) (L = 0: m < 1; L = C-1: everything beyond), and a level-L trip hops on level L's
 // planes b_L(n) = ((n / (H-1)) * 2 - 1) * mip_bound(L).  Planes of different levels are not ordered along a ray, so a level-L
 // plane at time T (negative axis a) is a barrier only when no trip of another level can reach past it:
@@ -607,9 +611,9 @@ __device__ __forceinline__ float fast_forward_to_barrier_pow2(const MarchConst& 
     int ex;
     (void)frexpf(fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz))), &ex);
     const int L = min(max(ex, 0), C - 1);
-    const float mb = ldexpf(1.0f, min(L, c.log2_bound));
+    const float mb = fminf(ldexpf(1.0f, L), c.bound);  // mip_bound(L)
     const float* tab = ctab + (uint32_t)L * (uint32_t)(H + 1);
-    const float slab_next = slab0 * ldexpf(1.0f, min(L + 1, c.log2_bound));
+    const float slab_next = slab0 * fminf(ldexpf(1.0f, L + 1), c.bound);
     const bool has_in = L >= 1, has_out = L <= C - 2;
     float ai = 0.f, bi = 0.f, ao = 0.f, bo = 0.f;
     const bool ok_in = has_in ? cube_interval(ldexpf(1.0f, L - 1) + pad, o, rd, ai, bi) : true;
@@ -621,9 +625,10 @@ __device__ __forceinline__ float fast_forward_to_barrier_pow2(const MarchConst& 
       const float eps = 4.0e-6f * mag * (1.0f + ard);
       const float xs = o[a] + t_hi * d[a];
       int n = (int)clamp3(ceilf((xs / mb + 1.0f) * (0.5f * (float)(H - 1))), 0.0f, (float)H);
+      if (n > H - 1) continue;  // (beyond the level's grid: clamped into slab H-1, above its plane)
       float T = (tab[n] - o[a]) * rd[a], e = T + eps;
       if (!(e <= t_hi)) {
-        n = min(n + 1, H);
+        if (++n > H - 1) continue;
         T = (tab[n] - o[a]) * rd[a];
         e = T + eps;
       }
@@ -635,7 +640,7 @@ __device__ __forceinline__ float fast_forward_to_barrier_pow2(const MarchConst& 
       for (int Lp = L + 2; Lp <= C - 1 && ok; ++Lp) {                 // (O)
         float a2, b2;
         ok = cube_interval(ldexpf(1.0f, Lp - 1) - pad, o, rd, a2, b2);
-        ok = ok && a2 <= T - slab0 * ldexpf(1.0f, min(Lp, c.log2_bound)) * ard - eps && e <= b2;
+        ok = ok && a2 <= T - slab0 * fminf(ldexpf(1.0f, Lp), c.bound) * ard - eps && e <= b2;
       }
       if (ok) best = fmaxf(best, e);
     }

@@ -850,8 +850,12 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
       if (last < far_m) far_m = last;
       if (any) t_skip = first;
 #if NRF_MARCH_FF
-      if (MARCH == MARCH_UNIT && COARSE_LDS && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
-      if (MARCH == MARCH_POW2 && COARSE_LDS && any && P.march_ff != 0) t = fast_forward_to_barrier_pow2(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      if (any && P.march_ff != 0) {  // (the generic march: any grid size / bound; its table sits in LDS or in global memory)
+        const float* tab = COARSE_LDS ? ctab_lds : M.cell_bound;
+        if (MARCH == MARCH_UNIT) t = fast_forward_to_barrier(mc, tab, 1.0f, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+        else if (MARCH == MARCH_POW2 || mc.C > 1) t = fast_forward_to_barrier_pow2(mc, tab, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+        else t = fast_forward_to_barrier(mc, tab, fminf(1.0f, mc.bound), o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      }
 #endif
     }
     if (alive) {  // direction encoding: only rays that will evaluate the network need it
@@ -1221,8 +1225,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
       if (last < far_m) far_m = last;
       if (any) t_skip = first;
 #if NRF_MARCH_FF
-      if (MARCH == MARCH_UNIT && any && P.march_ff != 0) t = fast_forward_to_barrier(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
-      if (MARCH == MARCH_POW2 && any && P.march_ff != 0) t = fast_forward_to_barrier_pow2(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      if (any && P.march_ff != 0) {
+        if (MARCH == MARCH_UNIT) t = fast_forward_to_barrier(mc, ctab_lds, 1.0f, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+        else if (MARCH == MARCH_POW2 || mc.C > 1) t = fast_forward_to_barrier_pow2(mc, ctab_lds, o, d, rdx, rdy, rdz, t, t_skip, far_m);
+        else t = fast_forward_to_barrier(mc, ctab_lds, fminf(1.0f, mc.bound), o, d, rdx, rdy, rdz, t, t_skip, far_m);
+      }
 #endif
     }
     TileAcc acc;

@@ -38,20 +38,25 @@ def ctab(level, n, H, bound):
     return f(f(f(f(n) / f(H - 1)) * f(2) - f(1)) * mb)
 
 
-def barrier_unit(H, o, d, rd, t_skip):
-    """fast_forward_to_barrier (one cascade, mip_bound 1): max over the negative axes of barrier_before"""
+def barrier_unit(H, o, d, rd, t_skip, mb=1.0):
+    """fast_forward_to_barrier (one cascade, mip_bound mb = min(1, bound)): max over the negative axes of barrier_before"""
     best = NONE
+    mb = f(mb)
     for a in range(3):
         if not (d[a] < 0) or not (rd[a] > f(-3.0e38)):
             continue
         xs = f(o[a] + f(t_skip * d[a]))
-        v = clamp3(np.ceil(f(f(xs + f(1)) * f(f(0.5) * f(H - 1)))), 0, H)
+        v = clamp3(np.ceil(f(f(f(xs / mb) + f(1)) * f(f(0.5) * f(H - 1)))), 0, H)
         n = int(v)
+        if n > H - 1:
+            continue  # above the plane of the last slab (positions beyond the grid clamp into it): no plane passed yet
         eps = f(f(f(4.0e-6) * f(t_skip + f(2))) * f(f(1) + abs(rd[a])))
-        e = f(f(f(ctab(0, n, H, 1.0) - o[a]) * rd[a]) + eps)
+        e = f(f(f(ctab(0, n, H, mb) - o[a]) * rd[a]) + eps)
         if not (e <= t_skip):
-            n = min(n + 1, H)
-            e = f(f(f(ctab(0, n, H, 1.0) - o[a]) * rd[a]) + eps)
+            n += 1
+            if n > H - 1:
+                continue
+            e = f(f(f(ctab(0, n, H, mb) - o[a]) * rd[a]) + eps)
         if e <= t_skip:
             best = max(best, e)
     return best
@@ -70,7 +75,6 @@ def cube_interval(s, o, rd):
 
 def barrier_pow2(C_, H, bound, o, d, rd, t, t_skip):
     """fast_forward_to_barrier_pow2: the search over shells, the window conditions (W) and (O)"""
-    log2_bound = int(np.log2(bound))
     mag = f(f(t_skip + f(bound)) + f(2))
     pad = f(f(1.0e-4) * mag)
     slab0 = f(f(2) / f(H))
@@ -81,8 +85,8 @@ def barrier_pow2(C_, H, bound, o, d, rd, t, t_skip):
         q = [clamp3(f(o[a] + f(t_hi * d[a])), -bound, bound) for a in range(3)]
         _, ex = np.frexp(f(max(abs(q[0]), abs(q[1]), abs(q[2]))))
         L = min(max(int(ex), 0), C_ - 1)
-        mb = f(2.0 ** min(L, log2_bound))
-        slab_next = f(slab0 * f(2.0 ** min(L + 1, log2_bound)))
+        mb = f(min(f(2.0 ** L), f(bound)))
+        slab_next = f(slab0 * f(min(f(2.0 ** (L + 1)), f(bound))))
         has_in, has_out = L >= 1, L <= C_ - 2
         ok_in, ai, bi = cube_interval(f(f(2.0 ** (L - 1)) + pad), o, rd) if has_in else (True, f(0), f(0))
         ok_out, ao, bo = cube_interval(f(f(2.0 ** L) - pad), o, rd) if has_out else (True, f(0), f(0))
@@ -93,10 +97,14 @@ def barrier_pow2(C_, H, bound, o, d, rd, t, t_skip):
             eps = f(f(f(4.0e-6) * mag) * f(f(1) + ard))
             xs = f(o[a] + f(t_hi * d[a]))
             n = int(clamp3(np.ceil(f(f(f(xs / mb) + f(1)) * f(f(0.5) * f(H - 1)))), 0, H))
+            if n > H - 1:
+                continue
             T = f(f(ctab(L, n, H, bound) - o[a]) * rd[a])
             e = f(T + eps)
             if not (e <= t_hi):
-                n = min(n + 1, H)
+                n += 1
+                if n > H - 1:
+                    continue
                 T = f(f(ctab(L, n, H, bound) - o[a]) * rd[a])
                 e = f(T + eps)
             if not (e <= t_hi):
@@ -110,7 +118,7 @@ def barrier_pow2(C_, H, bound, o, d, rd, t, t_skip):
             Lp = L + 2
             while Lp <= C_ - 1 and ok:
                 ok, a2, b2 = cube_interval(f(f(2.0 ** (Lp - 1)) - pad), o, rd)
-                ok = ok and a2 <= f(f(T - f(f(slab0 * f(2.0 ** min(Lp, log2_bound))) * ard)) - eps) and e <= b2
+                ok = ok and a2 <= f(f(T - f(f(slab0 * f(min(f(2.0 ** Lp), f(bound)))) * ard)) - eps) and e <= b2
                 Lp += 1
             if ok:
                 best = max(best, e)
@@ -158,6 +166,9 @@ CASES = [  # cascades, bound, H, dt_gamma, camera distance up to (in bounds), ra
     (1, 1.0, 128, 1.0 / 128.0, 5.0, 700), (1, 1.0, 64, 0.0, 4.0, 300), (1, 1.0, 32, 1.0 / 64.0, 6.0, 500), (1, 1.0, 128, 1.0 / 256.0, 5.0, 400),
     (2, 2.0, 64, 1.0 / 128.0, 4.0, 500), (3, 4.0, 128, 1.0 / 128.0, 4.0, 500), (5, 16.0, 64, 1.0 / 128.0, 3.0, 700), (5, 16.0, 128, 1.0 / 32.0, 3.0, 500),
     (4, 8.0, 32, 1.0 / 64.0, 3.0, 400), (2, 2.0, 64, 0.0, 3.0, 200),
+    # positions beyond the grid (one cascade with bound > 1, fewer cascades than the bound needs), grids / bounds that are not powers of two
+    (1, 2.0, 64, 1.0 / 128.0, 4.0, 1200), (1, 4.0, 128, 1.0 / 64.0, 3.0, 600), (2, 16.0, 64, 1.0 / 128.0, 3.0, 600), (1, 0.75, 100, 1.0 / 128.0, 5.0, 400),
+    (3, 3.0, 96, 1.0 / 128.0, 4.0, 500), (1, 1.0, 100, 0.0, 4.0, 300),
 ]
 
 
@@ -180,7 +191,7 @@ def test_first_member_behind_the_barrier_is_a_trip_start(cascade, bound, H, dt_g
         trip_starts = set(starts[:n].tolist())
         for t_skip in rng.uniform(float(near), float(far), size=3).astype(np.float32):
             if cascade == 1:
-                e = barrier_unit(H, o, d, rd, f(t_skip))
+                e = barrier_unit(H, o, d, rd, f(t_skip), min(1.0, bound))
             else:
                 e = barrier_pow2(cascade, H, bound, o, d, rd, near, f(t_skip))
             checked += 1

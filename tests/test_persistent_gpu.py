@@ -179,6 +179,24 @@ def test_barrier_fast_forward_with_cascades(sched, cascade, bound, grid_H, dt_ga
     _same(_render(desc, 240, 160, poses, sched, opts_kw=kw), ref, (cascade, bound, grid_H, dt_gamma, "fast-forward, cascades"))
 
 
+@pytest.mark.parametrize("sched", [PERSISTENT, STRIP])
+@pytest.mark.parametrize("kw", [
+    dict(H=96),                                                       # a grid that is no power of two: the generic march
+    dict(H=64, cascade=1, bound=2.0),                                 # one cascade, bound 2: positions beyond the grid clamp into its last slabs
+    dict(H=48, cascade=3, bound=3.0),                                 # a bound that is no power of two, several cascades
+    dict(H=64, n_neurons=32, n_features_per_level=4, n_levels=8),     # the generic network instance (always the generic march)
+    dict(H=64, cascade=3, bound=4.0, dir_otype="Frequency", n_frequencies=12),  # wide instance, cascades
+], ids=["H96", "bound2-1cascade", "bound3-3cascades", "generic-net", "wide-cascades"])
+def test_barrier_fast_forward_other_march_instances(sched, kw):
+    """The fast-forward in the generic march (any grid size / bound, the generic network instance) and next to the other
+    network instances; identical frames with NRF_MARCH_FF=0."""
+    desc, _ = models.build_model(log2_hashmap_size=13, **kw)[:2]
+    poses = _octant_poses()[::2] + _octant_poses(radius=2.4 / 0.33)[1::3] + _poses("inside", 2)
+    opts = {"dt_gamma": 1.0 / 128.0, "max_steps": 1024}
+    ref = _render(desc, 200, 144, poses, dict(sched, NRF_MARCH_FF="0"), opts_kw=opts)
+    _same(_render(desc, 200, 144, poses, sched, opts_kw=opts), ref, (kw, "fast-forward, other instances"))
+
+
 def test_persistent_kernel_with_cascades_and_sample_cap():
     """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
     dilated table, 44 KB of march tables in LDS) and a small max_steps."""
