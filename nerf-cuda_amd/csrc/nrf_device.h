@@ -532,10 +532,10 @@ __device__ __forceinline__ int march_next(const MarchConst& c, const uint32_t* _
 // direction component, or whose last plane lies before their start, keep their trips.
 //   eps: tt is computed as fl(t + fl(fl(b - x) * rd)) with x = fl(o + fl(t d)): x is within ~2 ulp(|o| + |t d|) of the
 //   true position, the products / sums add ~3 more relative roundings of a value <= t: |tt - T| <= ~1e-6 (1 + |rd_a|) for
-//   magnitudes up to ~8; eps = 4e-6 (t_skip + 2) (1 + |rd_a|) leaves a factor of four and scales with the magnitudes.
+//   magnitudes up to ~8; eps = 4e-6 (t_skip + bound + 2) (1 + |rd_a|) leaves a factor of four and scales with the magnitudes.
 // One cascade (mip_bound = min(1, bound)); with several cascades the planes of different levels are not ordered along a ray:
 // fast_forward_to_barrier_pow2 below.
-__device__ __forceinline__ float barrier_before(const float* ctab, int H, float mb, float o, float d, float rd, float t_skip) {
+__device__ __forceinline__ float barrier_before(const float* ctab, int H, float mb, float mag, float o, float d, float rd, float t_skip) {
   // the last plane of a NEGATIVE axis the ray passes before t_skip: returns T + eps, or -inf when there is none.
   // mb = the level's mip_bound.  Slab n's plane is ctab[n], n = 0 .. H-1; a position beyond the grid (one cascade with
   // bound > 1) clamps into slab H-1, whose plane it has not passed yet -- ctab[H] is no slab's plane.
@@ -545,7 +545,7 @@ __device__ __forceinline__ float barrier_before(const float* ctab, int H, float 
   const float v = clamp3(ceilf((xs / mb + 1.0f) * (0.5f * (float)(H - 1))), 0.0f, (float)H);  // first plane index at or above it
   int n = (int)v;
   if (n > H - 1) return NONE;
-  const float eps = 4.0e-6f * (t_skip + 2.0f) * (1.0f + fabsf(rd));
+  const float eps = 4.0e-6f * mag * (1.0f + fabsf(rd));  // mag = t_skip + bound + 2 >= the magnitudes of o, t d and the position
   float e = (ctab[n] - o) * rd + eps;
   if (!(e <= t_skip)) {  // the approximate position put the plane a hair behind t_skip: the one before it
     if (++n > H - 1) return NONE;
@@ -557,9 +557,10 @@ __device__ __forceinline__ float barrier_before(const float* ctab, int H, float 
 // mb: the mip_bound of the only level, min(1, bound)
 __device__ __forceinline__ float fast_forward_to_barrier(const MarchConst& c, const float* ctab, float mb, const float o[3], const float d[3],
                                                          float rdx, float rdy, float rdz, float t, float t_skip, float far) {
-  const float tb = fminf(fmaxf(barrier_before(ctab, (int)c.H, mb, o[0], d[0], rdx, t_skip),
-                               fmaxf(barrier_before(ctab, (int)c.H, mb, o[1], d[1], rdy, t_skip),
-                                     barrier_before(ctab, (int)c.H, mb, o[2], d[2], rdz, t_skip))), far);
+  const float mag = t_skip + c.bound + 2.0f;
+  const float tb = fminf(fmaxf(barrier_before(ctab, (int)c.H, mb, mag, o[0], d[0], rdx, t_skip),
+                               fmaxf(barrier_before(ctab, (int)c.H, mb, mag, o[1], d[1], rdy, t_skip),
+                                     barrier_before(ctab, (int)c.H, mb, mag, o[2], d[2], rdz, t_skip))), far);
   // every step below is a member before e: t < tb <= T + eps <= t_skip, and t < far as in `while (t < far ...)`
   // (an exact k-step jump -- t + k dt_max is one exact fma while t stays in its binade and dt_max is a multiple of its ulp --
   //  was built and measured: 0.4 % SLOWER than this four-instruction loop; the division and frexp per binade cost more)

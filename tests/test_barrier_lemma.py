@@ -38,7 +38,7 @@ def ctab(level, n, H, bound):
     return f(f(f(f(n) / f(H - 1)) * f(2) - f(1)) * mb)
 
 
-def barrier_unit(H, o, d, rd, t_skip, mb=1.0):
+def barrier_unit(H, o, d, rd, t_skip, mb=1.0, bound=1.0):
     """fast_forward_to_barrier (one cascade, mip_bound mb = min(1, bound)): max over the negative axes of barrier_before"""
     best = NONE
     mb = f(mb)
@@ -50,7 +50,7 @@ def barrier_unit(H, o, d, rd, t_skip, mb=1.0):
         n = int(v)
         if n > H - 1:
             continue  # above the plane of the last slab (positions beyond the grid clamp into it): no plane passed yet
-        eps = f(f(f(4.0e-6) * f(t_skip + f(2))) * f(f(1) + abs(rd[a])))
+        eps = f(f(f(4.0e-6) * f(f(t_skip + f(bound)) + f(2))) * f(f(1) + abs(rd[a])))
         e = f(f(f(ctab(0, n, H, mb) - o[a]) * rd[a]) + eps)
         if not (e <= t_skip):
             n += 1
@@ -191,7 +191,7 @@ def test_first_member_behind_the_barrier_is_a_trip_start(cascade, bound, H, dt_g
         trip_starts = set(starts[:n].tolist())
         for t_skip in rng.uniform(float(near), float(far), size=3).astype(np.float32):
             if cascade == 1:
-                e = barrier_unit(H, o, d, rd, f(t_skip), min(1.0, bound))
+                e = barrier_unit(H, o, d, rd, f(t_skip), min(1.0, bound), bound)
             else:
                 e = barrier_pow2(cascade, H, bound, o, d, rd, near, f(t_skip))
             checked += 1
