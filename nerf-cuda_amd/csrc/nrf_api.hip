@@ -226,6 +226,7 @@ struct nrf_context {
   int plan_max_pos = 1 << 14;  // launches of up to this many strips are planned (NRF_PLAN_MAX_POS; 0: never) -- one or two 1080p views
   void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
   int call_index = 0;          // ring position of the last render call
+  bool allow_gen_fast_grid = true;  // NRF_GEN_FAST_GRID=0: the generic instance always encodes with gen_level (A/B runs)
   int march_ff = 1;            // NRF_MARCH_FF=0: no barrier fast-forward ahead of t_skip (A/B runs, equality tests)
   int tail_split = 1;          // NRF_TAIL_SPLIT=0: no tail splitting in the persistent kernel (A/B runs)
   void* d_rgb8 = nullptr;
@@ -742,6 +743,7 @@ int nrf_create(int device, nrf_context** out) {
   }
   if (const char* e = std::getenv("NRF_TAIL_SPLIT")) c->tail_split = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("NRF_MARCH_FF")) c->march_ff = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("NRF_GEN_FAST_GRID")) c->allow_gen_fast_grid = std::atoi(e) != 0;
   HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
   HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
   if (const char* e = std::getenv("NRF_PLAN_MAX_POS")) c->plan_max_pos = std::max(0, std::min(std::atoi(e), (int)PLAN_CAP));
@@ -898,6 +900,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   if (generic || wide) {
     std::vector<_Float16>& fr = generic ? frags : frags_gen;
     G.F = F; G.interp = d->interpolation; G.n_levels = L; G.feat_raw = feat_raw; G.feat_w = feat_w;
+    G.fast_grid = (!generic_grid && F == 2 && d->interpolation == NRF_INTERP_LINEAR && c->allow_gen_fast_grid) ? 1u : 0u;
     G.feat_k = next_multiple(feat_w, 32u); G.width = Wn; G.dir_raw = raw; G.dir_w = dir_w; G.rgb_in = rgb_in;
     G.n_dens = d->density_hidden_layers + 1; G.n_rgb = d->rgb_hidden_layers + 1;
     const uint32_t max_k = G.feat_k > next_multiple(Wn, 32u) ? G.feat_k : next_multiple(Wn, 32u);

@@ -51,7 +51,9 @@ struct GenModel {
   uint32_t n_dens, n_rgb;   // matmuls of the density / rgb MLP (hidden layers + 1)
   uint32_t act_stride; // halves per row of the activation buffers X, Y
   uint32_t dir_stride; // halves per row of the per-pass direction rows
-  uint32_t pad0, pad1;
+  uint32_t fast_grid;  // 1: F == 2, Linear interpolation, every level dense / power-of-two hashed / LV_ADD_POW2 -- the feature rows come
+                       // from the register-resident instance's level_gather / level_interp (gen_encode_rows)
+  uint32_t pad1;
   GenLayer layer[GEN_MAX_LAYERS];  // density layers, then rgb layers
 };
 
@@ -381,6 +383,31 @@ __device__ __forceinline__ void gen_encode_rows(const DevModel& M, const GenMode
                                                 const float (&p01)[GEN_TILES][3], const bool (&valid)[GEN_TILES]) {
   const int g = lane >> 4, c = lane & 15;
   const half_t* __restrict__ grid = reinterpret_cast<const half_t*>(M.grid);
+  if (G.fast_grid != 0u) {
+    // The grid is the register-resident instance's kind (only the networks behind it are not): its gathers -- byte-offset MUBUF
+    // loads with the per-level constants of LevelParams, every load of the lane's (up to four) levels in flight before the
+    // first is consumed -- instead of gen_level's literal index arithmetic, one level at a time.  Same values: both follow
+    // grid.h:100-117 / :186-267 (tests/test_generic_gpu.py compares the rows with the oracle's bit for bit).
+#pragma unroll
+    for (int n = 0; n < GEN_TILES; ++n) {
+      half_t* row = Lw.X + (size_t)(16 * n + c) * G.act_stride;
+      for (uint32_t j = G.feat_raw + (uint32_t)g; j < G.feat_k; j += 4u) row[j] = (half_t)0.0f;
+      if (!valid[n]) continue;
+      uint32_t v[4][8];
+      float fr[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lv = (uint32_t)g + 4u * (uint32_t)j;
+        if (lv < G.n_levels) level_gather<0>(M.grid, M.grid_bytes, lvs[lv], p01[n][0], p01[n][1], p01[n][2], v[j], fr[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lv = (uint32_t)g + 4u * (uint32_t)j;
+        if (lv < G.n_levels) *reinterpret_cast<uint32_t*>(row + 2u * lv) = level_interp<false>(v[j], fr[j]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < GEN_TILES; ++n) {
     half_t* row = Lw.X + (size_t)(16 * n + c) * G.act_stride;

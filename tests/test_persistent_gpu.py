@@ -197,6 +197,26 @@ def test_barrier_fast_forward_other_march_instances(sched, kw):
     _same(_render(desc, 200, 144, poses, sched, opts_kw=opts), ref, (kw, "fast-forward, other instances"))
 
 
+@pytest.mark.parametrize("sched", [PERSISTENT, STRIP])
+@pytest.mark.parametrize("kw", [
+    dict(H=64, density_hidden_layers=2, rgb_hidden_layers=3),            # other depths: generic networks behind a standard grid
+    dict(H=64, n_neurons=32, n_levels=13),                               # fewer levels than 16 (lanes without a fourth level), 32 neurons
+    dict(H=64, log2_hashmap_size=12, sh_degree=6, n_levels=5),           # dense levels only + a few hashed ones
+    dict(H=32, cascade=2, bound=2.0, activation="Sigmoid"),              # another activation, two cascades
+], ids=["depths", "13levels-32n", "5levels-sh6", "sigmoid-2cascades"])
+def test_generic_instance_fast_grid_equals_literal_grid(sched, kw):
+    """gen_encode_rows takes the register-resident instance's gathers (level_gather / level_interp) when the grid is of its
+    kind (F = 2, Linear, dense / power-of-two levels); NRF_GEN_FAST_GRID=0 keeps gen_level's literal arithmetic.  Same
+    features, hence the same frames, bit for bit."""
+    kw = dict(kw)
+    log2T = kw.pop("log2_hashmap_size", 14)
+    env = dict(sched, NRF_WIDTH_INSTANCES="0")  # (16 / 32 / 128-neuron and SH models: the generic instance, not their own ones)
+    desc, _ = models.build_model(log2_hashmap_size=log2T, **kw)[:2]
+    poses = _poses("orbit", 3) + _poses("inside", 1)
+    ref = _render(desc, 240, 160, poses, dict(env, NRF_GEN_FAST_GRID="0"))
+    _same(_render(desc, 240, 160, poses, env), ref, (kw, "fast grid"))
+
+
 def test_persistent_kernel_with_cascades_and_sample_cap():
     """BASELINE config 4 shape (bound 16, five cascades: per-cascade visibility walks on the workgroup's own copy of the
     dilated table, 44 KB of march tables in LDS) and a small max_steps."""
