@@ -157,6 +157,37 @@ void pack_fragments_width(const std::vector<_Float16>& w16, int Wd, std::vector<
   for (int s = 0; s < KS; ++s) put(fR2 + s, R2, Wd, 0, [&](int g, int j) { return khid(s, g, j); });
 }
 
+// DEPTH instance (nrf_device.h DF_*, mlp_tiles_depth): 64 neurons, nd / nr hidden layers in the density / rgb MLP.  Parameter order
+// (tcnn): D0 [64][32] | (nd - 1) x [64][64] | D1 [16][64] | R0 [64][32] | (nr - 1) x [64][64] | R2 [16][64].  DEPTH_FRAGS fragments,
+// unused ones zero.
+void pack_fragments_depth(const std::vector<_Float16>& w16, int nd, int nr, std::vector<_Float16>& frags) {
+  frags.assign((size_t)DEPTH_FRAGS * 64 * 8, (_Float16)0.0f);
+  const int xd = nd - 1, xr = nr - 1;
+  const _Float16* D0 = w16.data();
+  const _Float16* DW = D0 + 64 * 32;
+  const _Float16* D1 = DW + (size_t)xd * 64 * 64;
+  const _Float16* R0 = D1 + 16 * 64;
+  const _Float16* RW = R0 + 64 * 32;
+  const _Float16* R2 = RW + (size_t)xr * 64 * 64;
+  auto khid = [](int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); };
+  auto put = [&](int f, const _Float16* Wm, int in, int m, auto kmap) {
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 8; ++j) {
+        const int k = kmap(l >> 4, j);
+        frags[((size_t)f * 64 + l) * 8 + j] = k < in ? Wm[(size_t)(16 * m + (l & 15)) * in + k] : (_Float16)0.0f;
+      }
+  };
+  for (int m = 0; m < 4; ++m) put(DF_D0 + m, D0, 32, m, [](int g, int j) { return 2 * (4 * (j >> 1) + g) + (j & 1); });
+  for (int s = 0; s < 2; ++s) put(DF_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+  for (int m = 0; m < 4; ++m) put(DF_R0 + m, R0, 32, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int s = 0; s < 2; ++s) put(DF_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+  for (int e = 0; e < xd + xr; ++e) {
+    const _Float16* Wm = e < xd ? DW + (size_t)e * 64 * 64 : RW + (size_t)(e - xd) * 64 * 64;
+    for (int m = 0; m < 4; ++m)
+      for (int s = 0; s < 2; ++s) put(DF_WW + 8 * e + 2 * m + s, Wm, 64, m, [&](int g, int j) { return khid(s, g, j); });
+  }
+}
+
 // Generic instance (nrf_generic.h gen_layer): fragment (m, s) of a layer W[N][K], lane l, element j =
 // W[16 m + (l & 15)][32 s + 8 (l >> 4) + j]  (natural K order), zero beyond K.
 void pack_generic_layer(const _Float16* Wm, uint32_t N, uint32_t K, std::vector<_Float16>& frags) {
@@ -881,7 +912,17 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                                     d->density_output_activation == NRF_ACT_NONE &&
                                     (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                                     d->sigma_activation == NRF_ACT_EXPONENTIAL;
-  const uint32_t hot_width = (base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u;
+  // ... and for its depth: 64 neurons with other numbers of hidden layers (>= 1 each, at most DEPTH_MAX_WW 64 -> 64 layers in all)
+  // keep the register-resident form as the DEPTH instance -- reported as hot_width 64
+  const bool base_shape_but_depth = !generic_grid && F == 2 && L == 16 && Wn == 64 && dir_w == 16 && d->interpolation == NRF_INTERP_LINEAR &&
+                                    d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+                                    d->density_output_activation == NRF_ACT_NONE &&
+                                    (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
+                                    d->sigma_activation == NRF_ACT_EXPONENTIAL && d->density_hidden_layers >= 1 && d->rgb_hidden_layers >= 1 &&
+                                    !(d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2) &&
+                                    (d->density_hidden_layers - 1) + (d->rgb_hidden_layers - 1) <= (uint32_t)DEPTH_MAX_WW;
+  const bool hot_depth = base_shape_but_depth && c->allow_width_instances;
+  const uint32_t hot_width = hot_depth ? 64u : ((base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u);
   // ... and for its direction encoding: SphericalHarmonics of degree 5..8 (32..64 padded values) keeps the register-resident
   // MLPs in the persistent kernel's NET_WIDE_SH form (per-ray rows of coefficients in LDS)
   const bool wide_sh = !generic_grid && F == 2 && L == 16 && Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 &&
@@ -893,7 +934,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   GenModel G;
   std::memset(&G, 0, sizeof(G));
   if (!generic) pack_fragments(w16, rgb_in, frags);
-  if (hot_width) pack_fragments_width(w16, (int)hot_width, frags_hot);
+  if (hot_depth) pack_fragments_depth(w16, (int)d->density_hidden_layers, (int)d->rgb_hidden_layers, frags_hot);
+  else if (hot_width) pack_fragments_width(w16, (int)hot_width, frags_hot);
   if (wide_sh) pack_fragments(w16, rgb_in, frags_hot);  // the wide layout: first rgb layer in RK_WIDE K steps
   // the generic description + fragments: the generic instance's model, and -- for a wide model -- what the stage
   // entry points nrf_encode_dir / nrf_mlp_forward run on (rows of the padded widths)
@@ -1008,6 +1050,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.gen_wave_bytes = gen_wave_bytes;
   M.gen_frag_bytes = generic ? (uint32_t)(frags.size() * 2) : 0u;
   M.hot_width = hot_width;
+  M.depth_xd = hot_depth ? d->density_hidden_layers - 1 : 0u;
+  M.depth_xr = hot_depth ? d->rgb_hidden_layers - 1 : 0u;
   M.wfrag_hot = (const uint4*)c->d_wfrag_hot;
   c->model_hot_width = hot_width;
   c->model_wide_sh = wide_sh;

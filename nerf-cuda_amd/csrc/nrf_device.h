@@ -92,6 +92,12 @@ struct MlpShape {
 static_assert(MlpShape<64>::D1 == FRAG_D1 && MlpShape<64>::R0 == FRAG_R0 && MlpShape<64>::R1 == FRAG_R1 && MlpShape<64>::R2 == FRAG_R2 &&
                   MlpShape<64>::N == N_FRAGS, "MlpShape<64> is the base.json layout");
 
+// DEPTH instance (64 neurons, any number of hidden layers in either MLP, tcnn's FullyFusedMLP n_hidden_layers): the layers of
+// base.json's shape plus a RUNTIME number of 64 -> 64 layers.  Fragment order in LDS / DevModel::wfrag_hot:
+//   D0 [64][32] m = 0..3 | D1 [16][64] s = 0..1 | R0 [64][32] m = 0..3 | R2 [16][64] s = 0..1 | the density MLP's 64 -> 64 layers
+//   (8 fragments each: 2 m + s) | the rgb MLP's 64 -> 64 layers
+enum : int { DF_D0 = 0, DF_D1 = 4, DF_R0 = 6, DF_R2 = 10, DF_WW = 12, DEPTH_MAX_WW = 5, DEPTH_FRAGS = DF_WW + 8 * DEPTH_MAX_WW };
+
 struct DevModel {
   const uint32_t* grid;      // half2 entries
   const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
@@ -138,7 +144,8 @@ struct DevModel {
   // a model of the base.json SHAPE with 16 / 32 / 128 neurons: `generic` is set (stage entry points, the per-strip kernel and
   // the density-grid generation run the generic instance), but its frames are rendered by a register-resident instance of
   // the persistent kernel of that width, from fragments in the MlpShape<width> order
-  uint32_t hot_width;       // 0, 16, 32 or 128
+  uint32_t hot_width;       // 0, 16, 32 or 128 -- or 64: the DEPTH instance (64 neurons, other numbers of hidden layers: depth_xd / depth_xr)
+  uint32_t depth_xd, depth_xr;  // hot_width == 64: 64 -> 64 layers of the density MLP (hidden layers - 1) and of the rgb MLP (hidden layers - 1)
   const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4; wide_sh: the wide layout (N_FRAGS_WIDE_ALL fragments)
   uint32_t wide_sh;         // SphericalHarmonics of degree 5..8 on the base.json shape: NET_WIDE_SH renders the frames (persistent kernel)
   uint32_t dir_w;           // padded width of the direction encoding (16 .. 80)
@@ -1107,6 +1114,107 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {  // network_output rows 0..2 (fp16)
+    out.rg[n] = pack_h2(dacc[n][0], dacc[n][1]);
+    out.bx[n] = pack_h2(dacc[n][2], dacc[n][3]);
+  }
+}
+
+// mlp_tiles for 64 neurons with a RUNTIME number of hidden layers (the DEPTH instance): xd / xr 64 -> 64 layers between the
+// first and the output layer of the density / rgb MLP (base.json: 0 / 1).  The same in-lane D -> B chaining, the same K
+// permutation in every 64-wide input (pack_fragments_depth); fragments in the DF_* order.
+template <int NT, typename Frags>
+__device__ __forceinline__ void mlp_tiles_depth(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
+                                                bool rgb_sigmoid, uint32_t xd, uint32_t xr) {
+  static_assert(NT == 1 || NT == 2, "tiles per pass");
+  constexpr int MT = 4, KS = 2;
+  const float4_t zero = {0.f, 0.f, 0.f, 0.f};
+  float4_t acc[NT][MT];
+  half8_t hb[NT][KS];
+  auto repack = [&]() {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) hb[n][s] = pack_acc(acc[n][2 * s], acc[n][2 * s + 1]);
+  };
+  auto hidden = [&](int base) {  // one 64 -> 64 layer on hb, result back in hb
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n][m] = zero;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const half8_t a = frag(base + KS * m + s);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, hb[n][s], acc[n][m]);
+      }
+    }
+    repack();
+  };
+  // ---- density MLP: 32 -> 64, xd x (64 -> 64), 64 -> 16
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const half8_t a = frag(DF_D0 + m);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, feat[n], zero);
+  }
+  repack();
+  for (uint32_t e = 0; e < xd; ++e) hidden(DF_WW + 8 * (int)e);  // (wave-uniform trip count)
+  float4_t dacc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) dacc[n] = zero;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const half8_t a = frag(DF_D1 + s);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
+  }
+  half8_t rin[NT];
+  uint32_t d01[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    half8_t r;
+    r[0] = (half_t)dacc[n][0];
+    r[1] = (half_t)dacc[n][1];
+    r[2] = (half_t)dacc[n][2];
+    r[3] = (half_t)dacc[n][3];
+    r[4] = dirf[n][0];
+    r[5] = dirf[n][1];
+    r[6] = dirf[n][2];
+    r[7] = dirf[n][3];
+    rin[n] = r;
+    half2_t lo;
+    lo.x = r[0]; lo.y = r[1];
+    d01[n] = h2_bits(lo);
+  }
+  uint32_t dall = d01[0];
+  if constexpr (NT >= 2) dall = __builtin_amdgcn_permlane16_swap(d01[0], d01[1], false, false)[0];
+  out.sigma = (half_t)expf((float)bits_h2(dall).x);
+  // ---- rgb MLP: 32 -> 64, xr x (64 -> 64), 64 -> 16
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const half8_t a = frag(DF_R0 + m);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(a, rin[n], zero);
+  }
+  repack();
+  for (uint32_t e = 0; e < xr; ++e) hidden(DF_WW + 8 * (int)(xd + e));
+#pragma unroll
+  for (int n = 0; n < NT; ++n) dacc[n] = zero;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const half8_t a = frag(DF_R2 + s);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) dacc[n] = mfma16(a, hb[n][s], dacc[n]);
+  }
+  if (rgb_sigmoid) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dacc[n][r] = 1.0f / (1.0f + expf(-dacc[n][r]));
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
     out.rg[n] = pack_h2(dacc[n][0], dacc[n][1]);
     out.bx[n] = pack_h2(dacc[n][2], dacc[n][3]);
   }

@@ -45,13 +45,15 @@ constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // NET_W16 / NET_W32 / NET_W128: the register-resident instance for the other widths of tcnn's FullyFusedMLP (persistent kernel only)
 // NET_WIDE_SH: the wide form for SphericalHarmonics of degree 5..8 (32..64 direction values): the entries beyond the first sixteen
 // are computed once per ray into an LDS row (not per sample in-lane as for Frequency) -- persistent kernel only
-enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6 };
+// NET_DEPTH: 64 neurons with other numbers of hidden layers than base.json's 1 + 2 (mlp_tiles_depth) -- persistent kernel only
+enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6, NET_DEPTH = 7 };
 constexpr int SH_ROW_HALVES = 72;                     // a ray's row: up to 64 direction values + 8 halves of padding (rows 4 banks apart)
 constexpr int LDS_SHROW_BYTES = 64 * SH_ROW_HALVES * 2;  // 9216 per wave
 __host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 16 : (net == NET_W32 ? 32 : (net == NET_W128 ? 128 : 64)); }
 __host__ __device__ constexpr int net_wfrag_bytes(int net) {  // weight fragments a workgroup keeps in LDS
   return (net == NET_WIDE || net == NET_WIDE_SH) ? (N_FRAGS + 4 * (RK_WIDE - 1)) * 1024
-       : net == NET_W16 ? MlpShape<16>::N * 1024 : net == NET_W32 ? MlpShape<32>::N * 1024 : net == NET_W128 ? MlpShape<128>::N * 1024 : N_FRAGS * 1024;
+       : net == NET_W16 ? MlpShape<16>::N * 1024 : net == NET_W32 ? MlpShape<32>::N * 1024 : net == NET_W128 ? MlpShape<128>::N * 1024
+       : net == NET_DEPTH ? DEPTH_FRAGS * 1024 : N_FRAGS * 1024;
 }
 constexpr int LDS_WFRAG_WIDE_BYTES = (N_FRAGS + 4 * (RK_WIDE - 1)) * 64 * 16;  // 28672: + the extra K steps of the first rgb layer
 constexpr int LDS_RAYD_BYTES = 64 * 3 * 4;  // wide instance: 0.5 d + 0.5 of every ray of a wave (fp32)
@@ -103,7 +105,7 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
 // evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
 // SHROWS (NET_WIDE_SH): those entries come from the ray's LDS row instead (rows = the wave's rows, SH_ROW_HALVES apart).
-template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false>
+template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, bool DEPTH = false>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale,
                                                  const half_t* rows = nullptr) {
@@ -169,7 +171,8 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   MlpOut<NT> o;
-  if constexpr (WD == 64) mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
+  if constexpr (DEPTH) mlp_tiles_depth<NT>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, M.depth_xd, M.depth_xr);
+  else if constexpr (WD == 64) mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
   else mlp_tiles<NT, 0, LdsFragsPlain, 1, WD>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
   if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
 #pragma unroll
@@ -254,8 +257,9 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
     constexpr int NTM = WD == 128 ? 1 : NT_MAX;  // 128 neurons: eight accumulator fragments per tile -- one tile per pass
     for (int base = 0; base < S; base += 16 * NTM) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
-      else network_from_lds<NTM, RK, FAST, WD, SHR>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
+      constexpr bool DP = NET == NET_DEPTH;
+      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR, DP>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
+      else network_from_lds<NTM, RK, FAST, WD, SHR, DP>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
     }
   }
 }
@@ -309,7 +313,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
 // copies the instance's weight fragments into LDS (hot: 0 .. N_FRAGS - 1; wide: followed by FRAG_R0X ..)
 template <int NET>
 __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
-  if constexpr (net_width(NET) != 64) {
+  if constexpr (net_width(NET) != 64 || NET == NET_DEPTH) {
     for (int i = threadIdx.x; i < net_wfrag_bytes(NET) / 16; i += blockDim.x) wl[i] = M.wfrag_hot[i];
     return;
   }
@@ -2102,6 +2106,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
     } else if (M.hot_width) {  // 16 / 32 / 128 neurons in the base.json shape: the register-resident instance of that width
       if (M.hot_width == 16) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_GENERIC); }
       else if (M.hot_width == 32) { if (unit) NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_GENERIC); }
+      else if (M.hot_width == 64) { if (unit) NRF_LAUNCH_PERSISTENT(NET_DEPTH, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_DEPTH, MARCH_GENERIC); }
       else { if (unit) NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_GENERIC); }
     } else if (M.generic) {  // (the generic instance has one march form)
       if (waves == 12 && M.gen_weights_lds) NRF_LAUNCH_PERSISTENT_W(NET_GENERIC, MARCH_GENERIC, 12, true);
@@ -2355,7 +2360,7 @@ int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t 
 }
 // ... of the 16-wave workgroup of a width instance (NET_W16 / NET_W32 / NET_W128)
 int render_persistent_lds_width_bytes(int width) {
-  const int net = width == 16 ? NET_W16 : (width == 32 ? NET_W32 : NET_W128);
+  const int net = width == 16 ? NET_W16 : (width == 32 ? NET_W32 : (width == 64 ? NET_DEPTH : NET_W128));
   return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + 16 * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
 }
 int render_persistent_lds_widesh_bytes() {  // the 8-wave workgroup of NET_WIDE_SH without its march tables

@@ -21,6 +21,11 @@ SHAPES = [
     ("SH degree 6 (wide-SH form when persistent)", dict(sh_degree=6)),
     ("SH degree 8 (wide-SH form when persistent)", dict(sh_degree=8)),
     ("SH degree 6, NRF_WIDTH_INSTANCES=0 (generic)", dict(sh_degree=6, _env={"NRF_WIDTH_INSTANCES": "0"})),
+    ("hidden layers 2 + 2 (depth instance when persistent)", dict(density_hidden_layers=2, rgb_hidden_layers=2)),
+    ("hidden layers 1 + 1 (depth instance)", dict(density_hidden_layers=1, rgb_hidden_layers=1)),
+    ("hidden layers 3 + 4 (depth instance)", dict(density_hidden_layers=3, rgb_hidden_layers=4)),
+    ("hidden layers 2 + 2, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=2, rgb_hidden_layers=2, _env={"NRF_WIDTH_INSTANCES": "0"})),
+    ("hidden layers 3 + 4, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=3, rgb_hidden_layers=4, _env={"NRF_WIDTH_INSTANCES": "0"})),
 ]
 for name, kw in SHAPES:
     kw = dict(kw)

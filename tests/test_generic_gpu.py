@@ -379,7 +379,7 @@ def test_wide_and_generic_instances_shard_batch_and_group_like_the_hot_one(ctx, 
     g.close()
 
 
-@pytest.mark.parametrize("shape", ["w16", "w32", "w128", "sh5", "sh6", "sh7", "sh8"])
+@pytest.mark.parametrize("shape", ["w16", "w32", "w128", "sh5", "sh6", "sh7", "sh8", "d2_2", "d1_1", "d3_4", "d1_3", "d2_1"])
 def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shape):
     """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons (T/src/fully_fused_mlp.cu:700-725).  In the base.json shape the
     other three widths have register-resident instances of the persistent kernel too (NET_W16 / NET_W32 / NET_W128: the MFMA
@@ -390,9 +390,14 @@ def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shap
     the wide form with every coefficient of a ray computed once into an LDS row (instance 4)."""
     import os
 
-    kw = dict(n_neurons=int(shape[1:])) if shape[0] == "w" else dict(sh_degree=int(shape[2:]))
+    # "d<a>_<b>": 64 neurons with a / b hidden layers in the density / rgb MLP (base.json: 1 / 2) -- the DEPTH instance
+    # (mlp_tiles_depth: a runtime number of 64 -> 64 layers, the same in-lane chaining), reported as a width instance too
+    if shape[0] == "d":
+        kw = dict(density_hidden_layers=int(shape[1]), rgb_hidden_layers=int(shape[3]))
+    else:
+        kw = dict(n_neurons=int(shape[1:])) if shape[0] == "w" else dict(sh_degree=int(shape[2:]))
     width = shape
-    want_instance = 3 if shape[0] == "w" else 4
+    want_instance = 3 if shape[0] in "wd" else 4
     desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, **kw)
     o = op.Oracle(desc)
     W, H = 120, 88
