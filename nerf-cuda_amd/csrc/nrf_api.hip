@@ -942,7 +942,8 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   if (generic || wide) {
     std::vector<_Float16>& fr = generic ? frags : frags_gen;
     G.F = F; G.interp = d->interpolation; G.n_levels = L; G.feat_raw = feat_raw; G.feat_w = feat_w;
-    G.fast_grid = (!generic_grid && F == 2 && d->interpolation == NRF_INTERP_LINEAR && c->allow_gen_fast_grid) ? 1u : 0u;
+    G.fast_grid = (!generic_grid && F == 2 && (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP) &&
+                   c->allow_gen_fast_grid) ? 1u : 0u;
     G.feat_k = next_multiple(feat_w, 32u); G.width = Wn; G.dir_raw = raw; G.dir_w = dir_w; G.rgb_in = rgb_in;
     G.n_dens = d->density_hidden_layers + 1; G.n_rgb = d->rgb_hidden_layers + 1;
     const uint32_t max_k = G.feat_k > next_multiple(Wn, 32u) ? G.feat_k : next_multiple(Wn, 32u);

@@ -51,7 +51,7 @@ struct GenModel {
   uint32_t n_dens, n_rgb;   // matmuls of the density / rgb MLP (hidden layers + 1)
   uint32_t act_stride; // halves per row of the activation buffers X, Y
   uint32_t dir_stride; // halves per row of the per-pass direction rows
-  uint32_t fast_grid;  // 1: F == 2, Linear interpolation, every level dense / power-of-two hashed / LV_ADD_POW2 -- the feature rows come
+  uint32_t fast_grid;  // 1: F == 2, Linear or Smoothstep interpolation, every level dense / power-of-two hashed / LV_ADD_POW2 -- the feature rows come
                        // from the register-resident instance's level_gather / level_interp (gen_encode_rows)
   uint32_t pad1;
   GenLayer layer[GEN_MAX_LAYERS];  // density layers, then rgb layers
@@ -398,7 +398,16 @@ __device__ __forceinline__ void gen_encode_rows(const DevModel& M, const GenMode
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t lv = (uint32_t)g + 4u * (uint32_t)j;
-        if (lv < G.n_levels) level_gather<0>(M.grid, M.grid_bytes, lvs[lv], p01[n][0], p01[n][1], p01[n][2], v[j], fr[j]);
+        if (lv < G.n_levels) {
+          level_gather<0>(M.grid, M.grid_bytes, lvs[lv], p01[n][0], p01[n][1], p01[n][2], v[j], fr[j]);
+          if (G.interp == NRF_INTERP_SMOOTHSTEP) {  // (wave-uniform) val*val*(3.0f - 2.0f*val) on the fractions, as gen_level does
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const float f = fr[j][d], sq = f * f, b = 2.0f * f;
+              fr[j][d] = sq * (3.0f - b);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -203,7 +203,8 @@ def test_barrier_fast_forward_other_march_instances(sched, kw):
     dict(H=64, n_neurons=32, n_levels=13),                               # fewer levels than 16 (lanes without a fourth level), 32 neurons
     dict(H=64, log2_hashmap_size=12, sh_degree=6, n_levels=5),           # dense levels only + a few hashed ones
     dict(H=32, cascade=2, bound=2.0, activation="Sigmoid"),              # another activation, two cascades
-], ids=["depths", "13levels-32n", "5levels-sh6", "sigmoid-2cascades"])
+    dict(H=64, interpolation="Smoothstep"),                               # Smoothstep: the fractions are transformed, the gathers are the same
+], ids=["depths", "13levels-32n", "5levels-sh6", "sigmoid-2cascades", "smoothstep"])
 def test_generic_instance_fast_grid_equals_literal_grid(sched, kw):
     """gen_encode_rows takes the register-resident instance's gathers (level_gather / level_interp) when the grid is of its
     kind (F = 2, Linear, dense / power-of-two levels); NRF_GEN_FAST_GRID=0 keeps gen_level's literal arithmetic.  Same
