@@ -11,12 +11,13 @@ for p in (ROOT / "nerf-cuda_amd", ROOT / "tests"):
 import models, nerfhip as nh, synthetic as syn
 
 W, H = 1920, 1080
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # views per call
 desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
-cam = np.ascontiguousarray(np.stack([syn.default_camera(W, H)]), np.float32)
-ctx = nh.NerfHip(0); ctx.load_model(desc); ctx.set_resolution(W, H)
+cam = np.ascontiguousarray(np.stack([syn.default_camera(W, H)] * V), np.float32)
+ctx = nh.NerfHip(0); ctx.load_model(desc); ctx.set_resolution(W, H); ctx.set_max_views(V)
 tot_w = tot_d = 0.0
 for az in range(0, 360, 45):
-    pose = np.ascontiguousarray(syn.orbit_pose(float(az), 30.0), np.float32).reshape(1, 16)
+    pose = np.ascontiguousarray(np.stack([syn.orbit_pose(float(az + 45 * v), 30.0) for v in range(V)]), np.float32).reshape(V, 16)
     wall, dev = [], []
     for i in range(17):
         t0 = time.perf_counter()
@@ -25,4 +26,4 @@ for az in range(0, 360, 45):
         dev.append(f.render_ms)
     w, d = float(np.median(wall[2:])), float(np.median(dev[2:]))
     tot_w += w; tot_d += d
-print(f"render_frame to host bytes: {tot_w / 8:.4f} ms per call, device {tot_d / 8:.4f}, host tail {(tot_w - tot_d) / 8:.4f}")
+print(f"{V} view(s) per call to host bytes: {tot_w / 8:.4f} ms per call, device {tot_d / 8:.4f}, host tail {(tot_w - tot_d) / 8:.4f}")
