@@ -1190,7 +1190,7 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
   P.skip_outside = skip_outside;
   c->call_index = (c->call_index + 1) % CALL_RING;
   char* counters = call_slot(c, c->call_index);
-  unsigned* plan = c->plan_max_pos > 0 ? (unsigned*)((char*)c->d_plan + (size_t)c->call_index * PLAN_BYTES) : nullptr;
+  unsigned* plan = (c->plan_max_pos > 0 && prog == nullptr) ? (unsigned*)((char*)c->d_plan + (size_t)c->call_index * PLAN_BYTES) : nullptr;
   HIP_TRY(hipEventRecord(c->ev0, st));  // (render_ms covers the clearing of the call's counters and the planning of its queues)
   // views per launch: NRF_MAX_VIEWS, fewer when the frames are so large that the persistent kernel's 24-bit queue positions
   // (strip rows of all views x strips per row) would not hold the launch (8K frames: 64 views)
@@ -1481,8 +1481,11 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
     // its rows within the last tenth of the render -- nothing to copy meanwhile, and copies that are already queued behind the
     // render's event start sooner than ones the waiting thread issues when it sees the flags (one 1080p view: 1.09 against
     // 1.14 ms per call; three views and more, which are not planned: 2.54 against 2.98 the other way round)
+    // ... and two views gain next to nothing from the plan on the device (1.64 against 1.67 ms) while it costs their host end
+    // the progressive copies (2.00 against 1.82 ms per call): only a frame rendered alone is planned here, every larger call
+    // keeps the queue order of its views and copies them as they complete (render_views_impl: no plan with progress reporting)
     const long strips = (long)n_views * tiles_y * ((c->W + 31) / 32);
-    if (c->plan_max_pos > 0 && strips <= (long)c->plan_max_pos) h.progressive = false;
+    if (n_views == 1 && c->plan_max_pos > 0 && strips <= (long)c->plan_max_pos) h.progressive = false;
   }
   const size_t depth_off = h.views * px * 3;  // depth planes follow the rgb planes of ALL views the slot holds
   h.rows.assign((size_t)2 * n_views, 0);
