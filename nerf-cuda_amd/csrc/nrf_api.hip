@@ -296,6 +296,7 @@ struct nrf_context {
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
   int march_budget = 256;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
+  int sample_cap = 2;      // per-round sample queue of a ray by its transmittance (FrameParams::sample_cap); NRF_SAMPLE_CAP=0 / 1: A/B runs
   bool rendered = false;
   hipStream_t last_stream = nullptr;
 };
@@ -400,6 +401,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.density_scale = c->opt.density_scale;
   P.max_steps = c->opt.max_steps;
   P.march_budget = c->march_budget;
+  P.sample_cap = c->sample_cap;
   P.centre_out = c->centre_out ? 1 : 0;
   P.out_mode = c->bound_rgbd8 ? OUT_RGBD8 : (c->bound_rgb8 ? OUT_U8 : OUT_F32);
   P.skip_outside = 0;
@@ -743,6 +745,7 @@ int nrf_create(int device, nrf_context** out) {
     const int b = std::atoi(e);
     if (b >= 1 && b <= 4096) c->march_budget = b;
   }
+  if (const char* e = std::getenv("NRF_SAMPLE_CAP")) c->sample_cap = std::atoi(e);
   if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_GEN_WLDS")) c->allow_gen_wlds = std::atoi(e) != 0;
@@ -1072,6 +1075,12 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     c->grid_missing = true;
   }
   c->model_loaded = true;
+  // the code objects of the render kernel's families are loaded here, not by the first frame (once per process and device)
+  static bool preloaded[64] = {false};
+  if (c->device >= 0 && c->device < 64 && !preloaded[c->device]) {
+    preload_kernels(true);
+    preloaded[c->device] = true;
+  }
   return NRF_OK;
 }
 
@@ -1445,7 +1454,9 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
   h.pending = false;
   const size_t px = (size_t)c->W * c->H;
   const int tiles_y = (c->H + 7) / 8;
-  if (h.px != px || h.views < (size_t)n_views) {
+  // keyed on the frame's GEOMETRY, not its pixel count: 1920x1080 -> 1080x1920 keeps W * H but changes the row bookkeeping
+  // (row_lo / row_hi / bg describe byte ranges of the old width) and the number of strip rows (d_done / h_flags entries)
+  if (h.px != px || h.W != c->W || h.H != c->H || h.views < (size_t)n_views) {
     HIP_TRY(hipDeviceSynchronize());
     for (void* q : {h.d_buf, (void*)h.d_done}) if (q) (void)hipFree(q);
     for (void* q : {(void*)h.h_buf, (void*)h.h_flags}) if (q) (void)hipHostFree(q);

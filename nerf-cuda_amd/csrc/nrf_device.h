@@ -208,6 +208,10 @@ struct FrameParams {
                     // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   int march_ff;     // 1 = a ray steps straight to its last barrier plane ahead of t_skip (fast_forward_to_barrier); 0 = every
                     // trip of that stretch is simulated (A/B runs and the equality tests: NRF_MARCH_FF=0)
+  int sample_cap;   // the samples a ray may queue per round shrink with its transmittance T: fewer samples evaluated behind a ray's
+                    // terminating one, frames unchanged (per-ray semantics).  2 (default) = what the ray still needs to reach
+                    // T < 1e-4 if every sample halves T (clamp(exponent(T) + 13, 1, 8): never short of the need unless alpha > 0.5);
+                    // 1 = 8 / 4 / 2 / 1 for T >= 0.4 / 0.1 / 0.02 / below; 0 = always up to 8 (A/B runs: NRF_SAMPLE_CAP)
   unsigned* prog_done;
   unsigned* prog_flags;
   // persistent kernel: the launch's queue order (plan_sort_kernel): entry [class offset + i] = the queue position the i-th pull of

@@ -293,20 +293,18 @@ int nrf_group_read_view_u8(nrf_group* g, int view, uint8_t* rgb, uint8_t* depth)
 }
 
 // ---- host frames (nerfhip.h "host frames")
-int nrf_group_submit_host_u8(nrf_group* g, int n_views, const float* cams, const float* poses, int flags, int* ticket) {
-  if (!g || !cams || !poses || !ticket || n_views < 1) return gfail(NRF_E_INVALID, "bad argument");
-  if (g->W <= 0) return gfail(NRF_E_STATE, "nrf_group_set_resolution has not been called");
+}  // extern "C"
+namespace {
+// issues every launch and copy of a group submit into slot h; the caller commits the slot (ticket, n_views, hs_next) only
+// when this has returned NRF_OK
+int group_submit_impl(nrf_group* g, nrf_group::HostSlot& h, int n_views, const float* cams, const float* poses, int flags) {
   const size_t n = g->ctx.size();
-  const int si = g->hs_next;
-  nrf_group::HostSlot& h = g->hs[si];
-  g->hs_next = (si + 1) % 2;
-  h.n_views = n_views;
   h.with_depth = !(flags & NRF_HOST_RGB_ONLY);
-  *ticket = si;
   if (n == 1) {  // one member: its own host-frame path (region-of-interest rows only, no untile)
     h.single = true;
-    h.pending = true;
-    return nrf_submit_host_u8(g->ctx[0], n_views, cams, poses, flags, &h.member_ticket);
+    const int rc = nrf_submit_host_u8(g->ctx[0], n_views, cams, poses, flags, &h.member_ticket);
+    h.pending = rc == NRF_OK;
+    return rc;
   }
   h.single = false;
   GHIP(hipSetDevice(g->devices[0]));
@@ -365,6 +363,32 @@ int nrf_group_submit_host_u8(nrf_group* g, int n_views, const float* cams, const
   GHIP(hipEventRecord(h.done, g->copy_stream));
   h.pending = true;
   g->last_views = 0;  // (the float frames of nrf_group_render_views are not what was rendered last)
+  return NRF_OK;
+}
+}  // namespace
+extern "C" {
+
+int nrf_group_submit_host_u8(nrf_group* g, int n_views, const float* cams, const float* poses, int flags, int* ticket) {
+  if (!g || !cams || !poses || !ticket || n_views < 1) return gfail(NRF_E_INVALID, "bad argument");
+  if (g->W <= 0) return gfail(NRF_E_STATE, "nrf_group_set_resolution has not been called");
+  const int si = g->hs_next;
+  nrf_group::HostSlot& h = g->hs[si];
+  const int rc = group_submit_impl(g, h, n_views, cams, poses, flags);
+  if (rc != NRF_OK) {
+    // nothing is committed: the slot holds no frames (a wait on it reports NRF_E_STATE instead of stale bytes), the next
+    // submit takes the same slot again, and whatever a member has already been handed (a render, half of the peer copies)
+    // is drained so that no copy is left in flight into buffers the next submit may reallocate
+    h.n_views = 0;
+    h.pending = false;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+      if (hipSetDevice(g->devices[i]) == hipSuccess && i < g->stream.size() && g->stream[i]) (void)hipStreamSynchronize(g->stream[i]);
+    }
+    if (g->ctx.size() > 1 && hipSetDevice(g->devices[0]) == hipSuccess && g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    return rc;
+  }
+  h.n_views = n_views;
+  g->hs_next = (si + 1) % 2;
+  *ticket = si;
   return NRF_OK;
 }
 

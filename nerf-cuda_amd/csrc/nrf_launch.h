@@ -36,6 +36,8 @@ hipError_t launch_untile_rgbd8_u8(const void* gathered, int shard_count, int til
                                   void* depth8, hipStream_t st);
 hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n, void* out, hipStream_t st);
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
+// loads the code objects of the render kernel's instance families now instead of at their first launch
+void preload_kernels(bool all);
 int render_lds_bytes();
 int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t gen_wave_bytes, int waves);
 int render_persistent_waves(uint32_t generic, uint32_t wide);

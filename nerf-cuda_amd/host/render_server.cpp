@@ -15,8 +15,11 @@
 // so batch k + 1 renders while batch k is copied, handed over and sent: the GPU is never idle while a
 // reply is in flight.  Requests that arrive while a batch renders form the next batch, so batching needs no
 // timer and a lone client sees no added latency.  A reply is sent straight from the pinned slot (no
-// per-request copy); a client that cannot take its image at once gets the remainder copied out, so that a
-// slow consumer never holds a slot (and with it the GPU) for longer than a memcpy.
+// per-request copy).  A slow consumer never holds a slot (and with it the GPU): the image being sent has its remainder
+// copied out as soon as the socket stops taking bytes, and the images of the same connection that wait behind it are
+// copied out the moment the worker wants their slot back (`SlotUse::wanted`, looked at every 2 ms by every connection
+// thread that waits for a socket or for a render) -- within a global budget of spilled bytes (NRF_SERVER_SPILL_MB, default
+// 1024); a connection that would exceed it, or that takes no byte for NRF_SERVER_SEND_TIMEOUT_S (default 30), is dropped.
 // NERF_SERVER_MODE=tile keeps the reference's own multi-GPU form instead: one NerfRender over all devices,
 // every frame tile-sharded over them (NGPU of common.h:91).
 // Devices: NERF_DEVICES="0,1,..." (repeats allowed: "0,0" rehearses two workers on one GPU), else
@@ -40,6 +43,7 @@
 #include <csignal>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -93,6 +97,7 @@ struct SlotUse {
   std::mutex m;
   std::condition_variable cv;
   int readers = 0;
+  std::atomic<bool> wanted{false};  // the worker waits for this slot: connection threads copy their pending images out of it
 };
 
 struct Request {
@@ -126,6 +131,11 @@ struct Server {
   int max_clients = 256;
   bool test_hooks = false;  // NRF_SERVER_TEST_HOOKS=1
   size_t frame_bytes = 0;
+  // images copied out of a slot on behalf of slow consumers: bounded, a connection that would exceed the budget is dropped
+  std::atomic<long long> spill_bytes{0};
+  long long spill_budget = 1024ll << 20;  // NRF_SERVER_SPILL_MB
+  int send_timeout_ms = 30000;            // NRF_SERVER_SEND_TIMEOUT_S: a client that takes no byte for this long is dropped
+  std::atomic<unsigned long> evictions{0}, dropped_slow{0};
   int listen_fd = -1;
   std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
 
@@ -139,8 +149,8 @@ struct Server {
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     char buf[256];
-    std::snprintf(buf, sizeof(buf), "batches %lu frames %lu workers %zu gpu_ms %.3f wall_ms %.3f", b, f, workers.size(), (double)us * 1e-3,
-                  wall_ms);
+    std::snprintf(buf, sizeof(buf), "batches %lu frames %lu workers %zu gpu_ms %.3f wall_ms %.3f evictions %lu dropped_slow %lu", b, f,
+                  workers.size(), (double)us * 1e-3, wall_ms, evictions.load(), dropped_slow.load());
     return buf;
   }
 };
@@ -204,7 +214,11 @@ void worker_loop(Server& s, Worker& w) {
         if (next_slot >= 0 && si != next_slot) continue;
         SlotUse& su = w.slot[si];
         std::unique_lock<std::mutex> lk(su.m);
-        su.cv.wait(lk, [&] { return su.readers == 0; });
+        if (su.readers != 0) {
+          su.wanted = true;  // connection threads holding images of this slot copy them out (<= 2 ms + a memcpy)
+          su.cv.wait(lk, [&] { return su.readers == 0; });
+          su.wanted = false;
+        }
       }
       try {
         std::vector<Camera> cams;
@@ -234,6 +248,15 @@ void worker_loop(Server& s, Worker& w) {
   }
 }
 
+// stop + wake-up under each worker's mutex: a worker that has just found its predicate false cannot miss the notification
+void stop_workers(Server& s) {
+  for (const auto& w : s.workers) {
+    std::lock_guard<std::mutex> lk(w->m);
+    s.stop = true;
+    w->cv.notify_all();
+  }
+}
+
 // the dispatcher: a whole request goes to the GPU with the fewest views waiting or rendering
 std::shared_ptr<Request> submit(Server& s, const Camera& cam, const float pose[16]) {
   auto req = std::make_shared<Request>();
@@ -242,58 +265,153 @@ std::shared_ptr<Request> submit(Server& s, const Camera& cam, const float pose[1
   Worker* best = s.workers[0].get();
   for (const auto& w : s.workers)
     if (w->load.load() < best->load.load()) best = w.get();
-  best->load++;
   {
     std::lock_guard<std::mutex> lk(best->m);
+    if (s.stop.load()) {  // the workers are leaving (or gone): nobody would ever complete this request
+      req->done = req->failed = true;
+      return req;
+    }
+    best->load++;
     best->queue.push_back(req);
   }
   best->cv.notify_one();
   return req;
 }
 
-// Sends a finished image straight from its pinned slot.  What the socket does not take at once is copied out first, so
-// the slot is released after at most one memcpy.
-bool wait_and_send(int sock, const std::shared_ptr<Request>& req, size_t frame_bytes) {
-  {
-    std::unique_lock<std::mutex> lk(req->m);
-    req->cv.wait(lk, [&] { return req->done; });
+// The replies of one connection, in request order, each sent straight from its pinned slot.  See the file header for what
+// happens to a consumer that does not keep up.  Returns false when the connection is lost (or dropped); every slot
+// reference of `reqs` has been given back when it returns, whatever happened.
+class ReplySender {
+ public:
+  ReplySender(Server& s, int sock, std::vector<std::shared_ptr<Request>>& reqs) : s_(s), sock_(sock) {
+    for (auto& r : reqs) items_.push_back(Item{r, {}, false, false});
   }
-  if (req->failed) return false;
-  const unsigned char* p = req->rgb;
-  size_t left = frame_bytes;
-  bool ok = true;
-  while (left) {
-    const ssize_t r = ::send(sock, p, left, MSG_NOSIGNAL | MSG_DONTWAIT);
-    if (r > 0) {
-      p += r;
-      left -= (size_t)r;
-      continue;
+  ~ReplySender() {
+    for (size_t j = 0; j < items_.size(); ++j) {  // a lost connection: still wait for every image and give its slot back
+      wait_done(j, /*service=*/false);
+      release(j);
+      drop_copy(j);
     }
-    if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) break;  // socket buffer full: finish from a copy
-    ok = false;
-    break;
   }
-  std::vector<unsigned char> rest;
-  if (ok && left) rest.assign(p, p + left);
-  {
-    std::lock_guard<std::mutex> lk(req->slot->m);
-    if (--req->slot->readers == 0) req->slot->cv.notify_all();
+  bool run() {
+    bool ok = true;
+    for (cur_ = 0; ok && cur_ < items_.size(); ++cur_) {
+      off_ = 0;
+      if (!wait_done(cur_, /*service=*/true) || items_[cur_].req->failed) return false;
+      ok = send_current();
+      release(cur_);
+      drop_copy(cur_);
+    }
+    return ok;
   }
-  if (ok && left) ok = write_n(sock, rest.data(), rest.size());
-  return ok;
-}
+
+ private:
+  struct Item {
+    std::shared_ptr<Request> req;
+    std::vector<unsigned char> copy;  // the image (the current one: its unsent remainder) once it has left the slot
+    bool released, spilled;
+  };
+  Server& s_;
+  int sock_;
+  std::vector<Item> items_;
+  size_t cur_ = 0, off_ = 0;  // the image being sent and how much of it has gone
+
+  bool is_done(size_t j) {
+    std::lock_guard<std::mutex> lk(items_[j].req->m);
+    return items_[j].req->done;
+  }
+  // waits for image j; meanwhile (service) the later images of this connection leave a slot its worker wants back
+  bool wait_done(size_t j, bool service) {
+    Request& r = *items_[j].req;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lk(r.m);
+        if (r.cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return r.done; })) return true;
+      }
+      if (service && !service_evictions()) return false;
+    }
+  }
+  void release(size_t j) {
+    Item& it = items_[j];
+    if (it.released || !it.req->slot) return;
+    it.released = true;
+    std::lock_guard<std::mutex> lk(it.req->slot->m);
+    if (--it.req->slot->readers == 0) it.req->slot->cv.notify_all();
+  }
+  void drop_copy(size_t j) {
+    Item& it = items_[j];
+    if (it.spilled) s_.spill_bytes -= (long long)it.copy.size();
+    it.spilled = false;
+    std::vector<unsigned char>().swap(it.copy);
+  }
+  // copies what is left of image j out of its slot and gives the slot back; false: over the budget -> drop the connection
+  bool spill(size_t j) {
+    Item& it = items_[j];
+    if (it.released || it.req->failed || !it.req->rgb) return true;
+    const size_t from = j == cur_ ? off_ : 0, n = s_.frame_bytes - from;
+    if (s_.spill_bytes.fetch_add((long long)n) + (long long)n > s_.spill_budget) {
+      s_.spill_bytes -= (long long)n;
+      s_.dropped_slow++;
+      std::fprintf(stderr, "slow consumer dropped: the budget of spilled reply bytes (NRF_SERVER_SPILL_MB) is used up\n");
+      return false;
+    }
+    it.copy.assign(it.req->rgb + from, it.req->rgb + s_.frame_bytes);
+    it.spilled = true;
+    release(j);
+    return true;
+  }
+  // the finished images of this connection that sit in a slot its worker waits for leave it now
+  bool service_evictions() {
+    for (size_t j = cur_; j < items_.size(); ++j) {
+      Item& it = items_[j];
+      if (it.released || !is_done(j) || it.req->failed || !it.req->slot) continue;
+      if (!it.req->slot->wanted.load()) continue;
+      if (!spill(j)) return false;
+      s_.evictions++;
+    }
+    return true;
+  }
+  bool send_current() {
+    Item& it = items_[cur_];
+    auto last_progress = std::chrono::steady_clock::now();
+    while (off_ < s_.frame_bytes) {
+      // (an image that was evicted while it waited its turn is sent from its copy: the whole image, offset 0)
+      const unsigned char* src = it.spilled ? it.copy.data() + (off_ - (s_.frame_bytes - it.copy.size())) : it.req->rgb + off_;
+      const ssize_t r = ::send(sock_, src, s_.frame_bytes - off_, MSG_NOSIGNAL | MSG_DONTWAIT);
+      if (r > 0) {
+        off_ += (size_t)r;
+        last_progress = std::chrono::steady_clock::now();
+        continue;
+      }
+      if (!(r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR))) return false;
+      // the socket takes no more for now: what is left of this image leaves the slot (one memcpy), the images behind it when
+      // their worker asks; then wait for the socket in 2 ms steps
+      if (!it.released && !spill(cur_)) return false;
+      if (!service_evictions()) return false;
+      pollfd pf{sock_, POLLOUT, 0};
+      (void)::poll(&pf, 1, 2);
+      if (pf.revents & (POLLERR | POLLHUP | POLLNVAL)) return false;
+      if (std::chrono::steady_clock::now() - last_progress > std::chrono::milliseconds(s_.send_timeout_ms)) {
+        s_.dropped_slow++;
+        std::fprintf(stderr, "slow consumer dropped: no byte taken for %d ms (NRF_SERVER_SEND_TIMEOUT_S)\n", s_.send_timeout_ms);
+        return false;
+      }
+    }
+    return true;
+  }
+};
+
+bool send_replies(Server& s, int sock, std::vector<std::shared_ptr<Request>>& reqs) { return ReplySender(s, sock, reqs).run(); }
 
 void serve_client(int sock, const std::string peer, const Camera default_cam, std::shared_ptr<Server> sp) {
   Server& s = *sp;
-  const size_t frame_bytes = s.frame_bytes;
   std::cout << "Received a connection request from " << peer << std::endl;
   float nerf_pos[16] = {0};
   while (read_n(sock, nerf_pos, sizeof(nerf_pos))) {
     if (s.test_hooks && std::memcmp(nerf_pos, "QUIT", 4) == 0 && nerf_pos[1] == 0.0f && nerf_pos[15] == 0.0f) {
       std::printf("\n%s\n", s.stat_line().c_str());  // one write: other threads print too
       std::fflush(stdout);
-      s.stop = true;
-      for (const auto& w : s.workers) w->cv.notify_all();
+      stop_workers(s);
       ::shutdown(s.listen_fd, SHUT_RDWR);  // wakes the acceptor
       break;
     }
@@ -320,22 +438,13 @@ void serve_client(int sock, const std::string peer, const Camera default_cam, st
           const float* r = body.data() + (size_t)v * 20;
           reqs.push_back(submit(s, Camera{r[0], r[1], r[2], r[3]}, r + 4));
         }
-        for (const auto& r : reqs) {
-          if (ok) ok = wait_and_send(sock, r, frame_bytes);
-          else {  // the connection is lost: still wait for the image and give its slot back
-            std::unique_lock<std::mutex> lk(r->m);
-            r->cv.wait(lk, [&] { return r->done; });
-            if (r->slot) {
-              std::lock_guard<std::mutex> lk2(r->slot->m);
-              if (--r->slot->readers == 0) r->slot->cv.notify_all();
-            }
-          }
-        }
+        ok = send_replies(s, sock, reqs);
       }
       if (!ok) break;
       continue;
     }
-    if (!wait_and_send(sock, submit(s, default_cam, nerf_pos), frame_bytes)) break;
+    std::vector<std::shared_ptr<Request>> one{submit(s, default_cam, nerf_pos)};
+    if (!send_replies(s, sock, one)) break;
   }
   std::cout << "Connection closed" << std::endl;
   ::close(sock);
@@ -412,6 +521,8 @@ int main(int argc, char** argv) {
       const char* hooks = std::getenv("NRF_SERVER_TEST_HOOKS");
       s.test_hooks = hooks && std::strcmp(hooks, "1") == 0;
       if (const char* mc = std::getenv("NRF_SERVER_MAX_CLIENTS")) s.max_clients = std::max(1, std::atoi(mc));
+      if (const char* v = std::getenv("NRF_SERVER_SPILL_MB")) s.spill_budget = (long long)std::max(0, std::atoi(v)) << 20;
+      if (const char* v = std::getenv("NRF_SERVER_SEND_TIMEOUT_S")) s.send_timeout_ms = std::max(1, std::atoi(v)) * 1000;
     }
     for (auto& w : s.workers) w->thread = std::thread(worker_loop, std::ref(s), std::ref(*w));
     s.t_start = std::chrono::steady_clock::now();
@@ -436,11 +547,9 @@ int main(int argc, char** argv) {
       s.live_clients++;
       std::thread(serve_client, sock, std::string(inet_ntoa(peer.sin_addr)), cam, server).detach();
     }
-    s.stop = true;
-    for (auto& w : s.workers) {
-      w->cv.notify_all();
+    stop_workers(s);
+    for (auto& w : s.workers)
       if (w->thread.joinable()) w->thread.join();
-    }
     ::close(srv);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

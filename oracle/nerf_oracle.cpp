@@ -125,6 +125,7 @@ struct nrfo_model {
   std::vector<uint32_t> dens_dims, rgb_dims;  // layer widths: in, W, ..., 16
   std::vector<uint16_t> grid;                 // fp16 table
   std::vector<float> density_grid;
+  uint32_t mlp_acc_block = 0;  // nrfo_set_mlp_accumulate: 0 = fp32 sums; n = fp16 accumulator updated every n products
 };
 
 extern "C" {
@@ -324,6 +325,16 @@ void nrfo_widths(const nrfo_model* m, uint32_t* feat_width, uint32_t* dir_width)
   if (dir_width) *dir_width = m->dir_width;
 }
 
+// the accumulator arithmetic of the two MLPs (see mlp_one); the default is NRFO_ACC_FP32
+int nrfo_set_mlp_accumulate(nrfo_model* m, int mode) {
+  if (!m) return fail(NRF_E_INVALID, "null model");
+  if (mode != NRFO_ACC_FP32 && mode != NRFO_ACC_FP16_STEP && mode != NRFO_ACC_FP16_K4 && mode != NRFO_ACC_FP16_K8 &&
+      mode != NRFO_ACC_FP16_K16)
+    return fail(NRF_E_INVALID, "mlp accumulate mode must be 0 (fp32), 1, 4, 8 or 16 (fp16 accumulator per K block)");
+  m->mlp_acc_block = (uint32_t)mode;
+  return NRF_OK;
+}
+
 // T/include/tiny-cuda-nn/encodings/grid.h:100-117
 uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32_t y, uint32_t z) {
   const uint32_t hashmap_size = m->lv.offset[level + 1] - m->lv.offset[level];
@@ -501,10 +512,18 @@ void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
   }
 }
 
-// y = act(W x) chains, T/src/fully_fused_mlp.cu:500-558.  fp16 in, fp32
-// accumulate in ascending k, activation on the fp32 sum, fp16 store per layer.
+// y = act(W x) chains, T/src/fully_fused_mlp.cu:500-558.  fp16 in; acc_block == 0 (the arithmetic contract shared with
+// the HIP path): fp32 accumulate in ascending k, activation on the fp32 sum, fp16 store per layer.
+// acc_block == n > 0 (nrfo_set_mlp_accumulate): the reference's own accumulator type.  Its result fragments are
+// `wmma::fragment<accumulator, 16, 16, 16, __half>` in every layer (fully_fused_mlp.cu:69 hidden, :334 input, :437 last;
+// OUT_T = __half, :573-634) and one `mma_sync` per 16-wide K block adds 16 exact fp16 x fp16 products to it
+// (:100-104, :373-376, :461-465): the running sum is an fp16 value after every block of n = 16 products.  How the tensor
+// core sums INSIDE a block is not specified; here the block's products are summed in fp32 (ascending k, each product
+// exact in fp32) together with the accumulator and rounded to fp16 once (RNE).  n = 1 rounds after every product (the
+// pessimistic bound), n = 4 / 8 are the K granularities of older HMMA forms.  The activation then works on the fp16
+// accumulator value (`warp_activation<__half>`, common_device.h:68-114: float math on the fp16 value, fp16 result).
 void mlp_one(const std::vector<std::vector<float>>& w, const std::vector<uint32_t>& dims,
-             uint32_t act, uint32_t out_act, const float* in, float* out /*16, fp16-rounded*/) {
+             uint32_t act, uint32_t out_act, uint32_t acc_block, const float* in, float* out /*16, fp16-rounded*/) {
   float buf0[128], buf1[128];
   const float* cur = in;
   float* nxt = buf0;
@@ -517,7 +536,16 @@ void mlp_one(const std::vector<std::vector<float>>& w, const std::vector<uint32_
     for (uint32_t o = 0; o < N; ++o) {
       float acc = 0.0f;
       const float* row = W + (size_t)o * K;
-      for (uint32_t k = 0; k < K; ++k) acc += row[k] * cur[k];
+      if (acc_block == 0) {
+        for (uint32_t k = 0; k < K; ++k) acc += row[k] * cur[k];
+      } else {
+        for (uint32_t kb = 0; kb < K; kb += acc_block) {
+          float part = acc;  // the fp16 accumulator enters the block's sum
+          const uint32_t ke = kb + acc_block < K ? kb + acc_block : K;
+          for (uint32_t k = kb; k < ke; ++k) part += row[k] * cur[k];
+          acc = h2f(f2h(part));
+        }
+      }
       dst[o] = h2f(f2h(activate(last ? out_act : act, acc)));
     }
     cur = dst;
@@ -531,10 +559,10 @@ void network_encoded_one(const nrfo_model* m, const uint16_t* feat, const uint16
                          uint16_t* out4) {
   float in[128], dens[16], rgbin[128], rgb[16];
   for (uint32_t j = 0; j < m->feat_width; ++j) in[j] = h2f(feat[j]);
-  mlp_one(m->dens_w, m->dens_dims, m->d.density_activation, m->d.density_output_activation, in, dens);
+  mlp_one(m->dens_w, m->dens_dims, m->d.density_activation, m->d.density_output_activation, m->mlp_acc_block, in, dens);
   for (uint32_t j = 0; j < 16; ++j) rgbin[j] = dens[j];  // rows 0..15 (nerf_network.h:162-164)
   for (uint32_t j = 0; j < m->dir_width; ++j) rgbin[16 + j] = h2f(dirfeat[j]);  // rows 16.. (:177-182)
-  mlp_one(m->rgb_w, m->rgb_dims, m->d.rgb_activation, m->d.rgb_output_activation, rgbin, rgb);
+  mlp_one(m->rgb_w, m->rgb_dims, m->d.rgb_activation, m->d.rgb_output_activation, m->mlp_acc_block, rgbin, rgb);
   out4[0] = f2h(rgb[0]);
   out4[1] = f2h(rgb[1]);
   out4[2] = f2h(rgb[2]);

@@ -49,6 +49,15 @@ void nrfo_destroy(nrfo_model* m);
 /* padded widths of the position / direction encodings (fp16 values per sample) */
 void nrfo_widths(const nrfo_model* m, uint32_t* feat_width, uint32_t* dir_width);
 
+/* Accumulator arithmetic of the two MLPs.  NRFO_ACC_FP32 (default) is the contract shared with the HIP path.  The
+ * FP16 modes emulate the reference's own accumulators -- `wmma::fragment<accumulator,16,16,16,__half>` in every layer,
+ * T/src/fully_fused_mlp.cu:69,334,437 -- to MEASURE how far the fp32-accumulate neighbour is from it: the running sum is
+ * rounded to fp16 (RNE) after every block of n products (n = 16: one mma_sync per K block, the reference's granularity;
+ * n = 1: after every product, the pessimistic bound; 4 / 8: older HMMA K granularities), and the activation is applied
+ * to that fp16 value (warp_activation<__half>).  Tensor-core rounding inside a block is unspecified: summed in fp32. */
+enum { NRFO_ACC_FP32 = 0, NRFO_ACC_FP16_STEP = 1, NRFO_ACC_FP16_K4 = 4, NRFO_ACC_FP16_K8 = 8, NRFO_ACC_FP16_K16 = 16 };
+int nrfo_set_mlp_accumulate(nrfo_model* m, int mode);
+
 /* fp16 helpers (round-to-nearest-even, IEEE binary16) */
 uint16_t nrfo_f32_to_f16(float f);
 float nrfo_f16_to_f32(uint16_t h);

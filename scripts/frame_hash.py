@@ -28,7 +28,7 @@ for (W, H) in ((1920, 1080), (800, 800), (333, 211)):
     for az, el in ((0, 30), (45, 30), (90, 30), (135, -20), (200, 60), (290, 5)):
         rgba, depth = render(cam, syn.orbit_pose(az, el), W, H)
         print(W, H, az, el, hashlib.sha1(rgba.tobytes()).hexdigest()[:16], hashlib.sha1(depth.tobytes()).hexdigest()[:16],
-              c.stats().n_samples)
+              c.stats().n_samples, c.stats().n_composited)
 
 # BASELINE config 4 shape: bound 16, 5 cascades (generic march instance, per-cascade visibility walk)
 desc4, keep4, _ = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)
@@ -41,4 +41,4 @@ for (W, H) in ((640, 360), (201, 133)):
     for az, el, radius in ((0, 30, 4.0311), (120, -15, 1.5 / 0.33), (250, 70, 9.0 / 0.33), (33, 5, 0.4 / 0.33)):
         rgba, depth = render(cam, syn.orbit_pose(az, el, radius=radius), W, H)
         print("c4", W, H, az, el, radius, hashlib.sha1(rgba.tobytes()).hexdigest()[:16], hashlib.sha1(depth.tobytes()).hexdigest()[:16],
-              c.stats().n_samples)
+              c.stats().n_samples, c.stats().n_composited)

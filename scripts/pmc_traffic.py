@@ -16,12 +16,15 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 root, out = sys.argv[1], sys.argv[2]
 views = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-rows = []
+rows, mlp_rows = [], []
 for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
+        rec = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
+               (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
         if "render_kernel" in r["Kernel_Name"] or "render_persistent_kernel" in r["Kernel_Name"]:
-            rows.append((r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
-                         (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6))
+            rows.append(rec)
+        elif "mlp_forward_kernel<false>" in r["Kernel_Name"] or "mlp_forward_kernel<0>" in r["Kernel_Name"]:
+            mlp_rows.append(rec)  # the fused-MLP stage kernel, HBM-fed (scripts/mlp_steady.py under --pmc: profile_gpu.sh `mlp_*` passes)
 # the batched launches of the timed region: the persistent kernel's grid is the same for every launch (one workgroup per
 # CU), so the single-view replays are told apart by their duration
 longest = max(r[4] for r in rows)
@@ -62,6 +65,44 @@ other = max(valu - f32 - f16 - trans - cvt - int32 - mfma, 0.0)
 mix = min(2 * g("SQ_INSTS_VALU_ADD_F16"), g("SQ_INSTS_VALU_FMA_F32"))
 cycles = 2.25 * (f32 - mix) + 4.1 * mix + 3.0 * int32 + 4.1 * cvt + 4.1 * f16 + 8 * trans + 3.2 * other + 8 * mfma
 simd_cycles = g("GRBM_GUI_ACTIVE") / 8 * 1024  # per-XCD active cycles x 1024 SIMDs
+
+
+def mfma_block(cc, ms, flop_per_sample=None, samples=None):
+    """Counter-side MFMA utilisation (north_star: "rocprof showing achieved MFMA utilisation").  SQ_VALU_MFMA_BUSY_CYCLES counts
+    SIMD cycles in which the matrix pipe is busy (16 per v_mfma_f32_16x16x32_f16: MI355X_MICROARCH.md); a SIMD that issued an
+    MFMA every 16 cycles would be at 1.0 = 1024 FLOP per cycle and SIMD = 2.5 PFLOP/s at 2.4 GHz over 1024 SIMDs."""
+    gg = lambda k: cc.get(k, 0.0)  # noqa: E731
+    cyc = gg("GRBM_GUI_ACTIVE") / 8
+    n_mfma, busy, mops = gg("SQ_INSTS_MFMA"), gg("SQ_VALU_MFMA_BUSY_CYCLES"), gg("SQ_INSTS_VALU_MFMA_MOPS_F16")
+    flops_insts = n_mfma * 16384.0  # every MFMA of these kernels is a 16x16x32 f16: 2 x 16 x 16 x 32 FLOP
+    flops_mops = mops * 512.0 if mops else None
+    d = {"mfma_insts_per_launch": n_mfma, "mfma_busy_cycles_per_launch": busy,
+         "mfma_busy_cycles_per_mfma": round(busy / max(n_mfma, 1), 2),
+         "mfma_busy_frac": round(busy / max(cyc * 1024, 1), 4),
+         "mfma_busy_frac_counter": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
+         "mfma_flops_from_counters": flops_mops if flops_mops else flops_insts,
+         "mfma_flops_counter": ("SQ_INSTS_VALU_MFMA_MOPS_F16 x 512" if flops_mops else "SQ_INSTS_MFMA x 16384 (SQ_INSTS_VALU_MFMA_MOPS_F16 not collected)"),
+         "mfma_flops_from_inst_count": flops_insts,
+         "mfma_tflops_from_counters": round((flops_mops if flops_mops else flops_insts) / (ms * 1e-3) / 1e12, 2),
+         "effective_clock_ghz": round(cyc / (ms * 1e-3) / 1e9, 3),
+         "kernel_ms_profiled": round(ms, 4)}
+    d["mfma_frac_of_2p5_pflops"] = round(d["mfma_tflops_from_counters"] / 2500.0, 4)
+    if flop_per_sample and samples:
+        d["algorithmic_flops"] = flop_per_sample * samples
+    return d
+
+
+mlp = None
+if mlp_rows:
+    longest_mlp = max(r[4] for r in mlp_rows)
+    mc_ = collections.defaultdict(list)
+    for name, g_, counter, value, ms in mlp_rows:
+        if ms >= 0.6 * longest_mlp:  # the 2^24-sample launches (the 2^22 ones take a quarter of the time)
+            mc_[counter].append(value)
+            mc_["_ms"].append(ms)
+    mm = {k: statistics.mean(v) for k, v in mc_.items()}
+    mlp = {"kernel": "nrf::mlp_forward_kernel<false>", "launch": "nrf_mlp_forward on 2^24 resident samples (scripts/mlp_steady.py)",
+           **mfma_block(mm, mm["_ms"], 20480, 1 << 24)}
 ta_busy = g("TA_TA_BUSY_sum") / max(g("GRBM_GUI_ACTIVE") / 8 * 256, 1)  # 256 texture addressers (one per CU)
 wave_cycles = max(g("SQ_WAVE_CYCLES"), 1)
 doc = {
@@ -85,6 +126,8 @@ doc = {
     "wave_time_split": {"issuing": round(g("SQ_ACTIVE_INST_ANY") / wave_cycles, 3), "issue_stalled": round(g("SQ_WAIT_INST_ANY") / wave_cycles, 3),
                         "parked_on_waitcnt_or_barrier": round(g("SQ_WAIT_ANY") / wave_cycles, 3)},
     "l2_hit_rate": round(g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1), 4),
+    "mfma": mfma_block(c, statistics.mean(agg[grid]["_ms"])),
+    "mlp_forward_kernel": mlp,
     "limiter": {
         # two units are loaded about equally; `frac` is the busier one's figure, both are given
         "resource": ("VALU issue port, with the texture-address (gather) path close behind" if cycles / max(simd_cycles, 1) > ta_busy

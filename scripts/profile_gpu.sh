@@ -30,4 +30,10 @@ pass ta2 TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum || true
 pass tcp1 TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum || true
 pass tcp2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum || true
 pass tcp3 TCP_TA_TCP_STATE_READ_sum || true
+# counter-side MFMA utilisation: the render kernel (bench.py) and the fused-MLP stage kernel alone (scripts/mlp_steady.py)
+pass mfma SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE || true
+MLP="python3 $OLDPWD/scripts/mlp_steady.py"
+mlp_pass() { n=$1; shift; timeout -k 10 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_mlp_$n" -- $MLP > "$OUT/pmc_mlp_$n.log" 2>&1; }
+mlp_pass a SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY || true
+mlp_pass b SQ_INSTS_VALU_MFMA_MOPS_F16 || true
 echo profile done

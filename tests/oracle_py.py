@@ -17,6 +17,8 @@ ORACLE_DIR = ROOT / "oracle"
 LIB = ORACLE_DIR / "libnerf_oracle.so"
 
 SCHED_REFERENCE, SCHED_TILE64, SCHED_PER_RAY = 0, 1, 2
+# nrfo_set_mlp_accumulate: fp32 sums (the contract shared with the HIP path) / fp16 accumulator rounded every n products
+ACC_FP32, ACC_FP16_STEP, ACC_FP16_K4, ACC_FP16_K8, ACC_FP16_K16 = 0, 1, 4, 8, 16
 _lib = None
 
 
@@ -38,6 +40,7 @@ def lib():
     L.nrfo_destroy.restype = None
     L.nrfo_widths.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.nrfo_widths.restype = None
+    L.nrfo_set_mlp_accumulate.argtypes = [vp, C.c_int]
     L.nrfo_f32_to_f16.argtypes = [C.c_float]
     L.nrfo_f32_to_f16.restype = C.c_uint16
     L.nrfo_f16_to_f32.argtypes = [C.c_uint16]
@@ -89,11 +92,13 @@ def _fp(a):
 
 
 class Oracle:
-    def __init__(self, desc: nh.ModelDesc):
+    def __init__(self, desc: nh.ModelDesc, accumulate: int = ACC_FP32):
         self.L = lib()
         h = C.c_void_p()
         _ck(self.L.nrfo_create(C.byref(desc), C.byref(h)))
         self.h = h
+        if accumulate != ACC_FP32:
+            self.set_mlp_accumulate(accumulate)
         fw, dw = C.c_uint32(), C.c_uint32()
         self.L.nrfo_widths(h, C.byref(fw), C.byref(dw))
         self.feat_width, self.dir_width = int(fw.value), int(dw.value)  # padded encoding widths (MLP input widths)
@@ -102,6 +107,11 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.nrfo_destroy(self.h)
             self.h = None
+
+    def set_mlp_accumulate(self, mode):
+        """MLP accumulator arithmetic: ACC_FP32 (default, the HIP path's) or the fp16-accumulator emulations of the
+        reference's `__half` WMMA fragments (T/src/fully_fused_mlp.cu:69,334,437)."""
+        _ck(self.L.nrfo_set_mlp_accumulate(self.h, int(mode)))
 
     def grid_index(self, level, x, y, z):
         return int(self.L.nrfo_grid_index(self.h, level, x, y, z))

@@ -129,10 +129,11 @@ def test_generic_shape_stage_by_stage_and_frame(ctx, name):
     rgba, depth = ctx.read_f32()
     st = ctx.stats()
     wantf, wdepth, wst = o.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
-    # evaluated samples: a ray queues up to 8 per round, so at most 7 lie behind its terminating one per round it ends in;
-    # how many do depends on timing since tail splitting (a tiny frame is ALL tail: idle waves take rays every round) --
-    # the deterministic bound is 7 per ray, the samples that reach a compositing sum are the oracle's own
-    assert st.n_samples > 0 and wst.n_samples * 0.995 - 8 <= st.n_samples <= wst.n_samples + 7 * W * H
+    # evaluated samples: a ray queues up to 8 per round (fewer as its transmittance falls: nrf_render.h, sample cap), so a
+    # few lie behind its terminating one; how many depends on timing since tail splitting (a tiny frame is ALL tail: idle
+    # waves take rays every round).  Guarded with a measured margin (tiny frames: <= 5 %), not the worst case of 7 per ray;
+    # the samples that reach a compositing sum are the oracle's own
+    assert st.n_composited <= st.n_samples <= 1.12 * st.n_composited + 256, (name, st.n_samples, st.n_composited)
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.01 * wst.n_composited + 16
     assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0, name
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0

@@ -456,6 +456,66 @@ def test_render_server_survives_rude_clients(snapshot):
         srv.wait(timeout=20)
 
 
+@pytest.mark.gpu
+def test_render_server_stalled_client_does_not_hold_the_gpu(snapshot):
+    """a client that sends an extended request of many views and then reads nothing pinned its replies' host-frame
+    slot for ever, and with it the worker of that GPU -- for every other client.  Now the images waiting behind a stalled
+    socket are copied out of the slot when the worker wants it back (within a budget of spilled bytes), and a consumer that
+    takes no byte for NRF_SERVER_SEND_TIMEOUT_S is dropped.  A stalled NRF1 client beside a normal one: the normal
+    client's 40 sequential requests must all be answered (bytes equal to the binding's render) while the stalled one
+    still holds its connection; the statistics then show evictions, and the stalled connection is closed by the server."""
+    path, desc, keep, cfg = snapshot
+    W, H, port = 640, 480, 23463  # 0.9 MB per image: a 24-view reply is far more than a socket buffer takes
+    env = dict(SERVER_TEST_ENV, NRF_SERVER_BIND="127.0.0.1", NRF_SERVER_SEND_TIMEOUT_S="3")
+    srv = subprocess.Popen([str(HOST / "render_server"), str(port), str(path), str(W), str(H)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, env=env)
+    try:
+        cam = np.array([840, 840, 339, 590], np.float32) * (np.float32(W) / np.float32(1080.0))
+        stalled = _connect(port)
+        assert stalled is not None, "server did not come up"
+        stalled.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)
+        views = [syn.orbit_pose(11.0 * i, 20.0) for i in range(24)]
+        msg = b"NRF1" + np.uint32(len(views)).tobytes()
+        for p in views:
+            msg += cam.tobytes() + np.ascontiguousarray(p, np.float32).tobytes()
+        stalled.sendall(msg)  # ... and never reads
+        time.sleep(0.3)
+        good = _connect(port)
+        good.settimeout(20)  # a worker stuck behind the stalled client's slot would time this out
+        poses = [syn.orbit_pose(9.0 * i, 30.0) for i in range(40)]
+        frames = []
+        t0 = time.time()
+        for p in poses:
+            good.sendall(np.ascontiguousarray(p, np.float32).tobytes())
+            frames.append(np.frombuffer(_recv_exact(good, 3 * W * H), np.uint8).reshape(H, W, 3))
+        served_s = time.time() - t0
+        ctx = nh.NerfHip(0)
+        ctx.load_model(desc)
+        ctx.set_resolution(W, H)
+        for i in (0, 1, 2, 20, 39):
+            ctx.render(cam, poses[i])
+            np.testing.assert_array_equal(frames[i], ctx.read_u8()[0])
+        ctx.close()
+        stat = np.zeros(16, np.float32)
+        stat[:1] = np.frombuffer(b"STAT", np.float32)
+        good.sendall(stat.tobytes())
+        line = _recv_exact(good, 256).rstrip(b"\0").decode().split()
+        fields = dict(zip(line[0::2], line[1::2]))
+        assert int(fields["evictions"]) >= 1, fields  # the stalled client's images were copied out of a slot the worker wanted
+        assert served_s < 15, served_s
+        # the stalled client takes nothing: after the send timeout the server drops it
+        time.sleep(4.5)
+        good.sendall(stat.tobytes())
+        fields = dict(zip(*[iter(_recv_exact(good, 256).rstrip(b"\0").decode().split())] * 2))
+        assert int(fields["dropped_slow"]) >= 1, fields
+        assert srv.poll() is None
+        good.close()
+        stalled.close()
+    finally:
+        srv.kill()
+        srv.wait(timeout=20)
+
+
 def test_snapshot_parser_rejects_hostile_input(tmp_path):
     """The msgpack reader trusts nothing: an array/map length larger than the bytes that follow, or nesting deep
     enough to exhaust the stack, is an error message -- not a 16 GiB reservation or a crash."""

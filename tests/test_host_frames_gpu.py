@@ -296,3 +296,25 @@ def test_host_frames_1080p_size_independent_properties():
         np.testing.assert_array_equal(third[1][7 - v], d8)
     assert (first[0][0][:8] == 255).all() and first[0][0].min() < 200
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H,n_views", [(96, 56, 1), (96, 56, 16), (480, 272, 3)])
+def test_resolution_change_on_a_live_context_keeps_no_state_of_the_old_geometry(model, W, H, n_views):
+    """the host-frame slots were keyed on W * H, so a portrait / landscape flip (same pixel count) kept the old
+    width's row bookkeeping -- stale pixels came back as background -- and, when H grew, strip-row arrays sized for the
+    old tiles_y.  WxH, then HxW, then WxH again on ONE context, each against nrf_render + nrf_read_u8 of a fresh context."""
+    desc, keep, cfg = model
+    poses = [syn.orbit_pose(25.0 * i, 20 + (i % 3) * 10, radius=(4.0311 if i % 4 else 9.0)) for i in range(n_views)]
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    ctx.set_max_views(n_views)
+    for w, h in ((W, H), (H, W), (W, H), (H, W)):
+        cam = syn.default_camera(w, h)
+        want = _reference_u8(desc, w, h, [cam] * n_views, poses)
+        ctx.set_resolution(w, h)
+        for rep in range(2):  # both slots
+            rgb, depth = ctx.render_host_u8([cam] * n_views, poses)
+            for i in range(n_views):
+                np.testing.assert_array_equal(rgb[i], want[i][0], err_msg=f"rgb {w}x{h} view {i} pass {rep}")
+                np.testing.assert_array_equal(depth[i], want[i][1], err_msg=f"depth {w}x{h} view {i} pass {rep}")
+    ctx.close()

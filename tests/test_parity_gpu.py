@@ -261,10 +261,11 @@ def test_render_frame_matches_oracle(ctx, small, W, H, az, el):
     assert np.abs(rgba - want).max() <= 2.0 / 255.0
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
     assert models.psnr(rgba, want) >= 45.0
-    # the kernel batches up to 8 samples per ray and round, so it may evaluate a few samples past a
-    # ray's termination that the one-sample-at-a-time oracle never emits
-    # (how many depends on timing since tail splitting: the deterministic bound is 7 per ray)
-    assert wst.n_samples * 0.995 - 8 <= st.n_samples <= wst.n_samples + 7 * W * H
+    # the kernel batches up to 8 samples per ray and round, so it may evaluate a few samples past a ray's termination that
+    # the one-sample-at-a-time oracle never emits: how many depends on timing (tail splitting), but the per-round queue
+    # shrinks with a ray's transmittance (nrf_render.h, sample cap), so a MEASURED margin guards it: 10 % + 256 on tiny
+    # frames (measured <= 3 %), where the deterministic worst case would be 7 per ray (which guards nothing)
+    assert st.n_composited <= st.n_samples <= 1.10 * st.n_composited + 256, (st.n_samples, st.n_composited)
     # ... while the samples that reach a ray's compositing sum are the oracle's own (per-ray schedule), up to the rays whose
     # termination test falls the other way within the MLP tolerance
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.002 * wst.n_composited + 8 and wst.n_composited == wst.n_samples
@@ -345,6 +346,14 @@ def test_full_size_properties_1080p(ctx):
         np.testing.assert_array_equal(da, db)
     assert np.all(np.isfinite(a)) and a[..., 3].min() >= 0 and a[..., 3].max() <= 1 + 1e-5
     assert da.min() >= 0 and sa.n_samples > 1_000_000
+    # wasted network evaluations (samples a ray queued behind its terminating one) are guarded: a view alone <= 10 %,
+    # the 16-view launch of bench.py <= 4 % (measured with the transmittance-dependent queue: < 1 %)
+    assert sa.n_composited <= sa.n_samples <= 1.10 * sa.n_composited, (sa.n_samples, sa.n_composited)
+    ctx.set_max_views(16)
+    ctx.render_views(np.stack([cam] * 16), np.stack([syn.orbit_pose(45.0 * (i % 8), 30.0) for i in range(16)]))
+    sb = ctx.stats()
+    assert sb.n_composited <= sb.n_samples <= 1.04 * sb.n_composited, (sb.n_samples, sb.n_composited)
+    ctx.render(cam, pose)  # (the single view is the frame the checks below read)
     # rays that miss the aabb are exactly background
     _, _, nr, fr = o.generate_rays(cam, pose, W, H)
     miss = (nr >= fr).reshape(H, W)
