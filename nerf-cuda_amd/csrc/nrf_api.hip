@@ -275,12 +275,13 @@ struct nrf_context {
     size_t views = 0, px = 0;  // capacity
     hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;  // done: the call's last copy; t0 / t1: around its render launches
     hipEvent_t grp[2] = {nullptr, nullptr};                 // the two copy groups a progressive call keeps in flight (progressive_copies)
-    std::vector<int> row_lo, row_hi;  // per view: the rows of the pinned planes that do not hold the background value
+    std::vector<int> row_lo, row_hi;  // per view: the rows of the pinned planes that do not hold the background value ...
+    std::vector<int> col_lo, col_hi;  // ... and, inside those rows, the columns
     int bg = -1;               // the 8-bit background value the other rows hold (-1: nothing filled yet)
     int n_views = 0, W = 0, H = 0;
     bool with_depth = true, pending = false;
     uint64_t copied = 0;
-    std::vector<int> rows;     // this call: per view the rows [lo, hi) of its region of interest (what is copied)
+    std::vector<int> rows;     // this call: per view the rows [lo, hi) and the columns [x0, x1) of its region of interest (what is copied)
     // progress reporting (FrameParams::prog_*): the kernel flags finished strip rows, nrf_wait_host_u8 copies them meanwhile
     unsigned* d_done = nullptr;   // device [views][tiles_y]
     unsigned* h_flags = nullptr;  // pinned host [views][tiles_y]
@@ -292,10 +293,12 @@ struct nrf_context {
   hipStream_t copy_stream = nullptr;
   bool host_merge = true;        // NRF_HOST_MERGE=0: every ready band is copied by itself, at once (A/B runs)
   bool host_progressive = true;  // NRF_HOST_PROGRESSIVE=0: every copy of a host frame waits for the end of its render (A/B runs)
+  bool host_cols = true;         // NRF_HOST_COLS=0: a host frame that is copied after its render travels as whole rows (A/B runs)
   bool host_skip_outside = true; // NRF_HOST_SKIP_OUTSIDE=0: the kernel writes the background rows of a host frame as well (A/B runs)
   void* last_rgba = nullptr;
   void* last_depth = nullptr;
   int march_budget = 256;  // NRF_MARCH_BUDGET overrides (tuning only; the image does not depend on it)
+  bool sample_cap_forced = false;  // NRF_SAMPLE_CAP was given: it holds for every launch (else launches of one or two views queue 8)
   int sample_cap = 2;      // per-round sample queue of a ray by its transmittance (FrameParams::sample_cap); NRF_SAMPLE_CAP=0 / 1: A/B runs
   bool rendered = false;
   hipStream_t last_stream = nullptr;
@@ -745,7 +748,7 @@ int nrf_create(int device, nrf_context** out) {
     const int b = std::atoi(e);
     if (b >= 1 && b <= 4096) c->march_budget = b;
   }
-  if (const char* e = std::getenv("NRF_SAMPLE_CAP")) c->sample_cap = std::atoi(e);
+  if (const char* e = std::getenv("NRF_SAMPLE_CAP")) { c->sample_cap = std::atoi(e); c->sample_cap_forced = true; }
   if (const char* e = std::getenv("NRF_PERSISTENT")) c->allow_persistent = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_CENTRE_OUT")) c->centre_out = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_GEN_WLDS")) c->allow_gen_wlds = std::atoi(e) != 0;
@@ -759,6 +762,7 @@ int nrf_create(int device, nrf_context** out) {
   if (const char* e = std::getenv("NRF_HOST_PROGRESSIVE")) c->host_progressive = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_HOST_MERGE")) c->host_merge = std::atoi(e) != 0;
   if (const char* e = std::getenv("NRF_HOST_SKIP_OUTSIDE")) c->host_skip_outside = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_HOST_COLS")) c->host_cols = std::atoi(e) != 0;
   // The copy stream gets a hardware queue of its own.  HIP maps streams onto a few hardware queues (4 by default) and a
   // device-to-host copy issued while a render is resident on a queue it shares does not start before that render has
   // ended (scripts/copy_overlap_probe.py: a 133 MB copy issued 2 ms into a 14 ms render ended 2.3 ms after the render's
@@ -1181,10 +1185,22 @@ void roi_rows(const int roi[4], int H, int& lo, int& hi) {
   hi = std::min(H, 8 * (ty1 + 1));
 }
 
+// the columns [x0, x1) of whole tiles a view's region of interest touches: the tiles beside them are background (the kernel tests
+// every tile's 8x8 pixels against the region)
+void roi_cols(const int roi[4], int W, int& x0, int& x1) {
+  x0 = x1 = 0;
+  if (roi[2] < roi[0] || roi[3] < roi[1]) return;
+  const int tiles_x = (W + 7) / 8;
+  const int tx0 = std::max(roi[0] >> 3, 0), tx1 = std::min(roi[2] >> 3, tiles_x - 1);
+  if (tx1 < tx0) return;
+  x0 = 8 * tx0;
+  x1 = std::min(W, 8 * (tx1 + 1));
+}
+
 // One launch per NRF_MAX_VIEWS cameras; all launches of a call go to the same stream back to back.  Every call takes the
 // next slot of the context's ring of statistics counters + work queues (cleared on the call's own stream), so calls of
 // one context that overlap on different streams never share a queue.
-// rows_out (optional): per view the rows [lo, hi) its region of interest covers.
+// rows_out (optional): per view the rows [lo, hi) and the columns [x0, x1) (whole tiles) its region of interest covers.
 constexpr float MAX_CAMERA_DISTANCE = 4096.0f;  // in the reference's ngp units (0.33 x the nerf pose's + 0.5), see render_views_impl
 struct ProgressArgs {
   unsigned* done;   // device [n_views][tiles_y], zeroed on the stream before the launches
@@ -1197,6 +1213,9 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
   fill_frame_params(c, cams, poses, P);
   P.out_mode = out_mode;
   P.skip_outside = skip_outside;
+  // one or two views alone are latency-bound, not throughput-bound: their last tiles end sooner when every ray queues its full
+  // eight samples per round, and the few samples evaluated for nothing cost nobody anything (0.904 against 0.914 ms per 1080p view)
+  if (n_views <= 2 && !c->sample_cap_forced) P.sample_cap = 0;
   c->call_index = (c->call_index + 1) % CALL_RING;
   char* counters = call_slot(c, c->call_index);
   unsigned* plan = (c->plan_max_pos > 0 && prog == nullptr) ? (unsigned*)((char*)c->d_plan + (size_t)c->call_index * PLAN_BYTES) : nullptr;
@@ -1229,7 +1248,11 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
           VB.v[v].roi[2] = VB.v[v].roi[3] = -1;
         }
       }
-      if (rows_out) roi_rows(VB.v[v].roi, c->H, rows_out[2 * (first + v)], rows_out[2 * (first + v) + 1]);
+      if (rows_out) {  // {row lo, row hi, column lo, column hi} per view
+        int* ro = rows_out + 4 * (size_t)(first + v);
+        roi_rows(VB.v[v].roi, c->H, ro[0], ro[1]);
+        roi_cols(VB.v[v].roi, c->W, ro[2], ro[3]);
+      }
     }
     if (prog) {  // (the kernel indexes its progress arrays by the launch's own view numbers)
       P.prog_done = prog->done + (size_t)first * P.tiles_y;
@@ -1315,15 +1338,29 @@ static uint8_t host_quant_u8(float v) {  // quant_u8 of nrf_kernels.hip
 }
 
 namespace {
-// copies the rows [lo, hi) of view v of a host-frame slot (both planes) on the context's copy stream
-int copy_rows(nrf_context* c, nrf_context::HostSlot& h, int v, int lo, int hi) {
+// copies the rows [lo, hi) of view v of a host-frame slot (both planes) on the context's copy stream; x0 < x1: only the
+// columns [x0, x1) of those rows (a pitched copy: scripts/copy2d_probe.py measured 46.5 GB/s for 80 % of a 1080p frame's width
+// against 49.1 GB/s for whole rows -- 0.85 of the time)
+int copy_rows(nrf_context* c, nrf_context::HostSlot& h, int v, int lo, int hi, int x0 = 0, int x1 = 0) {
   if (hi <= lo) return NRF_OK;
   const size_t Wb = (size_t)h.W, px = h.px, depth_off = h.views * px * 3;
+  const bool cols = x1 > x0 && (x0 > 0 || x1 < h.W);
   const size_t ro = ((size_t)v * px + (size_t)lo * Wb) * 3, rn = (size_t)(hi - lo) * Wb * 3;
+  const size_t dofs = depth_off + (size_t)v * px + (size_t)lo * Wb, dn = (size_t)(hi - lo) * Wb;
+  if (cols) {
+    const size_t wpx = (size_t)(x1 - x0), n_rows = (size_t)(hi - lo);
+    HIP_TRY(hipMemcpy2DAsync(h.h_buf + ro + (size_t)x0 * 3, Wb * 3, (const uint8_t*)h.d_buf + ro + (size_t)x0 * 3, Wb * 3, wpx * 3, n_rows,
+                             hipMemcpyDeviceToHost, c->copy_stream));
+    h.copied += wpx * 3 * n_rows;
+    if (h.with_depth) {
+      HIP_TRY(hipMemcpy2DAsync(h.h_buf + dofs + x0, Wb, (const uint8_t*)h.d_buf + dofs + x0, Wb, wpx, n_rows, hipMemcpyDeviceToHost, c->copy_stream));
+      h.copied += wpx * n_rows;
+    }
+    return NRF_OK;
+  }
   HIP_TRY(hipMemcpyAsync(h.h_buf + ro, (const uint8_t*)h.d_buf + ro, rn, hipMemcpyDeviceToHost, c->copy_stream));
   h.copied += rn;
   if (h.with_depth) {
-    const size_t dofs = depth_off + (size_t)v * px + (size_t)lo * Wb, dn = (size_t)(hi - lo) * Wb;
     HIP_TRY(hipMemcpyAsync(h.h_buf + dofs, (const uint8_t*)h.d_buf + dofs, dn, hipMemcpyDeviceToHost, c->copy_stream));
     h.copied += dn;
   }
@@ -1344,12 +1381,12 @@ int progressive_copies(nrf_context* c, nrf_context::HostSlot& h) {
   // 16 KiB copies issued during a 13 ms render all ended with it, 64 KiB ones ran beside it).  The smallest copy of a band
   // is its depth plane (W bytes per row; rgb-only frames: 3 W).
   long total = 0;
-  for (int v = 0; v < h.n_views; ++v) total += (h.rows[2 * v + 1] + 7) / 8 - h.rows[2 * v] / 8;
+  for (int v = 0; v < h.n_views; ++v) total += (h.rows[4 * v + 1] + 7) / 8 - h.rows[4 * v] / 8;
   const long want_rows = std::max(4L, (total + 15) / 16);  // strip rows per band
   const long row_bytes = (long)h.W * (h.with_depth ? 1 : 3);
   const long min_rows = (65536 + 8 * row_bytes - 1) / (8 * row_bytes);  // strip rows whose smallest plane is 64 KiB
   for (int v = 0; v < h.n_views; ++v) {
-    const int lo = h.rows[2 * v], hi = h.rows[2 * v + 1];
+    const int lo = h.rows[4 * v], hi = h.rows[4 * v + 1];
     if (hi <= lo) continue;
     const long s_lo = lo / 8, s_hi = (hi + 7) / 8, n = s_hi - s_lo;
     const long per = std::max(want_rows, min_rows);
@@ -1477,6 +1514,8 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
     h.epoch = 0;
     h.row_lo.assign(h.views, 0);
     h.row_hi.assign(h.views, c->H);  // unknown content: everything counts as "not background"
+    h.col_lo.assign(h.views, 0);
+    h.col_hi.assign(h.views, c->W);
     h.bg = -1;
   }
   h.W = c->W;
@@ -1499,7 +1538,7 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
     if (n_views == 1 && c->plan_max_pos > 0 && strips <= (long)c->plan_max_pos) h.progressive = false;
   }
   const size_t depth_off = h.views * px * 3;  // depth planes follow the rgb planes of ALL views the slot holds
-  h.rows.assign((size_t)2 * n_views, 0);
+  h.rows.assign((size_t)4 * n_views, 0);
   ProgressArgs prog{h.d_done, h.h_flags, 0u};
   if (h.progressive) {
     prog.epoch = ++h.epoch;
@@ -1514,37 +1553,59 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
   if (!h.progressive) {  // every copy after the render's end
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, h.t1, 0));
     for (int v = 0; v < n_views; ++v) {
-      rc = copy_rows(c, h, v, h.rows[2 * v], h.rows[2 * v + 1]);
+      // (the copies of a call that is not progressive start after the render: only the region's columns travel.  Progressive
+      //  copies run BESIDE the render, where a pitched copy the runtime chose to move with a blit kernel would find no compute
+      //  unit free -- they keep whole rows)
+      rc = copy_rows(c, h, v, h.rows[4 * v], h.rows[4 * v + 1], c->host_cols ? h.rows[4 * v + 2] : 0, c->host_cols ? h.rows[4 * v + 3] : 0);
       if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(h.done, c->copy_stream));
     h.copies_issued = true;
   }
-  // while the GPU works: the rows outside the regions of interest.  Pinned rows hold the background value unless a copy
-  // has written them since (row_lo / row_hi), so only the difference to the new ranges is filled.
+  // while the GPU works: the pixels outside the regions of interest.  The pinned planes hold the background value except in
+  // the rectangle the copies of earlier calls have written (row_lo / row_hi x col_lo / col_hi), so only that rectangle's
+  // difference to the new one is filled.
   {
     const int bg = host_quant_u8(c->opt.bg_color);
     const bool all = h.bg != bg;
     const size_t Wb = (size_t)c->W;
-    auto fill = [&](int v, int a, int b) {
-      if (b <= a) return;
-      std::memset(h.h_buf + ((size_t)v * px + (size_t)a * Wb) * 3, bg, (size_t)(b - a) * Wb * 3);
-      std::memset(h.h_buf + depth_off + (size_t)v * px + (size_t)a * Wb, 0, (size_t)(b - a) * Wb);  // depth of a missed ray: 0
+    auto fill = [&](int v, int r0, int r1, int c0, int c1) {
+      if (r1 <= r0 || c1 <= c0) return;
+      if (c0 == 0 && c1 == c->W) {
+        std::memset(h.h_buf + ((size_t)v * px + (size_t)r0 * Wb) * 3, bg, (size_t)(r1 - r0) * Wb * 3);
+        std::memset(h.h_buf + depth_off + (size_t)v * px + (size_t)r0 * Wb, 0, (size_t)(r1 - r0) * Wb);  // depth of a missed ray: 0
+        return;
+      }
+      for (int r = r0; r < r1; ++r) {
+        std::memset(h.h_buf + ((size_t)v * px + (size_t)r * Wb + (size_t)c0) * 3, bg, (size_t)(c1 - c0) * 3);
+        std::memset(h.h_buf + depth_off + (size_t)v * px + (size_t)r * Wb + (size_t)c0, 0, (size_t)(c1 - c0));
+      }
     };
+    const bool use_cols = c->host_cols && !h.progressive;  // (what this call's copies write: the region's columns, or whole rows)
     for (int v = 0; v < (int)h.views; ++v) {
       if (v < n_views) {
-        const int lo = h.rows[2 * v], hi = h.rows[2 * v + 1];
+        const int lo = h.rows[4 * v], hi = h.rows[4 * v + 1];
+        int x0 = use_cols ? h.rows[4 * v + 2] : 0, x1 = use_cols ? h.rows[4 * v + 3] : c->W;
+        if (x1 <= x0) { x0 = 0; x1 = c->W; }
         const int plo = all ? 0 : h.row_lo[v], phi = all ? c->H : h.row_hi[v];
-        if (hi <= lo) fill(v, plo, phi);
+        const int pc0 = all ? 0 : h.col_lo[v], pc1 = all ? c->W : h.col_hi[v];
+        if (hi <= lo) fill(v, plo, phi, pc0, pc1);
         else {
-          fill(v, plo, std::min(phi, lo));
-          fill(v, std::max(plo, hi), phi);
+          fill(v, plo, std::min(phi, lo), pc0, pc1);
+          fill(v, std::max(plo, hi), phi, pc0, pc1);
+          const int m0 = std::max(plo, lo), m1 = std::min(phi, hi);  // the rows both rectangles share: the columns beside the new one
+          fill(v, m0, m1, pc0, std::min(pc1, x0));
+          fill(v, m0, m1, std::max(pc0, x1), pc1);
         }
         h.row_lo[v] = lo;
         h.row_hi[v] = hi;
+        h.col_lo[v] = x0;
+        h.col_hi[v] = x1;
       } else if (all) {  // (not part of this call: stays as it is, counted as unknown)
         h.row_lo[v] = 0;
         h.row_hi[v] = c->H;
+        h.col_lo[v] = 0;
+        h.col_hi[v] = c->W;
       }
     }
     h.bg = bg;

@@ -318,3 +318,40 @@ def test_resolution_change_on_a_live_context_keeps_no_state_of_the_old_geometry(
                 np.testing.assert_array_equal(rgb[i], want[i][0], err_msg=f"rgb {w}x{h} view {i} pass {rep}")
                 np.testing.assert_array_equal(depth[i], want[i][1], err_msg=f"depth {w}x{h} view {i} pass {rep}")
     ctx.close()
+
+
+def test_region_of_interest_narrower_than_the_frame_travels_by_columns(model):
+    """A frame that is copied after its render (one view per call) sends only the COLUMNS of its region of interest (pitched
+    copies); the pinned planes hold the background beside them.  The object moves across the frame from call to call on the
+    same two slots (principal point shifted left / right / up, far and near cameras, an all-background view in between, a
+    changed background colour, rgb-only frames): every byte must equal nrf_render + nrf_read_u8 of a fresh context, and a
+    narrow region must have moved fewer bytes than the frame has."""
+    desc, keep, cfg = model
+    W, H = 640, 360
+    base = syn.default_camera(W, H)
+    far, near = syn.orbit_pose(40, 20, radius=14.0 / 0.33), syn.orbit_pose(40, 20, radius=3.0 / 0.33)
+    seq = []
+    for dx, dy, pose in ((-200, 0, far), (200, 0, far), (0, 0, near), (0, -100, far), (250, 120, far), (0, 0, _away(far)), (-250, -120, far),
+                         (0, 0, syn.orbit_pose(10, 40)), (120, 60, far)):
+        cam = base.copy(); cam[2] += dx; cam[3] += dy
+        seq.append((cam, pose))
+    ctx = nh.NerfHip(0)
+    ctx.load_model(desc)
+    ctx.set_resolution(W, H)
+    narrow = 0
+    for bg, flags in ((1.0, 0), (0.25, 0), (0.25, nh.NRF_HOST_RGB_ONLY)):
+        o = nh.default_options(); o.bg_color = bg
+        ctx.set_options(o)
+        want = _reference_u8(desc, W, H, [c for c, _ in seq], [p for _, p in seq], o)
+        for i, (cam, pose) in enumerate(seq):
+            f = ctx.render_host_u8_raw(np.ascontiguousarray(cam, np.float32).reshape(1, 4), np.ascontiguousarray(pose, np.float32).reshape(1, 16), flags)
+            rgb, depth = nh._host_frame_arrays(f, False)
+            np.testing.assert_array_equal(rgb[0], want[i][0], err_msg=f"rgb, bg {bg}, flags {flags}, call {i}")
+            if not flags:
+                np.testing.assert_array_equal(depth[0], want[i][1], err_msg=f"depth, bg {bg}, call {i}")
+            obj = np.any(want[i][0] != want[i][0][0, 0], axis=2)
+            if obj.any() and obj.any(axis=0).sum() < W // 3:  # the object covers less than a third of the width
+                assert f.copied_bytes < W * H * (3 if flags else 4) * 0.6, (i, f.copied_bytes)
+                narrow += 1
+    assert narrow >= 6
+    ctx.close()
