@@ -130,6 +130,38 @@ void pack_fragments(const std::vector<_Float16>& w16, uint32_t rgb_in, std::vect
   for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
 }
 
+// GRID instances (nrf_render.h grid_features): base.json's MLPs behind a grid of F features per level, feat_w = its padded width
+// (16 or 32).  The hot layout (fragments 0 .. N_FRAGS - 1) with the first density layer's K order of that grid: lane group g
+// holds, in this order, the features of the levels {g, 4 + g, ...} it encodes --
+//   F = 2: kmap(g, j) = 2 (4 (j >> 1) + g) + (j & 1)     F = 4: 4 (4 (j >> 2) + g) + (j & 3)     F = 8: 8 g + j
+// -- and zero columns where the grid has no level (k >= feat_w, or a padded feature of feat_w itself).
+void pack_fragments_grid(const std::vector<_Float16>& w16, uint32_t feat_w, uint32_t rgb_in, uint32_t F, std::vector<_Float16>& frags) {
+  frags.assign((size_t)N_FRAGS * 64 * 8, (_Float16)0.0f);
+  const _Float16* D0 = w16.data();                  // [64][feat_w]
+  const _Float16* D1 = D0 + 64 * (size_t)feat_w;    // [16][64]
+  const _Float16* R0 = D1 + 16 * 64;                // [64][rgb_in]
+  const _Float16* R1 = R0 + 64 * (size_t)rgb_in;    // [64][64]
+  const _Float16* R2 = R1 + 64 * 64;                // [16][64]
+  auto khid = [](int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); };
+  auto put = [&](int f, const _Float16* Wm, int in, int m, auto kmap) {
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 8; ++j) {
+        const int k = kmap(l >> 4, j);
+        frags[((size_t)f * 64 + l) * 8 + j] = k < in ? Wm[(size_t)(16 * m + (l & 15)) * in + k] : (_Float16)0.0f;
+      }
+  };
+  const int Fi = (int)F;
+  for (int m = 0; m < 4; ++m)
+    put(FRAG_D0 + m, D0, (int)feat_w, m, [Fi](int g, int j) {
+      return Fi == 2 ? 2 * (4 * (j >> 1) + g) + (j & 1) : (Fi == 4 ? 4 * (4 * (j >> 2) + g) + (j & 3) : 8 * g + j);
+    });
+  for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+  for (int m = 0; m < 4; ++m) put(FRAG_R0 + m, R0, (int)rgb_in, m, [](int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); });
+  for (int m = 0; m < 4; ++m)
+    for (int s = 0; s < 2; ++s) put(FRAG_R1 + 2 * m + s, R1, 64, m, [&](int g, int j) { return khid(s, g, j); });
+  for (int s = 0; s < 2; ++s) put(FRAG_R2 + s, R2, 64, 0, [&](int g, int j) { return khid(s, g, j); });
+}
+
 // The same fragment order for 16 / 32 / 128 neurons (nrf_device.h MlpShape<W>): D0 [W][32] | D1 [16][W] | R0 [W][32] | R1 [W][W] | R2 [16][W],
 // MT = W / 16 row tiles, KS = ceil(W / 32) K steps; columns beyond a matrix's width are zero (W = 16: the upper half of the one step).
 void pack_fragments_width(const std::vector<_Float16>& w16, int Wd, std::vector<_Float16>& frags) {
@@ -232,6 +264,7 @@ struct nrf_context {
   void* d_ctab = nullptr;
   void* d_gen = nullptr;
   void* d_wfrag_gen = nullptr;  // wide models: generic-layout fragments for the stage entry points
+  uint32_t model_hot_grid = 0;  // the loaded model's F if it has a register-resident GRID instance (else 0)
   uint32_t model_hot_width = 0; // the loaded model's width if it has a register-resident width instance (else 0)
   bool model_wide_sh = false;   // ... or the NET_WIDE_SH form (SH degree 5..8)
   void* d_wfrag_hot = nullptr;  // 16 / 32 / 128-neuron models of the base.json shape: fragments of their register-resident instance
@@ -637,10 +670,12 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
   M.n_cus = (uint32_t)c->n_cus;
   M.hot_width = c->model_hot_width;  // (decided again for every grid: nrf_generate_density_grid calls this too)
   M.wide_sh = c->model_wide_sh ? 1u : 0u;
+  M.hot_grid = c->model_hot_grid;
   bool width_instance = false;  // the model's frames come from the register-resident instance of its width (persistent kernel only)
-  if (c->allow_persistent && M.lds_coarse_words > 0 && (M.hot_width || M.wide_sh)) {
+  if (c->allow_persistent && M.lds_coarse_words > 0 && (M.hot_width || M.wide_sh || M.hot_grid)) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
-    const size_t fixed = M.wide_sh ? (size_t)render_persistent_lds_widesh_bytes() : (size_t)render_persistent_lds_width_bytes((int)M.hot_width);
+    const size_t fixed = M.wide_sh ? (size_t)render_persistent_lds_widesh_bytes()
+                         : M.hot_grid ? (size_t)render_persistent_lds_fixed_bytes(0u, 0u, 0u, 16) : (size_t)render_persistent_lds_width_bytes((int)M.hot_width);
     if (fixed + tables <= 160u * 1024u) {
       M.persistent = 1;
       M.persist_waves = M.wide_sh ? 8 : 16;
@@ -649,7 +684,7 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
       width_instance = true;
     }
   }
-  if (!width_instance) M.hot_width = M.wide_sh = 0;  // (the tables do not fit beside its workgroup: the generic instance renders)
+  if (!width_instance) M.hot_width = M.wide_sh = M.hot_grid = 0;  // (the tables do not fit beside its workgroup: the generic instance renders)
   if (c->allow_persistent && M.lds_coarse_words > 0 && !width_instance) {
     const size_t tables = 4 * ((size_t)M.lds_coarse_words + M.lds_ctab_floats + dilated.size());
     // generic instance: 12 waves with the weight fragments in LDS, 12 waves without, 8 with, 8 without -- the first that fits
@@ -937,6 +972,15 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                        d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
                        (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                        d->sigma_activation == NRF_ACT_EXPONENTIAL && c->allow_width_instances;
+  // ... and for its grid: F = 2 with fewer than 16 levels, F = 4 / 8 with at most 32 features in all, Linear or Smoothstep, every
+  // level dense / power-of-two hashed / LV_ADD_POW2 -- the GRID instances (NET_GRID2 / 4 / 8) keep base.json's MLPs in registers
+  const bool hot_grid_ok = !generic_grid && (F == 2 || F == 4 || F == 8) && !(F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR) && L * F <= 32 &&
+                           Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 && dir_w == 16 &&
+                           (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP) &&
+                           d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
+                           (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
+                           d->sigma_activation == NRF_ACT_EXPONENTIAL && c->allow_width_instances;
+  const uint32_t hot_grid = hot_grid_ok ? F : 0u;
   std::vector<_Float16> frags, frags_gen, frags_hot;
   GenModel G;
   std::memset(&G, 0, sizeof(G));
@@ -944,6 +988,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   if (hot_depth) pack_fragments_depth(w16, (int)d->density_hidden_layers, (int)d->rgb_hidden_layers, frags_hot);
   else if (hot_width) pack_fragments_width(w16, (int)hot_width, frags_hot);
   if (wide_sh) pack_fragments(w16, rgb_in, frags_hot);  // the wide layout: first rgb layer in RK_WIDE K steps
+  if (hot_grid) pack_fragments_grid(w16, feat_w, rgb_in, F, frags_hot);
   // the generic description + fragments: the generic instance's model, and -- for a wide model -- what the stage
   // entry points nrf_encode_dir / nrf_mlp_forward run on (rows of the padded widths)
   if (generic || wide) {
@@ -996,20 +1041,25 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   };
-  for (LevelParams& L : lp) {  // byte-offset constants of level_gather
+  // byte-offset constants of level_gather / level_gather_wide: an entry is 2 F bytes (F = 1 never takes these paths)
+  const uint32_t sh_b = F == 8 ? 4u : (F == 4 ? 3u : 2u);
+  for (LevelParams& L : lp) {
     const bool hashed_pow2 = L.mode == LV_HASH_POW2;
-    L.off_b = L.offset << 2;
+    L.off_b = L.offset << sh_b;
     if (hashed_pow2) {
-      L.my_b = 2654435761u << 2;
-      L.mz_b = 805459861u << 2;
-    }  // else: the additive multipliers of the stride loop above (dense: res, res^2; LV_ADD_POW2: possibly wrapped / 0)
-    L.mask_b = (hashed_pow2 || L.mode == LV_ADD_POW2) ? ((L.size - 1) << 2) : 0xffffffffu;
+      L.my_b = 2654435761u << sh_b;
+      L.mz_b = 805459861u << sh_b;
+    } else {  // the additive multipliers of the stride loop above (dense: res, res^2; LV_ADD_POW2: possibly wrapped / 0)
+      L.my_b = (L.my_b >> 2) << sh_b;
+      L.mz_b = (L.mz_b >> 2) << sh_b;
+    }
+    L.mask_b = (hashed_pow2 || L.mode == LV_ADD_POW2) ? ((L.size - 1) << sh_b) : 0xffffffffu;
   }
   HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   if (generic || wide) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
   if (wide) HIP_TRY(upload(&c->d_wfrag_gen, frags_gen.data(), frags_gen.size() * 2));
-  if (hot_width || wide_sh) HIP_TRY(upload(&c->d_wfrag_hot, frags_hot.data(), frags_hot.size() * 2));
+  if (hot_width || wide_sh || hot_grid) HIP_TRY(upload(&c->d_wfrag_hot, frags_hot.data(), frags_hot.size() * 2));
   HIP_TRY(upload(&c->d_lv, lp.data(), lp.size() * sizeof(LevelParams)));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -1062,6 +1112,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   M.depth_xr = hot_depth ? d->rgb_hidden_layers - 1 : 0u;
   M.wfrag_hot = (const uint4*)c->d_wfrag_hot;
   c->model_hot_width = hot_width;
+  c->model_hot_grid = hot_grid;
+  M.hot_grid = hot_grid;
+  M.grid_smooth = d->interpolation == NRF_INTERP_SMOOTHSTEP ? 1u : 0u;
   c->model_wide_sh = wide_sh;
   M.wide_sh = wide_sh ? 1u : 0u;
   M.dir_w = dir_w;
@@ -1682,7 +1735,7 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
 // 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons), 4 its wide form for SH degree 5..8; + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
 extern "C" int nrf_debug_instance(nrf_context* c) {
   if (!c || !c->model_loaded) return -1;
-  return (c->dm.wide_sh ? 4 : (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0)))) + (c->dm.persistent ? 16 : 0);
+  return (c->dm.wide_sh ? 4 : (c->dm.hot_grid ? 5 : (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0))))) + (c->dm.persistent ? 16 : 0);
 }
 
 // Diagnostic build: entry / exit stamps (s_memtime) of the persistent kernel's waves, 2 x n values.

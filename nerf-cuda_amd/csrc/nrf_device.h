@@ -147,6 +147,10 @@ struct DevModel {
   uint32_t hot_width;       // 0, 16, 32 or 128 -- or 64: the DEPTH instance (64 neurons, other numbers of hidden layers: depth_xd / depth_xr)
   uint32_t depth_xd, depth_xr;  // hot_width == 64: 64 -> 64 layers of the density MLP (hidden layers - 1) and of the rgb MLP (hidden layers - 1)
   const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4; wide_sh: the wide layout (N_FRAGS_WIDE_ALL fragments)
+  uint32_t hot_grid;        // 0, or F = 2 / 4 / 8: a grid other than base.json's 16 x 2 -- fewer than 16 levels at F = 2, F = 4 / 8 with up to 32
+                            // features in all, Linear or Smoothstep -- in front of base.json's MLPs: the register-resident GRID instance
+                            // (NET_GRID2 / 4 / 8, persistent kernel only; fragments in wfrag_hot with that grid's K order)
+  uint32_t grid_smooth;     // the grid interpolates with Smoothstep (GRID instances)
   uint32_t wide_sh;         // SphericalHarmonics of degree 5..8 on the base.json shape: NET_WIDE_SH renders the frames (persistent kernel)
   uint32_t dir_w;           // padded width of the direction encoding (16 .. 80)
 };
@@ -706,9 +710,10 @@ __device__ __forceinline__ half2_t weight_times_entry(float w, uint32_t entry) {
 // lane): the network phase is bound by gather latency, not by instruction issue.
 //   level_gather: corner indices + the 8 loads (results not touched) + the fractional position
 //   level_interp: trilinear weights and the fp16 accumulation in corner order
-template <int UNI = 0>
-__device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
-                                             float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
+// level_offsets: the eight corners' BYTE offsets into the table.  SH = log2 of an entry's bytes: 2 for F = 2 (one dword per entry,
+// the base.json shape), 3 / 4 for F = 4 / 8 (nrf_load_model shifts the per-level constants off_b / my_b / mz_b / mask_b alike).
+template <int UNI = 0, int SH = 2>
+__device__ __forceinline__ void level_offsets(const LevelParams L, float px, float py, float pz, uint32_t (&off)[8], float (&frac)[3]) {
   float fx = px * L.scale; fx = fx + 0.5f;
   float fy = py * L.scale; fy = fy + 0.5f;
   float fz = pz * L.scale; fz = fz + 0.5f;
@@ -724,16 +729,15 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
   // offset per lane, so no 64-bit address arithmetic is spent per corner.  The shift by 2 is folded
   // into the per-axis terms ((a ^ b ^ d) << 2 == (a<<2) ^ (b<<2) ^ (d<<2), (g * P) << 2 == g * (P << 2)
   // mod 2^32); nrf_load_model rejects tables of 4 GiB or more.
-  uint32_t off[8];
   const uint32_t level_off = L.off_b;
   {
     // dense and power-of-two hashed levels share the per-axis parts; only the combiner differs
     const bool hashed = UNI == 2 || (UNI == 0 && L.mode == LV_HASH_POW2);
-    const uint32_t my = UNI == 2 ? (2654435761u << 2) : L.my_b;
-    const uint32_t mz = UNI == 2 ? (805459861u << 2) : L.mz_b;
+    const uint32_t my = UNI == 2 ? (2654435761u << SH) : L.my_b;
+    const uint32_t mz = UNI == 2 ? (805459861u << SH) : L.mz_b;
     const uint32_t mask = UNI == 1 ? 0xffffffffu : L.mask_b;
-    const uint32_t ax0 = (gx << 2) + (hashed ? 0u : level_off);  // dense: the level offset rides on the x term
-    const uint32_t ax[2] = {ax0, ax0 + 4u};
+    const uint32_t ax0 = (gx << SH) + (hashed ? 0u : level_off);  // dense: the level offset rides on the x term
+    const uint32_t ax[2] = {ax0, ax0 + (1u << SH)};
     const uint32_t ay0 = gy * my, az0 = gz * mz;
     const uint32_t ay[2] = {ay0, ay0 + my};
     const uint32_t az[2] = {az0, az0 + mz};
@@ -754,7 +758,7 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
       // lanes of one instruction mix dense and hashed levels: both 2-term forms, one v_cndmask per corner.
       // The additive form is masked as well: dense levels carry mask = ~0, an LV_ADD_POW2 level its (size - 1) << 2
       // with mz_b = 0 (nrf_load_model); the level offset is added last (hashed / XY levels are aligned, see above)
-      const uint32_t axr[2] = {gx << 2, (gx << 2) + 4u};
+      const uint32_t axr[2] = {gx << SH, (gx << SH) + (1u << SH)};
       const uint32_t am[2] = {(axr[0] & mask) | level_off, (axr[1] & mask) | level_off};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -765,6 +769,13 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
       }
     }
   }
+}
+
+template <int UNI = 0>
+__device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                             float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
+  uint32_t off[8];
+  level_offsets<UNI, 2>(L, px, py, pz, off, frac);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
 #ifdef NRF_DIAG_HASH_PAIRS
   // diagnostic build (never shipped; WRONG values for odd x): every (x, x + 1) corner pair of a hashed level as ONE aligned
@@ -839,6 +850,61 @@ __device__ __forceinline__ uint32_t level_interp(const uint32_t (&v)[8], const f
 #else
   return h2_bits(acc);
 #endif
+}
+
+// ---- grids with F = 4 / 8 features per level (tcnn's n_features_per_level; T/.../grid.h:1365-1386): an entry is 8 / 16 bytes, a
+// corner ONE aligned 8- / 16-byte MUBUF gather (the texture path charges per lane address, not per byte: profiles/r02/
+// gather_probe.txt), DW = F / 2 packed half2 accumulators per level.  Same arithmetic per feature as level_interp (grid.h:236-262).
+template <int UNI, int DW>
+__device__ __forceinline__ void level_gather_wide(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                                  float py, float pz, uint32_t (&v)[8 * DW], float (&frac)[3]) {
+  static_assert(DW == 2 || DW == 4, "F = 4 or 8");
+  uint32_t off[8];
+  level_offsets<UNI, DW == 2 ? 3 : 4>(L, px, py, pz, off, frac);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if constexpr (DW == 2) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off[c], 0, 0);
+      v[2 * c] = w.x;
+      v[2 * c + 1] = w.y;
+    } else {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[c], 0, 0);
+      v[4 * c] = w.x;
+      v[4 * c + 1] = w.y;
+      v[4 * c + 2] = w.z;
+      v[4 * c + 3] = w.w;
+    }
+  }
+}
+
+template <int DW>
+__device__ __forceinline__ void level_interp_wide(const uint32_t (&v)[8 * DW], const float (&frac)[3], uint32_t (&out)[DW]) {
+  const float wx[2] = {1 - frac[0], frac[0]};
+  const float wy[2] = {1 - frac[1], frac[1]};
+  const float wz[2] = {1 - frac[2], frac[2]};
+  half2_t acc[DW];
+#pragma unroll
+  for (int e = 0; e < DW; ++e) acc[e] = half2_t{(half_t)0.0f, (half_t)0.0f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];  // ((1 * wx) * wy) * wz in dimension order (grid.h:240-252)
+#pragma unroll
+    for (int e = 0; e < DW; ++e) acc[e] = acc[e] + weight_times_entry(w, v[DW * c + e]);  // result += (T)(weight * data), fp16 RNE
+  }
+#pragma unroll
+  for (int e = 0; e < DW; ++e) out[e] = h2_bits(acc[e]);
+}
+
+// Smoothstep interpolation (grid.h InterpolationType::Smoothstep): val * val * (3 - 2 val) on the fractions, T/.../common_device.h:379-381
+__device__ __forceinline__ void smoothstep_fractions(float (&frac)[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float f = frac[d], sq = f * f, b = 2.0f * f;
+    frac[d] = sq * (3.0f - b);
+  }
 }
 
 template <int UNI = 0, bool FAST = false>

@@ -44,6 +44,33 @@ __global__ __launch_bounds__(256) void gen_encode_grid_kernel(const DevModel M, 
     const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
     half_t* row = out + (size_t)s * G.feat_w;
     half_t r[8];
+    if (M.hot_grid != 0u) {
+      // the model's frames come from a GRID instance of the render kernel (nrf_render.h grid_features): this entry point then runs
+      // THAT instance's gathers and interpolation, so that the bit-exact encode test covers them (tests/test_generic_gpu.py)
+      float fr[3];
+      uint32_t o[4] = {0u, 0u, 0u, 0u};
+      if (M.hot_grid == 2u) {
+        uint32_t v[8];
+        level_gather<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (M.grid_smooth) smoothstep_fractions(fr);
+        o[0] = level_interp<false>(v, fr);
+      } else if (M.hot_grid == 4u) {
+        uint32_t v[16], q[2];
+        level_gather_wide<0, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (M.grid_smooth) smoothstep_fractions(fr);
+        level_interp_wide<2>(v, fr, q);
+        o[0] = q[0]; o[1] = q[1];
+      } else {
+        uint32_t v[32];
+        level_gather_wide<0, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (M.grid_smooth) smoothstep_fractions(fr);
+        level_interp_wide<4>(v, fr, o);
+      }
+      for (uint32_t f = 0; f < G.F; f += 2u) *reinterpret_cast<uint32_t*>(row + level * G.F + f) = o[f >> 1];
+      if (level == 0)
+        for (uint32_t j = G.feat_raw; j < G.feat_w; ++j) row[j] = (half_t)0.0f;
+      continue;
+    }
     switch (G.F) {
       case 1: { half_t q[1]; gen_level<1>(grid, lvs[level], G.interp, px, py, pz, q); r[0] = q[0]; } break;
       case 2: { half_t q[2]; gen_level<2>(grid, lvs[level], G.interp, px, py, pz, q); r[0] = q[0]; r[1] = q[1]; } break;
@@ -645,6 +672,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
     if ((long long)q * VB.class_cols >= 0xffffff) return hipErrorInvalidValue;  // 24-bit queue positions
     const int waves = (int)M.persist_waves;
     const int lds = (M.wide_sh ? render_persistent_lds_widesh_bytes() : M.hot_width ? render_persistent_lds_width_bytes((int)M.hot_width)
+                     : M.hot_grid ? render_persistent_lds_fixed_bytes(0u, 0u, 0u, 16)  // (the hot instance's workgroup)
                                  : render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves)) +
                     4 * (int)(M.lds_coarse_words + M.lds_ctab_floats + M.lds_dilated_words) +
                     (M.gen_weights_lds ? 16 + (int)M.gen_frag_bytes : 0);
@@ -672,6 +700,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
     const PersistLaunch L{&M, &P, &VB, rgba, depth, counters, queue, st, lds, wgs, waves, unit, pow2};
     if (M.wide_sh || M.wide) e = launch_persistent_wide(L);   // Frequency / SH directions beyond 16 values (nrf_kernels_wide.hip)
     else if (M.hot_width) e = launch_persistent_width(L);     // 16 / 32 / 128 neurons, other depths (nrf_kernels_width.hip)
+    else if (M.hot_grid) e = launch_persistent_grid(L);       // other grids in front of base.json's MLPs (nrf_kernels_grid.hip)
     else if (M.generic) e = launch_persistent_generic(L);     // nrf_kernels_generic.hip
     else e = launch_persistent_hot(L);                        // the base.json shape (nrf_kernels_hot.hip)
     if (e != hipSuccess) return e;
@@ -893,6 +922,7 @@ void preload_kernels(bool all) {
     preload_wide();
     preload_generic();
     preload_strip();
+    preload_grid();
   }
 }
 

@@ -50,7 +50,11 @@ constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // NET_WIDE_SH: the wide form for SphericalHarmonics of degree 5..8 (32..64 direction values): the entries beyond the first sixteen
 // are computed once per ray into an LDS row (not per sample in-lane as for Frequency) -- persistent kernel only
 // NET_DEPTH: 64 neurons with other numbers of hidden layers than base.json's 1 + 2 (mlp_tiles_depth) -- persistent kernel only
-enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6, NET_DEPTH = 7 };
+// NET_GRID2 / 4 / 8: base.json's MLPs behind another grid -- F = 2 with fewer than 16 levels, F = 4 / 8 with up to 32 features in all,
+// Linear or Smoothstep (grid_features) -- persistent kernel only
+enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6, NET_DEPTH = 7,
+             NET_GRID2 = 8, NET_GRID4 = 9, NET_GRID8 = 10 };
+__host__ __device__ constexpr int net_grid_f(int net) { return net == NET_GRID2 ? 2 : (net == NET_GRID4 ? 4 : (net == NET_GRID8 ? 8 : 0)); }
 constexpr int SH_ROW_HALVES = 72;                     // a ray's row: up to 64 direction values + 8 halves of padding (rows 4 banks apart)
 constexpr int LDS_SHROW_BYTES = 64 * SH_ROW_HALVES * 2;  // 9216 per wave
 __host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 16 : (net == NET_W32 ? 32 : (net == NET_W128 ? 128 : 64)); }
@@ -109,7 +113,40 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // RK > 1 (wide instance): rayd = the wave's ray directions; the direction entries beyond the first sixteen are
 // evaluated here, per sample, as B fragments of the first rgb layer's extra K steps.
 // SHROWS (NET_WIDE_SH): those entries come from the ray's LDS row instead (rows = the wave's rows, SH_ROW_HALVES apart).
-template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, bool DEPTH = false>
+// The lane's 8 grid features (4 dwords) of a GRID instance: lane group g encodes the levels {g, 4 + g, ...} it can hold -- 4 levels
+// of F = 2, 2 of F = 4, 1 of F = 8 -- features in tcnn's order level-major; levels the grid does not have are zero (the padding of
+// the grid encoding is ZERO, grid.h:959-969).  K order of the first density layer: nrf_api.hip pack_fragments_grid.
+template <int GF>
+__device__ __forceinline__ void grid_features(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]) {
+  constexpr int LPL = 8 / GF, DW = GF / 2;  // levels per lane, dwords per entry
+  uint32_t gv[LPL][8 * DW];
+  float gf[LPL][3];
+#pragma unroll
+  for (int jl = 0; jl < LPL; ++jl) {
+    const uint32_t lv = (uint32_t)(4 * jl + g);
+    if (lv < M.n_levels) {  // (masked lanes cost the texture path nothing)
+      const LevelParams L = lvs[lv];
+      if constexpr (GF == 2) level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+      else level_gather_wide<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+      if (M.grid_smooth) smoothstep_fractions(gf[jl]);  // wave-uniform
+    }
+  }
+#pragma unroll
+  for (int jl = 0; jl < LPL; ++jl) {
+    const uint32_t lv = (uint32_t)(4 * jl + g);
+    if (lv < M.n_levels) {
+      if constexpr (GF == 2) fb[jl] = level_interp<false>(gv[jl], gf[jl]);
+      else {
+        uint32_t o[DW];
+        level_interp_wide<DW>(gv[jl], gf[jl], o);
+#pragma unroll
+        for (int e = 0; e < DW; ++e) fb[DW * jl + e] = o[e];
+      }
+    }
+  }
+}
+
+template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, bool DEPTH = false, int GF = 0>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale,
                                                  const half_t* rows = nullptr) {
@@ -139,6 +176,9 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       // on four ADJACENT levels, which for the usual tables are all dense (jl = 0) or all hashed
       // (jl >= 2), so the index arithmetic is specialised per step by a wave-uniform branch.
       // all 32 gathers of the sample go out before the first one is consumed
+      if constexpr (GF != 0) {
+        grid_features<GF>(M, lvs, px, py, pz, g, fb);
+      } else {
       uint32_t gv[4][8];
       float gf[4][3];
 #pragma unroll
@@ -151,6 +191,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       }
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp<FAST>(gv[jl], gf[jl]);
+      }
       const int ray = __builtin_bit_cast(int, p.w);
       db = *reinterpret_cast<const uint2*>(&W->dirf[ray][2 * g]);
       if constexpr (RK > 1 && SHROWS) {
@@ -262,8 +303,9 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
     for (int base = 0; base < S; base += 16 * NTM) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
       constexpr bool DP = NET == NET_DEPTH;
-      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR, DP>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
-      else network_from_lds<NTM, RK, FAST, WD, SHR, DP>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
+      constexpr int GF = net_grid_f(NET);
+      if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR, DP, GF>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
+      else network_from_lds<NTM, RK, FAST, WD, SHR, DP, GF>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
     }
   }
 }
@@ -317,7 +359,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
 // copies the instance's weight fragments into LDS (hot: 0 .. N_FRAGS - 1; wide: followed by FRAG_R0X ..)
 template <int NET>
 __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
-  if constexpr (net_width(NET) != 64 || NET == NET_DEPTH) {
+  if constexpr (net_width(NET) != 64 || NET == NET_DEPTH || net_grid_f(NET) != 0) {  // (GRID: the hot layout, fragments 0 .. N_FRAGS - 1)
     for (int i = threadIdx.x; i < net_wfrag_bytes(NET) / 16; i += blockDim.x) wl[i] = M.wfrag_hot[i];
     return;
   }
@@ -1453,6 +1495,7 @@ hipError_t launch_persistent_hot(const PersistLaunch& L);
 hipError_t launch_persistent_width(const PersistLaunch& L);
 hipError_t launch_persistent_wide(const PersistLaunch& L);
 hipError_t launch_persistent_generic(const PersistLaunch& L);
+hipError_t launch_persistent_grid(const PersistLaunch& L);
 struct StripLaunch {
   const DevModel* M;
   const FrameParams* P;
@@ -1468,6 +1511,7 @@ void preload_width();
 void preload_wide();
 void preload_generic();
 void preload_strip();
+void preload_grid();
 
 // one instance of the persistent form: WV waves per workgroup, WL = generic weights in LDS, 8-bit output / fast_interp chosen at run time
 #define NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, FI)                                                                    \

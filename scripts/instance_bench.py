@@ -17,7 +17,13 @@ SHAPES = [
     ("128 neurons (width instance when persistent)", dict(n_neurons=128)),
     ("32 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=32, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("128 neurons, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_neurons=128, _env={"NRF_WIDTH_INSTANCES": "0"})),
-    ("F = 4 x 8 levels, Smoothstep (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep")),
+    ("F = 4 x 8 levels, Smoothstep (GRID instance when persistent)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep")),
+    ("F = 4 x 8 levels (GRID instance)", dict(n_features_per_level=4, n_levels=8)),
+    ("F = 8 x 4 levels (GRID instance)", dict(n_features_per_level=8, n_levels=4)),
+    ("F = 2 x 8 levels (GRID instance)", dict(n_levels=8)),
+    ("F = 2 x 16 levels, Smoothstep (GRID instance)", dict(interpolation="Smoothstep")),
+    ("F = 4 x 8 levels, Smoothstep, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep", _env={"NRF_WIDTH_INSTANCES": "0"})),
+    ("F = 2 x 8 levels, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_levels=8, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("SH degree 6 (wide-SH form when persistent)", dict(sh_degree=6)),
     ("SH degree 8 (wide-SH form when persistent)", dict(sh_degree=8)),
     ("SH degree 6, NRF_WIDTH_INSTANCES=0 (generic)", dict(sh_degree=6, _env={"NRF_WIDTH_INSTANCES": "0"})),
@@ -27,7 +33,10 @@ SHAPES = [
     ("hidden layers 2 + 2, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=2, rgb_hidden_layers=2, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("hidden layers 3 + 4, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=3, rgb_hidden_layers=4, _env={"NRF_WIDTH_INSTANCES": "0"})),
 ]
+only = sys.argv[1] if len(sys.argv) > 1 else None  # substring filter on the shape names
 for name, kw in SHAPES:
+    if only and only not in name:
+        continue
     kw = dict(kw)
     env = kw.pop("_env", {})
     os.environ.update(env)

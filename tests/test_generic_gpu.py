@@ -381,7 +381,15 @@ def test_wide_and_generic_instances_shard_batch_and_group_like_the_hot_one(ctx, 
     g.close()
 
 
-@pytest.mark.parametrize("shape", ["w16", "w32", "w128", "sh5", "sh6", "sh7", "sh8", "d2_2", "d1_1", "d3_4", "d1_3", "d2_1"])
+GRID_SHAPES = {  # base.json's MLPs behind another grid: the GRID instances (NET_GRID2 / 4 / 8, instance 5)
+    "g4_8": dict(n_features_per_level=4, n_levels=8), "g8_4": dict(n_features_per_level=8, n_levels=4),
+    "g4_6s": dict(n_features_per_level=4, n_levels=6, interpolation="Smoothstep"), "g8_2": dict(n_features_per_level=8, n_levels=2),
+    "g4_3s": dict(n_features_per_level=4, n_levels=3, interpolation="Smoothstep"), "g2_5": dict(n_levels=5), "g2_11": dict(n_levels=11),
+    "g2_16s": dict(interpolation="Smoothstep"), "g2_8": dict(n_levels=8), "g4_8_sig": dict(n_features_per_level=4, n_levels=8, rgb_output_activation="Sigmoid"),
+}
+
+
+@pytest.mark.parametrize("shape", ["w16", "w32", "w128", "sh5", "sh6", "sh7", "sh8", "d2_2", "d1_1", "d3_4", "d1_3", "d2_1"] + sorted(GRID_SHAPES))
 def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shape):
     """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons (T/src/fully_fused_mlp.cu:700-725).  In the base.json shape the
     other three widths have register-resident instances of the persistent kernel too (NET_W16 / NET_W32 / NET_W128: the MFMA
@@ -394,14 +402,31 @@ def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shap
 
     # "d<a>_<b>": 64 neurons with a / b hidden layers in the density / rgb MLP (base.json: 1 / 2) -- the DEPTH instance
     # (mlp_tiles_depth: a runtime number of 64 -> 64 layers, the same in-lane chaining), reported as a width instance too
-    if shape[0] == "d":
+    # "g<F>_<L>[s]": base.json's MLPs behind a grid of F features x L levels (s: Smoothstep) -- the GRID instances (round 4):
+    # F = 2 with fewer than 16 levels, F = 4 / 8 as 8- / 16-byte gathers; additionally the encode entry point (which runs the
+    # instance's own gathers for such a model) is compared with the oracle BIT FOR BIT
+    if shape[0] == "g":
+        kw = GRID_SHAPES[shape]
+    elif shape[0] == "d":
         kw = dict(density_hidden_layers=int(shape[1]), rgb_hidden_layers=int(shape[3]))
     else:
         kw = dict(n_neurons=int(shape[1:])) if shape[0] == "w" else dict(sh_degree=int(shape[2:]))
     width = shape
-    want_instance = 3 if shape[0] in "wd" else 4
+    want_instance = 5 if shape[0] == "g" else (3 if shape[0] in "wd" else 4)
     desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, **kw)
     o = op.Oracle(desc)
+    if shape[0] == "g":
+        c = nh.NerfHip(0)
+        c.load_model(desc)
+        rng = np.random.default_rng(17)
+        p01 = np.concatenate([rng.random((40000, 3), dtype=np.float32), np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.25], [0.5, 1, 1]], np.float32)])
+        want_rows = o.encode_grid(p01)
+        out_rows = torch.empty((len(p01), o.feat_width), dtype=torch.int16, device="cuda")
+        pd = dev(p01)
+        sync()
+        c.encode_grid(pd.data_ptr(), len(p01), out_rows.data_ptr())
+        np.testing.assert_array_equal(out_rows.cpu().numpy().view(np.uint16), want_rows)
+        c.close()
     W, H = 120, 88
     cam = syn.default_camera(W, H)
     poses = [syn.orbit_pose(215, 25), syn.orbit_pose(40, -10), syn.orbit_pose(120, 60)]
