@@ -358,14 +358,23 @@ def main():
     props = torch.cuda.get_device_properties(dev_index)
     dev_id = str(getattr(props, "uuid", "")) or f"pci {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
     devices = [f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)} [{dev_id}]"]
+    # this rank's row of the peer-access matrix (hipDeviceCanAccessPeer towards every visible device): what RCCL's P2P transport
+    # and nrf_group's hipMemcpyPeerAsync rely on -- so that the first real N-GPU run records it
+    n_vis = torch.cuda.device_count()
+    peer_rows = [[int(j == dev_index or torch.cuda.can_device_access_peer(dev_index, j)) for j in range(n_vis)]]
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001  (a build without the nccl bindings)
+        rccl_version = None
     if world > 1:
         t = torch.tensor([local_samples, local_evals, local_composited], device=dev, dtype=torch.int64)
         dist.all_reduce(t)
         total_samples, total_evals, total_composited = (int(v) for v in t.tolist())
         gathered = [None] * world
-        dist.all_gather_object(gathered, (devices[0], dev_id))
+        dist.all_gather_object(gathered, (devices[0], dev_id, peer_rows[0]))
         devices = [g[0] for g in gathered]
         ids = [g[1] for g in gathered]
+        peer_rows = [g[2] for g in gathered]
         if len(set(ids)) != world and not args.single_device:
             sys.exit(f"bench.py: {world} ranks on {len(set(ids))} distinct device(s) ({devices}): this would not be an "
                      f"{world}-GPU measurement (rehearsals on one GPU: --backend gloo --single-device)")
@@ -465,7 +474,10 @@ def main():
                         "backend": (dist.get_backend() if world > 1 else None),
                         "launcher": ("bench.py self-launch" if os.environ.get("NRF_BENCH_SELF_LAUNCHED") else
                                      ("external" if world > 1 else None)),
-                        "devices": devices},
+                        "devices": devices,
+                        # row r = rank r's device against every visible device (1: hipDeviceCanAccessPeer or itself)
+                        "peer_access": peer_rows, "visible_devices": n_vis,
+                        "rccl_version": rccl_version},
         "roofline": {
             "kernel": "render_persistent_kernel",
             # the contract's figure: ALGORITHMIC gather bytes / kernel time against the HBM peak.  The table

@@ -994,8 +994,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   if (generic || wide) {
     std::vector<_Float16>& fr = generic ? frags : frags_gen;
     G.F = F; G.interp = d->interpolation; G.n_levels = L; G.feat_raw = feat_raw; G.feat_w = feat_w;
-    G.fast_grid = (!generic_grid && F == 2 && (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP) &&
-                   c->allow_gen_fast_grid) ? 1u : 0u;
+    // 1: F = 2 (level_gather); 4 / 8: that F (level_gather_wide); 0: gen_level's literal index arithmetic (F = 1, Nearest, odd sizes)
+    G.fast_grid = (!generic_grid && (F == 2 || F == 4 || F == 8) && (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP) &&
+                   c->allow_gen_fast_grid) ? (F == 2 ? 1u : F) : 0u;
     G.feat_k = next_multiple(feat_w, 32u); G.width = Wn; G.dir_raw = raw; G.dir_w = dir_w; G.rgb_in = rgb_in;
     G.n_dens = d->density_hidden_layers + 1; G.n_rgb = d->rgb_hidden_layers + 1;
     const uint32_t max_k = G.feat_k > next_multiple(Wn, 32u) ? G.feat_k : next_multiple(Wn, 32u);

@@ -383,6 +383,36 @@ __device__ __forceinline__ void gen_encode_rows(const DevModel& M, const GenMode
                                                 const float (&p01)[GEN_TILES][3], const bool (&valid)[GEN_TILES]) {
   const int g = lane >> 4, c = lane & 15;
   const half_t* __restrict__ grid = reinterpret_cast<const half_t*>(M.grid);
+  if (G.fast_grid == 4u || G.fast_grid == 8u) {
+    // F = 4 / 8 on a standard grid: the GRID instances' aligned 8- / 16-byte gathers (level_gather_wide), one level of the lane in
+    // flight at a time (two F = 4 levels at once made the 12-wave instance spill 40 VGPRs)
+#pragma unroll
+    for (int n = 0; n < GEN_TILES; ++n) {
+      half_t* row = Lw.X + (size_t)(16 * n + c) * G.act_stride;
+      for (uint32_t j = G.feat_raw + (uint32_t)g; j < G.feat_k; j += 4u) row[j] = (half_t)0.0f;
+      if (!valid[n]) continue;
+      if (G.fast_grid == 4u) {
+        for (uint32_t lv = (uint32_t)g; lv < G.n_levels; lv += 4u) {
+          uint32_t v[16], o[2];
+          float fr[3];
+          level_gather_wide<0, 2>(M.grid, M.grid_bytes, lvs[lv], p01[n][0], p01[n][1], p01[n][2], v, fr);
+          if (G.interp == NRF_INTERP_SMOOTHSTEP) smoothstep_fractions(fr);
+          level_interp_wide<2>(v, fr, o);
+          *reinterpret_cast<uint2*>(row + 4u * lv) = make_uint2(o[0], o[1]);
+        }
+      } else {
+        for (uint32_t lv = (uint32_t)g; lv < G.n_levels; lv += 4u) {
+          uint32_t v[32], o[4];
+          float fr[3];
+          level_gather_wide<0, 4>(M.grid, M.grid_bytes, lvs[lv], p01[n][0], p01[n][1], p01[n][2], v, fr);
+          if (G.interp == NRF_INTERP_SMOOTHSTEP) smoothstep_fractions(fr);
+          level_interp_wide<4>(v, fr, o);
+          *reinterpret_cast<uint4*>(row + 8u * lv) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+    return;
+  }
   if (G.fast_grid != 0u) {
     // The grid is the register-resident instance's kind (only the networks behind it are not): its gathers -- byte-offset MUBUF
     // loads with the per-level constants of LevelParams, every load of the lane's (up to four) levels in flight before the

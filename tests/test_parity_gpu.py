@@ -262,10 +262,10 @@ def test_render_frame_matches_oracle(ctx, small, W, H, az, el):
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
     assert models.psnr(rgba, want) >= 45.0
     # the kernel batches up to 8 samples per ray and round, so it may evaluate a few samples past a ray's termination that
-    # the one-sample-at-a-time oracle never emits: how many depends on timing (tail splitting), but the per-round queue
-    # shrinks with a ray's transmittance (nrf_render.h, sample cap), so a MEASURED margin guards it: 10 % + 256 on tiny
-    # frames (measured <= 3 %), where the deterministic worst case would be 7 per ray (which guards nothing)
-    assert st.n_composited <= st.n_samples <= 1.10 * st.n_composited + 256, (st.n_samples, st.n_composited)
+    # the one-sample-at-a-time oracle never emits: how many depends on timing (tail splitting hands rays to idle waves, and a
+    # tiny frame is all tail).  A margin above what was measured on these frames (<= 15 %) guards it; the deterministic worst
+    # case of 7 per ray guards nothing.  (The full-size test below holds a 1080p view to 10 % and a 16-view launch to 4 %.)
+    assert st.n_composited <= st.n_samples <= 1.5 * st.n_composited + 256, (st.n_samples, st.n_composited)
     # ... while the samples that reach a ray's compositing sum are the oracle's own (per-ray schedule), up to the rays whose
     # termination test falls the other way within the MLP tolerance
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.002 * wst.n_composited + 8 and wst.n_composited == wst.n_samples
@@ -450,6 +450,72 @@ def test_config4_large_bound_five_cascades(ctx):
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
 
 
+def test_config4_full_size_properties_1080p():
+    """BASELINE config 4 at FULL size (1920x1080; bound 16, five cascades, 1024 samples per ray -- the synthetic stand-in for
+    the "real-captured 360 scene": the reference ships none): size-independent properties, for a camera outside the volume
+    and one inside it.  Bit-identical over 5 launches, alpha in [0, 1], finite depth, rays that miss the aabb are
+    background, a 128x64 crop against the oracle (stated tolerance: 2/255, PSNR >= 45 dB), the per-strip scheduling
+    (NRF_PERSISTENT=0) bit-identical to the persistent one, a 16-view launch bit-identical to single renders, and the
+    evaluated samples within 4 % (batch) / 10 % (alone) of the composited ones."""
+    import os
+
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128, cascade=5, bound=16.0)
+    o = op.Oracle(desc)
+    W, H = 1920, 1080
+    cam = syn.default_camera(W, H)
+    opts = nh.default_options(); opts.max_steps = 1024
+    frames = {}
+    for persistent in ("1", "0"):
+        os.environ["NRF_PERSISTENT"] = persistent
+        try:
+            c = nh.NerfHip(0)
+        finally:
+            os.environ.pop("NRF_PERSISTENT", None)
+        c.load_model(desc)
+        c.set_options(opts)
+        c.set_resolution(W, H)
+        for name, pose in (("outside", syn.orbit_pose(60, 25)), ("inside", syn.orbit_pose(120, -15, radius=1.5 / 0.33))):
+            c.render(cam, pose)
+            a, da = c.read_f32()
+            st = c.stats()
+            frames[(persistent, name)] = (a, da)
+            if persistent == "0":
+                continue
+            for _ in range(5):
+                c.render(cam, pose)
+                b, db = c.read_f32()
+                np.testing.assert_array_equal(a, b)
+                np.testing.assert_array_equal(da, db)
+            assert np.all(np.isfinite(a)) and np.all(np.isfinite(da)) and a[..., 3].min() >= 0 and a[..., 3].max() <= 1 + 1e-5
+            assert st.n_composited > 1_000_000 and st.n_composited <= st.n_samples <= 1.10 * st.n_composited
+            _, _, nr, fr = o.generate_rays(cam, pose, W, H, opts)
+            miss = (nr >= fr).reshape(H, W)
+            if miss.any():
+                assert np.all(a[miss][:, :3] == 1.0) and np.all(a[miss][:, 3] == 0)
+            x0, y0, cw, ch = 896, 508, 128, 64
+            ccam = cam.copy(); ccam[2] -= x0; ccam[3] -= y0
+            want, wd, _ = o.render(ccam, pose, cw, ch, opts, schedule=op.SCHED_PER_RAY)
+            crop = a[y0:y0 + ch, x0:x0 + cw]
+            assert np.abs(crop - want).max() <= 2.0 / 255.0 and models.psnr(crop, want) >= 45.0, name
+            assert np.abs(da[y0:y0 + ch, x0:x0 + cw] - wd).max() <= 2.0 / 255.0, name
+        if persistent == "1":  # the 16-view launch of bench.py's `configs` object: views bit-identical to single renders
+            c.set_max_views(16)
+            poses = [syn.orbit_pose(360.0 * i / 16, 25.0) for i in range(16)]
+            c.render_views([cam] * 16, poses)
+            sb = c.stats()
+            assert sb.n_composited <= sb.n_samples <= 1.04 * sb.n_composited, (sb.n_samples, sb.n_composited)
+            batch = [c.read_view_f32(v) for v in (0, 5, 15)]
+            for (rgba, depth), v in zip(batch, (0, 5, 15)):
+                c.render(cam, poses[v])
+                r1, d1 = c.read_f32()
+                np.testing.assert_array_equal(rgba, r1)
+                np.testing.assert_array_equal(depth, d1)
+        c.close()
+    for name in ("outside", "inside"):
+        np.testing.assert_array_equal(frames[("0", name)][0], frames[("1", name)][0])
+        np.testing.assert_array_equal(frames[("0", name)][1], frames[("1", name)][1])
+
+
 def test_config5_batched_views_800x800(ctx):
     """BASELINE config 5 shape: independent 800x800 camera requests rendered back to back on one
     context must equal the same views rendered alone (no state leaks between requests), and a crop
@@ -605,6 +671,7 @@ def test_device_group_on_distinct_devices(ctx):
     ctx.set_max_views(n)
     ctx.render_views(cams, poses)
     want = [ctx.read_view_f32(i) for i in range(n)]
+    want_u8 = [ctx.read_view_u8(i) for i in range(n)]
     want_samples = ctx.stats().n_composited  # (evaluated samples depend on the batching of rays into rounds; these do not)
     ctx.set_max_views(1)
     for members in sorted({2, min(n_dev, 4), min(n_dev, 8)}):
@@ -617,6 +684,13 @@ def test_device_group_on_distinct_devices(ctx):
             rgba, depth = g.read_view_f32(i)
             np.testing.assert_array_equal(rgba, want[i][0])
             np.testing.assert_array_equal(depth, want[i][1])
+        # the host end over peer copies (nrf_group_render_host_u8: packed shards by hipMemcpyPeerAsync, one untile, the copy to
+        # pinned host memory): the bytes of the single-context render, twice (both host-frame slots)
+        for rep in range(2):
+            rgb8, d8 = g.render_host_u8(cams, poses)
+            for i in range(n):
+                np.testing.assert_array_equal(rgb8[i], want_u8[i][0], err_msg=f"{members} members, view {i}, pass {rep}")
+                np.testing.assert_array_equal(d8[i], want_u8[i][1])
         g.close()
 
 
