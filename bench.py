@@ -76,7 +76,7 @@ CLOCK_HZ = 2.4e9                   # max engine clock (the chip holds ~2.2-2.3 G
 DEFAULT_VIEWS = 16                 # camera views per step (one launch)
 DEFAULT_DEPTH = 1                  # steps in flight at N = 1 (N > 1: 2, so that the gather of one step overlaps the next)
 CONFIG5_REQUESTS, CONFIG5_RES = 64, 800  # BASELINE.json configs[4]
-PMC_FILE = ROOT / "profiles" / "r03" / "pmc_traffic.json"
+PMC_FILE = ROOT / "profiles" / "r04" / "pmc_traffic.json"
 
 
 def kernel_source_sha16() -> str:
@@ -507,7 +507,14 @@ def main():
             "aggregate_frac": round(gather_gbs * in_flight / HBM_PEAK_GBS, 5),
             "isolated_kernel_ms": round(iso_kern_s * 1e3, 4),
             "isolated_frac": round(mean_samples_launch * BYTES_PER_SAMPLE / iso_kern_s / 1e9 / HBM_PEAK_GBS, 5),
+            # MFMA share of the render kernel: from this run's sample count (composited samples x 20 480 FLOP: the padding of the
+            # 16-sample tiles and the samples evaluated behind a ray's end are not in it) ...
             "mfma_tflops_aggregate": round(msamples_s * 1e6 * FLOP_PER_SAMPLE / 1e12 / max(world, 1), 3),
+            # ... and from the committed counters of the same command (north_star: "rocprof showing achieved MFMA utilisation"):
+            # SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles, FLOPs from SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 over the profiled kernel time
+            "mfma_busy_frac": ((pmc.get("mfma") or {}).get("mfma_busy_frac") if pmc else None),
+            "mfma_tflops_from_counters": ((pmc.get("mfma") or {}).get("mfma_tflops_from_counters") if pmc else None),
+            "mfma_frac_of_peak_from_counters": ((pmc.get("mfma") or {}).get("mfma_frac_of_2p5_pflops") if pmc else None),
             # what the counters say binds the kernel (profiles/r02: the issue-rate microbenchmark + PMC passes)
             "limiter": (pmc.get("limiter") if pmc else None),
             "valu_insts_per_launch": valu,
@@ -523,6 +530,12 @@ def main():
             out["march_fast_forward"] = march_ff_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V)
             with torch.cuda.stream(stream):
                 out["mlp_kernel"] = mlp_microbench(ctx, torch, dev)
+            if pmc and pmc.get("mlp_forward_kernel"):  # counter side of the same kernel at 2^24 samples (committed --pmc pass)
+                m = pmc["mlp_forward_kernel"]
+                out["mlp_kernel"]["counters"] = {k: m.get(k) for k in ("mfma_busy_frac", "mfma_tflops_from_counters", "mfma_frac_of_2p5_pflops",
+                                                                      "mfma_flops_from_counters", "algorithmic_flops", "effective_clock_ghz",
+                                                                      "kernel_ms_profiled", "mfma_flops_counter")}
+                out["mlp_kernel"]["counters"]["source"] = str(PMC_FILE.relative_to(ROOT))
             t0 = time.perf_counter()
             out["configs"] = configs_bench(nh, torch, dev, desc)
             out["configs"]["wall_s"] = round(time.perf_counter() - t0, 1)

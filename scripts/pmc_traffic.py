@@ -23,7 +23,8 @@ for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
                (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
         if "render_kernel" in r["Kernel_Name"] or "render_persistent_kernel" in r["Kernel_Name"]:
             rows.append(rec)
-        elif "mlp_forward_kernel<false>" in r["Kernel_Name"] or "mlp_forward_kernel<0>" in r["Kernel_Name"]:
+        elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<false>", "mlp_forward_kernel<0>", "mlp_forward_kernelILb0E")) and "gen_mlp" not in r["Kernel_Name"]:
+            # (rocprofv3 leaves this symbol mangled: its _Float16 parameter)
             mlp_rows.append(rec)  # the fused-MLP stage kernel, HBM-fed (scripts/mlp_steady.py under --pmc: profile_gpu.sh `mlp_*` passes)
 # the batched launches of the timed region: the persistent kernel's grid is the same for every launch (one workgroup per
 # CU), so the single-view replays are told apart by their duration
