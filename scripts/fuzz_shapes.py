@@ -28,6 +28,10 @@ for case in range(n_cases):
         kw["n_features_per_level"] = 2
     if rng.random() < 0.3:
         kw["rgb_output_activation"] = "Sigmoid"
+    if rng.random() < 0.35:  # base.json's MLPs behind the random grid: the GRID / hot instances (round 4)
+        kw.update(n_neurons=64, density_hidden_layers=1, rgb_hidden_layers=2)
+        kw.pop("dir_otype", None); kw.pop("n_frequencies", None)
+        kw["sh_degree"] = int(rng.integers(1, 5))
     geo = dict(H=int(rng.choice([16, 32, 33, 64])), log2_hashmap_size=int(rng.integers(8, 15)))
     if rng.random() < 0.4:
         geo.update(cascade=int(rng.integers(2, 5)), bound=float(rng.choice([2.0, 4.0, 3.0])))
@@ -40,9 +44,12 @@ for case in range(n_cases):
         p01 = rng.random((513, 3), dtype=np.float32)
         feat = o.encode_grid(p01)
         res = []
+        inst = {}
         for persistent in ("1", "0"):
             os.environ["NRF_PERSISTENT"] = persistent
             c = nh.NerfHip(0); c.load_model(desc); c.set_resolution(W, H)
+            c.lib.nrf_debug_instance.argtypes = [__import__("ctypes").c_void_p]
+            inst[persistent] = c.lib.nrf_debug_instance(c.h) & 15
             c.render(cam, pose)
             got, gdepth = c.read_f32()
             out = torch.empty((513, o.feat_width), dtype=torch.int16, device="cuda")
@@ -59,7 +66,14 @@ for case in range(n_cases):
                 print("FAIL", "persistent" if persistent == "1" else "per-strip", geo, kw, f"encode bit-exact {enc_ok}, max|d| {err:.2e}, depth {derr:.2e}, psnr {ps:.1f}, "
                       f"samples {c.stats().n_samples} (oracle {wst.n_samples})", flush=True)
             c.close()
-        if not (np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32)) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))):
+        # the two schedulings run the same instance bit for bit -- unless the persistent form has a register-resident instance
+        # of its own for this shape (width / depth / wide-SH / GRID: 3, 4, 5) while the per-strip kernel runs the generic one:
+        # those sum in different K orders and agree within the MLP tolerance (checked against the oracle above)
+        if inst["1"] in (3, 4, 5) and inst["0"] == 1:
+            same = float(np.abs(res[0][0] - res[1][0]).max()) <= 2.0 / 255.0
+        else:
+            same = np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32)) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+        if not same:
             bad += 1
             print("SCHEDULINGS DIFFER", geo, kw, flush=True)
     except nh.NerfHipError as e:

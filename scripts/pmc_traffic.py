@@ -143,11 +143,15 @@ doc = {
         "binding_unit": "VALU issue port and texture-address (gather) path, co-limiting",
         # the in-situ check of that attribution (round 3): instructions of a KNOWN count added to / taken from the two big phases
         "marginal_cost_in_situ": marginal,
-        "marginal_cost_reading": "after the barrier fast-forward (the march lost ~90 % of its trips) the texture-address path leads (0.87-0.88 busy) and "
-                                 "the issue port follows (0.80): an added half-rate instruction in the interpolation still costs 2.1-2.4 of its 4.1 "
-                                 "nominal cycles and an added v_mul_f32 per march trip 1.6-2.0 of 2.25, removing interpolation instructions returns "
-                                 "0.6 cycles each (nocvt), the opt-in fast_interp < 1 %: both units are within a tenth of each other, trading work "
-                                 "between them returns little",
+        "marginal_cost_reading": (None if not marginal else
+                                  "in situ (diagnostic builds that add / drop a known number of instructions): an added half-rate instruction in the "
+                                  f"interpolation costs {min(marginal['interp1']['cycles_per_instruction_and_simd'], marginal['interp2']['cycles_per_instruction_and_simd']):.1f}-"
+                                  f"{max(marginal['interp1']['cycles_per_instruction_and_simd'], marginal['interp2']['cycles_per_instruction_and_simd']):.1f} of its 4.1 nominal cycles, "
+                                  f"an added v_mul_f32 per march trip {min(marginal['march8']['cycles_per_instruction_and_simd'], marginal['march16']['cycles_per_instruction_and_simd']):.1f}-"
+                                  f"{max(marginal['march8']['cycles_per_instruction_and_simd'], marginal['march16']['cycles_per_instruction_and_simd']):.1f} of 2.25, removing the interpolation's "
+                                  f"conversions returns {marginal['nocvt']['cycles_per_instruction_and_simd']:.1f} cycles each: added vector work costs more than half "
+                                  "of its issue time (the port is a limiter), removed work returns little (the texture-address path binds at once) -- "
+                                  "both units are within a tenth of each other, trading work between them returns little"),
         "note": "The VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max / "
                 "med3, conversions, shifts, v_mul_lo_u32, packed fp16, v_fma_mix); transcendentals 8; an MFMA holds the issue port for 8 "
                 "(scripts/issue_rate/issue_rate.hip, profiles/r02/issue_rate.txt: 34 opcodes; the int32 and remainder counter classes are "
