@@ -450,19 +450,23 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict_
 // One view (a render_frame call) is ~8 strips per wave of the persistent kernel, and a heavy 8x8 tile alone is longer than a
 // wave's fair share of the frame: in which ORDER the queues hand the strips out decides how long the launch's tail is.
 // Two small kernels ahead of the render price and sort the launch's strips:
-//   plan_price_kernel  one thread per tile: its centre ray is sampled at PLAN_SAMPLES points between its entry into and its
+//   plan_price_kernel  one thread per tile: its centre ray walks the dilated coarse occupancy (a DDA, as the render kernel's visibility walk) between its entry into and its
 //                      exit from the box of occupied cells, against the dilated coarse occupancy table (LDS); the points in
 //                      set cells, times their spacing over the march's step there, estimate the ray's march steps.  A strip
 //                      takes the maximum of its four tiles.  (It also zeroes the call's statistics counters and queue words:
 //                      the memset that used to precede the render.)
 //   plan_sort_kernel   one workgroup: counting sort of every class's queue positions by that price, dearest first
 //                      (PLAN_BINS bins relative to the launch's dearest strip; a bin roughly keeps the centre-out order).
+// The price is GEOMETRIC on purpose: with the MEASURED cost of every tile as its price (a diagnostic experiment, round 4) a lone
+// 1080p view took 0.98 ms instead of 0.87 (no plan: 0.90) -- tiles of equal cost lie all over the picture, a cost-sorted
+// queue renders distant strips side by side and the table's cache locality is gone; the path length through the occupancy
+// varies smoothly over the picture, so sorting by it is roughly dearest-first AND spatially coherent.
 // The render kernel then reads position i of a class through this permutation.  Only the ORDER of the work depends on the
 // estimate: every strip is rendered exactly as before, and the frames are bit-identical with and without a plan
 // (tests/test_persistent_gpu.py).
 //   plan buffer (unsigned words): [1] max price (float bits; reset by the sort), [4 .. 4 + cap) price per position
 //   (class-major: class c's positions follow those of the classes before it), [4 + cap .. 4 + 2 cap) the order
-constexpr int PLAN_BINS = 64, PLAN_THREADS = 256, PLAN_SORT_THREADS = 1024, PLAN_SAMPLES = 32;
+constexpr int PLAN_BINS = 64, PLAN_THREADS = 256, PLAN_SORT_THREADS = 1024;
 struct PlanClasses {
   unsigned off[9];  // where each class's positions begin (class-major numbering); [8] = all positions
   unsigned n_cls;
@@ -533,22 +537,53 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_price_kernel(const DevModel
       box_interval(M.occ_box, o, 1 / d[0], 1 / d[1], 1 / d[2], t_in, t_out);
       const float t0 = fmaxf(t_in, near), t1 = fminf(far, t_out);
       if (near < far && M.occ_box[0] <= M.occ_box[3] && t0 < t1) {
+        // a DDA over the dilated coarse cells (the render kernel's own visibility walk, one per cascade on that cascade's stretch
+        // of the ray): the path inside set cells over the march's step there.  (Round 3 sampled 32 points along the ray: on a
+        // 2-3 unit stretch those are 0.06-0.1 apart, a coarse cell is 0.06 wide -- thin structures were priced at zero, and
+        // tiles as dear as 0.6 Mcycles started in the last third of a lone frame: profiles/r04/tile_cost_map_before.txt)
         const int Hc = (int)(M.H >> 2);
         const float dt_min = 2 * 1.7320508075688772f / 1024, dt_max = 2 * M.bound / (float)M.H;
-        const float seg = (t1 - t0) * (1.0f / PLAN_SAMPLES);
-        for (int i = 0; i < PLAN_SAMPLES; ++i) {  // (independent of each other: the table lookups overlap)
-          const float t = t0 + ((float)i + 0.5f) * seg;
-          const float x = o[0] + t * d[0], y = o[1] + t * d[1], z = o[2] + t * d[2];
-          const float m = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-          int e = 0;
-          (void)frexpf(m, &e);  // m in [2^(e-1), 2^e): the cascade whose cube first holds the point
-          const int k = min(max(e, 0), (int)M.cascade - 1);
-          const float mb = M.cascade > 1 ? fminf(ldexpf(1.0f, k), M.bound) : fminf(1.0f, M.bound);
-          const float rcs = (float)Hc / (2.0f * mb);
-          const int cx = (int)floorf((x + mb) * rcs), cy = (int)floorf((y + mb) * rcs), cz = (int)floorf((z + mb) * rcs);
-          if ((unsigned)cx < (unsigned)Hc && (unsigned)cy < (unsigned)Hc && (unsigned)cz < (unsigned)Hc) {
-            const uint32_t cc = ((uint32_t)cx * Hc + (uint32_t)cy) * Hc + (uint32_t)cz;
-            if ((s_dil[(size_t)k * M.dilated_level_words + (cc >> 5)] >> (cc & 31u)) & 1u) cost += seg / clampf(t * P.dt_gamma, dt_min, dt_max);
+        const float rd[3] = {1 / d[0], 1 / d[1], 1 / d[2]};
+        for (uint32_t k = 0; k < M.cascade; ++k) {
+          const float mb = M.cascade > 1 ? fminf(ldexpf(1.0f, (int)k), M.bound) : fminf(1.0f, M.bound);
+          float c_in = t0, c_out = t1;
+          if (M.cascade > 1) {
+            const float cube[6] = {-mb, -mb, -mb, mb, mb, mb};
+            float a, b;
+            box_interval(cube, o, rd[0], rd[1], rd[2], a, b);
+            if (a == a && b == b) {
+              c_in = fmaxf(c_in, a);
+              c_out = fminf(c_out, b);
+            }
+          }
+          if (!(c_in < c_out)) continue;
+          const uint32_t* dil = s_dil + (size_t)k * M.dilated_level_words;
+          const float cs = 2.0f * mb / (float)Hc, rcs = (float)Hc / (2.0f * mb);
+          int ci[3], step[3];
+          float tmax[3], tdelta[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float pa = o[a] + c_in * d[a];
+            int cc = (int)floorf((pa + mb) * rcs);
+            cc = cc < 0 ? 0 : (cc > Hc - 1 ? Hc - 1 : cc);
+            ci[a] = cc;
+            step[a] = d[a] >= 0.0f ? 1 : -1;
+            const float edge = (float)(cc + (d[a] >= 0.0f ? 1 : 0)) * cs - mb;
+            const bool flat = !(fabsf(rd[a]) <= 3.0e38f);
+            tmax[a] = flat ? 3.0e38f : (edge - o[a]) * rd[a];
+            tdelta[a] = flat ? 3.0e38f : cs * fabsf(rd[a]);
+          }
+          float t = c_in;
+          for (int guard = 0; guard < 3 * Hc + 3; ++guard) {
+            const uint32_t cc = ((uint32_t)ci[0] * Hc + (uint32_t)ci[1]) * Hc + (uint32_t)ci[2];
+            const float t_exit = fminf(fminf(tmax[0], fminf(tmax[1], tmax[2])), c_out);
+            if (((dil[cc >> 5] >> (cc & 31u)) & 1u) && t_exit > t) cost += (t_exit - t) / clampf(0.5f * (t + t_exit) * P.dt_gamma, dt_min, dt_max);
+            if (!(t_exit < c_out)) break;
+            t = t_exit;
+            if (tmax[0] <= t_exit) { ci[0] += step[0]; tmax[0] += tdelta[0]; }
+            if (tmax[1] <= t_exit) { ci[1] += step[1]; tmax[1] += tdelta[1]; }
+            if (tmax[2] <= t_exit) { ci[2] += step[2]; tmax[2] += tdelta[2]; }
+            if ((unsigned)ci[0] >= (unsigned)Hc || (unsigned)ci[1] >= (unsigned)Hc || (unsigned)ci[2] >= (unsigned)Hc) break;
           }
         }
       }
