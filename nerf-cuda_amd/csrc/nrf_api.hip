@@ -1384,7 +1384,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
 // context owns, and the rows outside it -- background by construction -- are filled by the calling thread while the GPU
 // renders (only those that held something else: a camera that moves a little costs a few rows).  Two slots: the copy of
 // one call overlaps the render of the next.
-static uint8_t host_quant_u8(float v) {  // quant_u8 of nrf_kernels.hip
+static uint8_t host_quant_u8(float v) {  // quant_u8 of nrf_render.h
   const double s = 255.0 * (double)v;
   if (!(s > 0.0)) return 0;
   if (s >= 255.0) return 255;
@@ -1423,7 +1423,7 @@ int copy_rows(nrf_context* c, nrf_context::HostSlot& h, int v, int lo, int hi, i
 
 // The copies of a progressive call, issued by the waiting thread while the render is still running: a band of strip rows
 // goes to the copy engine as soon as the kernel has flagged all of its rows (the bytes are in memory by then: write-through
-// stores, acknowledged before the row was counted -- nrf_kernels.hip tile_written); whatever is left when the kernel's end
+// stores, acknowledged before the row was counted -- nrf_render.h tile_written); whatever is left when the kernel's end
 // event fires is copied then.  The loop ends with the kernel at the latest: it cannot wait for a flag that never comes.
 int progressive_copies(nrf_context* c, nrf_context::HostSlot& h) {
   struct Band { int view, lo, hi, s0, s1; };  // pixel rows [lo, hi) = strip rows [s0, s1) of the view

@@ -209,7 +209,7 @@ struct FrameParams {
   int prog_epoch;
   int fast_interp;  // nrf_options::fast_interp: the FAST instances of the persistent register-resident kernel / encode_grid_kernel
   int tail_split;   // persistent kernel: 1 = waves that find the queues empty take rays off the rendering waves of their
-                    // workgroup (tail splitting, nrf_kernels.hip); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
+                    // workgroup (tail splitting, nrf_render.h); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   int march_ff;     // 1 = a ray steps straight to its last barrier plane ahead of t_skip (fast_forward_to_barrier); 0 = every
                     // trip of that stretch is simulated (A/B runs and the equality tests: NRF_MARCH_FF=0)
   int sample_cap;   // the samples a ray may queue per round shrink with its transmittance T: fewer samples evaluated behind a ray's
