@@ -1098,6 +1098,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   for (int jl = 0; jl < 4; ++jl) {
     bool all_dense = true, all_hash = true;
     for (int g = 0; g < 4; ++g) {
+      if ((uint32_t)(4 * jl + g) >= L) continue;  // (a level the grid does not have: its lanes are masked, grid_features)
       all_dense = all_dense && lp[4 * jl + g].mode == LV_DENSE;
       all_hash = all_hash && lp[4 * jl + g].mode == LV_HASH_POW2;
     }

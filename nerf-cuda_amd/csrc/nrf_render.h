@@ -126,8 +126,16 @@ __device__ __forceinline__ void grid_features(const DevModel& M, const LevelPara
     const uint32_t lv = (uint32_t)(4 * jl + g);
     if (lv < M.n_levels) {  // (masked lanes cost the texture path nothing)
       const LevelParams L = lvs[lv];
-      if constexpr (GF == 2) level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-      else level_gather_wide<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+      const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;  // the group's existing levels are all dense (1) / all hashed (2): wave-uniform
+      if constexpr (GF == 2) {
+        // (all three specialisations side by side over four masked levels cost this instance 8 VGPRs of spills: the hashed and the mixed form)
+        if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+      } else {
+        if (uni == 2u) level_gather_wide<2, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else if (uni == 1u) level_gather_wide<1, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        else level_gather_wide<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+      }
       if (M.grid_smooth) smoothstep_fractions(gf[jl]);  // wave-uniform
     }
   }
