@@ -78,6 +78,10 @@ def test_self_launched_two_rank_rehearsal_tile_sharded():
     # weak scaling is the default: the step grows with the ranks (2 frames per rank's worth of tiles -> 4 frames)
     assert out["scaling"] == "weak" and out["config"]["views_per_step"] == 4
     assert out["config"]["gather_root"] == "step % N"  # the default: every rank assembles every N-th step's frames
+    # what the first real N-GPU run is to record: every rank's row of the peer-access matrix and the RCCL version
+    d = out["distributed"]
+    assert len(d["peer_access"]) == 2 and all(len(row) == d["visible_devices"] and row[0] == 1 for row in d["peer_access"])
+    assert "rccl_version" in d
 
 
 @pytest.mark.gpu
