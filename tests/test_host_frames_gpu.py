@@ -355,3 +355,31 @@ def test_region_of_interest_narrower_than_the_frame_travels_by_columns(model):
                 narrow += 1
     assert narrow >= 6
     ctx.close()
+
+
+@pytest.mark.parametrize("members", [1, 2])
+def test_failed_group_submit_commits_nothing(model, members):
+    """nrf_group_submit_host_u8 used to advance its slot and hand out the ticket before anything was validated; a
+    submit that failed midway left a slot that a later wait reported as OK with stale frames.  A submit on a group WITHOUT a
+    model fails; waiting on either ticket afterwards is NRF_E_STATE ("nothing was submitted"), and once a model is loaded the
+    next submit takes ticket 0 again and returns the right bytes."""
+    desc, keep, cfg = model
+    W, H = 96, 64
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(30, 30)
+    g = nh.NerfGroup([0] * members)
+    g.set_resolution(W, H) if members == 1 else None
+    with pytest.raises(nh.NerfHipError):
+        g.submit_host_u8([cam], [pose])  # no model (and for several members: no resolution either)
+    for t in (0, 1):
+        with pytest.raises(nh.NerfHipError) as e:
+            g.wait_host_u8(t)
+        assert e.value.code == nh.NRF_E_STATE
+    g.load_model(desc)
+    g.set_resolution(W, H)
+    want = _reference_u8(desc, W, H, [cam], [pose])
+    t = g.submit_host_u8([cam], [pose])
+    assert t == 0
+    rgb, depth = g.wait_host_u8(t)
+    np.testing.assert_array_equal(rgb[0], want[0][0])
+    np.testing.assert_array_equal(depth[0], want[0][1])
+    g.close()
