@@ -539,6 +539,7 @@ def main():
             t0 = time.perf_counter()
             out["configs"] = configs_bench(nh, torch, dev, desc)
             out["configs"]["wall_s"] = round(time.perf_counter() - t0, 1)
+            out["server"] = server_bench()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity"] = cpu_baseline(nh, dev, desc, cam, poses[0], W, H, args.cpu_sample_div)
     print(json.dumps(out), flush=True)
@@ -615,6 +616,22 @@ def configs_bench(nh, torch, dev, desc2):
     # config 5: 64 camera requests of 800x800 in ONE launch (the render_server's batch)
     out["config5_64_requests_800x800"] = run(desc2, CONFIG5_RES, CONFIG5_RES, CONFIG5_REQUESTS, reps=3)
     return out
+
+
+def server_bench():
+    """BASELINE configs[4] through the REAL render_server (nerf-cuda_amd/host/render_server: the reference's wire protocol on TCP,
+    one queue + worker per GPU, 64-view batches, two in flight): 64 concurrent clients, each with one 800x800 request in
+    flight, 40 requests per client after two warm-up ones -- scripts/server_bench.py as a child process (its own server and
+    client threads; this process is idle meanwhile).  Never fails the bench: a problem is reported in the object."""
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "server_bench.py"), "--clients", "64", "--requests", "40", "--port", "23611"],
+                           capture_output=True, text=True, timeout=150)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:400]}
 
 
 def api_bench(nh, torch, dev, desc, cam, poses, W, H):

@@ -46,7 +46,7 @@ snap = Path(tmp) / "scene.msgpack"
 syn.write_snapshot(snap, cfg, keep[0], keep[1], binary="__half")
 env = dict(os.environ, NRF_SERVER_TEST_HOOKS="1", NRF_SERVER_BIND="127.0.0.1", NERF_DEVICES=args.devices, NERF_SERVER_MODE=args.mode,
            NRF_SERVER_MAX_CLIENTS=str(max(256, args.clients + 8)))
-srv = subprocess.Popen([str(ROOT / "nerf-cuda_amd" / "host" / "render_server"), str(args.port), str(snap), str(W), str(H)],
+srv = subprocess.Popen([os.environ.get("NRF_SERVER_BIN", str(ROOT / "nerf-cuda_amd" / "host" / "render_server")), str(args.port), str(snap), str(W), str(H)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
 
 
