@@ -8,7 +8,7 @@ import models, nerfhip as nh, synthetic as syn
 W, H, V = 1920, 1080, 16
 cams = np.stack([syn.default_camera(W, H)] * V)
 poses = np.stack([syn.orbit_pose(45.0 * (i % 8), 30.0) for i in range(V)])
-for log2t in (19, 20, 21, 22, 23):
+for log2t in [int(a) for a in sys.argv[1:]] or (19, 20, 21, 22, 23):
     desc, keep, _ = models.build_model(log2_hashmap_size=log2t, H=128)
     c = nh.NerfHip(0); c.load_model(desc); c.set_resolution(W, H); c.set_max_views(V)
     s = torch.cuda.Stream()
