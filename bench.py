@@ -126,6 +126,11 @@ def parse_args():
     ap.add_argument("--check", action="store_true", default=None,
                     help="rank 0 also renders the frame unsharded and compares (default: on whenever there is more than one rank)")
     ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU exchange even with ONE rank: init_process_group(--backend), the shard rendered tile-major "
+                         "and packed, the gather through the backend (RCCL: a one-rank communicator), the untile, the one-stream "
+                         "render / exchange hand-off and --check.  What a one-GPU box can execute of the N > 1 path; the line then "
+                         "carries no api / configs / cpu_baseline objects")
     return ap.parse_args()
 
 
@@ -153,6 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1 or args.force_dist  # the exchange leg of the path (a process group, gather, untile) is executed
     if world != args.gpus:
         # a line with the wrong n_gpus is worse than no line
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
@@ -173,8 +179,13 @@ def main():
                  "(rehearse on one GPU with --backend gloo --single-device)")
     dev_index = 0 if (world == 1 or args.single_device) else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:  # --force-dist without a launcher: this process is the one rank
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -182,7 +193,7 @@ def main():
         if dist.get_world_size() != args.gpus:
             sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     dev = torch.device("cuda", dev_index)
-    config = args.config or (2 if world == 1 else 3)
+    config = args.config or (3 if dist_on else 2)
     replica = config == 5
     W = args.width or (CONFIG5_RES if replica else WIDTH)
     H = args.height or (CONFIG5_RES if replica else HEIGHT)
@@ -191,7 +202,7 @@ def main():
     # `depth` steps are in flight: one context + stream + output buffers per slot, so the tail of one
     # batch (a few long-lived tiles) overlaps the head of the next.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
-    depth = args.frames_in_flight or (DEFAULT_DEPTH if world == 1 else 2)
+    depth = args.frames_in_flight or (2 if dist_on else DEFAULT_DEPTH)
     scaling = args.scaling or ("strong" if replica else "weak")
     if replica:
         # rank r takes the contiguous block r*V .. of the step's requests: whole frames, shard_count 1
@@ -210,13 +221,16 @@ def main():
         shard_index, shard_count = rank, world
     opts = nh.default_options()
     opts.shard_index, opts.shard_count = shard_index, shard_count
+    # one rank alone renders row-major frames; with --force-dist its single shard takes the shard layout, as every rank's does at N > 1
+    tiled = not replica and (shard_count > 1 or dist_on)
+    opts.tile_major = int(tiled and shard_count == 1)
     tps = nh.tiles_per_shard(W, H, shard_count)
     cam = syn.default_camera(W, H)
     if replica:  # 64 distinct cameras around the object (three elevations)
         poses = [syn.orbit_pose(360.0 * i / CONFIG5_REQUESTS, (10.0, 30.0, 50.0)[i % 3]) for i in range(CONFIG5_REQUESTS)]
     else:
         poses = [syn.orbit_pose(45.0 * i, 30.0) for i in range(8)]
-    n_px = tps * 64 if shard_count > 1 else W * H
+    n_px = tps * 64 if tiled else W * H
 
     def step_poses(i):
         """(global pose indices of step i rendered by THIS rank)"""
@@ -232,8 +246,8 @@ def main():
     # waits for render i's event and render i + 1 for render i on its stream -- both start when render i ends, RCCL's few
     # workgroups take their slots and the render the rest.  With a stream per slot render i + 1 is resident before render i
     # has ended, and the exchange of step i waits for the next gap (scripts/overlap_test.py: 17.2 against 14.2 ms per step).
-    render_stream = torch.cuda.Stream(dev) if world > 1 else None
-    packed = world > 1 and args.gather_format == "rgbd8"
+    render_stream = torch.cuda.Stream(dev) if dist_on else None
+    packed = dist_on and args.gather_format == "rgbd8"
     slots = []
     for _ in range(depth):
         sl = Slot()
@@ -254,7 +268,7 @@ def main():
             sl.ctx.bind_output(sl.rgba.data_ptr(), sl.depth.data_ptr())
         sl.rendered = torch.cuda.Event()
         sl.gathered = torch.cuda.Event()
-        if world > 1:
+        if dist_on:
             is_sink = rank == 0 or args.gather_root == "rotate"  # this rank assembles (some of) the steps' frames
             if packed:  # 4-byte pixels: one int32 "channel"
                 sl.all = torch.empty((world, V, n_px), dtype=torch.int32, device=dev) if is_sink else None
@@ -276,7 +290,7 @@ def main():
 
     def step(i, timed=False):
         sl = slots[i % depth]
-        if world > 1:
+        if dist_on:
             sl.stream.wait_event(sl.gathered)  # the slot's previous shard has left the building
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -285,7 +299,7 @@ def main():
         if timed:
             e1.record(sl.stream)
             launch_events.append((e0, e1))
-        if world > 1:
+        if dist_on:
             # the one exchange of the path: every rank's shard / frames -> the step's sink rank (direct xGMI sends: xGMI
             # is point-to-point, so a gather moves 1/N-th of what an all-gather would), untile there
             sl.rendered.record(sl.stream)
@@ -303,11 +317,11 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:
+    if dist_on:
         # RCCL sets up its peer-to-peer channels on the first send/recv of every pair: open them now, so that the
         # timed region never pays for connection set-up whatever --warmup is
         with torch.cuda.stream(comm):
@@ -322,7 +336,7 @@ def main():
         step(i, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -366,7 +380,7 @@ def main():
         rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:  # noqa: BLE001  (a build without the nccl bindings)
         rccl_version = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([local_samples, local_evals, local_composited], device=dev, dtype=torch.int64)
         dist.all_reduce(t)
         total_samples, total_evals, total_composited = (int(v) for v in t.tolist())
@@ -382,7 +396,7 @@ def main():
         total_samples, total_evals, total_composited = local_samples, local_evals, local_composited
 
     check = None
-    if (args.check if args.check is not None else world > 1) and world > 1:
+    if (args.check if args.check is not None else dist_on) and dist_on:
         # the gathered (+ untiled) frames of a step must equal unsharded single renders of the same poses
         torch.cuda.synchronize(dev)
         step(0)
@@ -411,7 +425,7 @@ def main():
         dist.barrier()
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -428,7 +442,7 @@ def main():
     # PMC passes cannot run inside this process: the counters of the same command are read from the committed
     # summary -- only when it was collected for exactly this launch shape AND these kernel sources
     pmc = None
-    if world == 1 and not replica and (W, H) == (WIDTH, HEIGHT) and V == DEFAULT_VIEWS and PMC_FILE.exists():
+    if not dist_on and not replica and (W, H) == (WIDTH, HEIGHT) and V == DEFAULT_VIEWS and PMC_FILE.exists():
         cand = json.loads(PMC_FILE.read_text())
         if cand.get("views_per_launch") == V and cand.get("kernel_source_sha16") == kernel_source_sha16():
             pmc = cand
@@ -468,10 +482,12 @@ def main():
                    "step": (f"{V_step} frames per step, each tile-sharded over the {world} rank(s)" if not replica else
                             f"{V_step} requests per step, {V} whole frames per rank"),
                    "views_per_rank_and_step": V, "steps_in_flight": depth,
-                   "gather": (args.gather_format if world > 1 else None),
-                   "gather_root": (("step % N" if args.gather_root == "rotate" else "rank 0") if world > 1 else None)},
-        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
-                        "backend": (dist.get_backend() if world > 1 else None),
+                   "gather": (args.gather_format if dist_on else None),
+                   "gather_root": (("step % N" if args.gather_root == "rotate" else "rank 0") if dist_on else None)},
+        "distributed": {"world_size": (dist.get_world_size() if dist_on else 1),
+                        "backend": (dist.get_backend() if dist_on else None),
+                        # True: ONE rank running the whole exchange leg (--force-dist): what a one-GPU box can execute of N > 1
+                        "forced_single_rank": bool(dist_on and world == 1),
                         "launcher": ("bench.py self-launch" if os.environ.get("NRF_BENCH_SELF_LAUNCHED") else
                                      ("external" if world > 1 else None)),
                         "devices": devices,
@@ -524,7 +540,7 @@ def main():
         out["sharded_frame_equals_unsharded"] = check
     if world == 1:
         out["config"]["samples_per_frame"] = int(mean_samples_launch / V)
-        if not replica and not args.no_extras:
+        if not replica and not args.no_extras and not dist_on:
             out["api"] = api_bench(nh, torch, dev, desc, cam, poses, W, H)
             out["fast_interp"] = fast_interp_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V, ms_per_step / V_step)
             out["march_fast_forward"] = march_ff_bench(nh, torch, dev, desc, cams_step, [poses[j] for j in step_poses(0)], W, H, V)
@@ -543,7 +559,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity"] = cpu_baseline(nh, dev, desc, cam, poses[0], W, H, args.cpu_sample_div)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 4
+#define NRF_ABI_VERSION 5
 #define NRF_MAX_VIEWS 128 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -160,6 +160,10 @@ typedef struct nrf_options {
    * kernel is co-limited by its gather path (DESIGN.md "What binds the kernel").  Honoured by the register-resident instance of the fused kernel in its persistent form and by
    * nrf_encode_grid; other instances render with the exact arithmetic.                                              */
   int32_t fast_interp; /* 0 */
+  /* 1: a single shard (shard_count == 1) is rendered in the shard layout as well -- tile-major [n_tiles][64], what
+   * nrf_untile* takes -- instead of the row-major frame.  What a one-rank rehearsal of the multi-GPU exchange renders
+   * (bench.py --force-dist: render -> RCCL gather -> untile with shard_count 1); host frames and nrf_read_* need 0.  */
+  int32_t tile_major;  /* 0 */
 } nrf_options;
 
 /* One rendered frame (device memory owned by the context, valid until the
@@ -173,8 +177,9 @@ typedef struct nrf_frame {
   void* rgba;           /* device float [n_px][4]; rgb after background blend
                            (render_utils.h:259-261), a = weight_sum           */
   void* depth;          /* device float [n_px] (render_utils.h:262-263)       */
-  /* layout: shard_count==1 -> row-major [H][W]; otherwise tile-major
-   * [n_tiles][64] in ascending tile id, see nrf_untile.                      */
+  /* layout: shard_count==1 (and nrf_options.tile_major == 0) -> row-major
+   * [H][W]; otherwise tile-major [n_tiles][64] in ascending tile id, see
+   * nrf_untile.                                                              */
   int32_t tile_major;
   /* batched renders (nrf_render_views): view i lives at rgba + i*view_stride_px
    * pixels (depth likewise); n_views == 1 for nrf_render                      */
@@ -358,6 +363,17 @@ int nrf_get_stats(nrf_context* ctx, nrf_stats* s);
 typedef struct nrf_group nrf_group;
 int nrf_group_create(int n_devices, const int* devices, nrf_group** out);
 int nrf_group_destroy(nrf_group* grp);
+/* The transport of the one exchange step (the reference: cudaMemcpyAsync D2H of every GPU's planes into one host buffer,
+ * nerf_render.cu:345-359).  NRF_GATHER_PEER_COPY (default): hipMemcpyPeerAsync per member.  NRF_GATHER_RCCL: one RCCL
+ * communicator per member (ncclCommInitAll) and one group of ncclSend / ncclRecv to devices[0] per call -- a direct gather
+ * over the point-to-point xGMI links; needs distinct devices (NRF_E_UNSUPPORTED otherwise) and librccl, which is opened
+ * on this call (a process that never asks never loads it).  In this mode a ONE-member group runs the whole exchange too
+ * (tile-major shard, send to self, untile).  Frames are the same bits either way.  May be called at any time between
+ * renders; the environment variable NRF_GROUP_GATHER=rccl|peer sets it at nrf_group_create.                          */
+enum { NRF_GATHER_PEER_COPY = 0, NRF_GATHER_RCCL = 1 };
+int nrf_group_set_gather(nrf_group* grp, int mode);
+/* rccl_version: ncclGetVersion() of the opened library in RCCL mode (e.g. 22703), else 0 */
+int nrf_group_get_gather(const nrf_group* grp, int* mode, int* rccl_version);
 int nrf_group_size(const nrf_group* grp);
 /* member i's context (owned by the group): stage entry points, per-device statistics */
 nrf_context* nrf_group_member(nrf_group* grp, int index);

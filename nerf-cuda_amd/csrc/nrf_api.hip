@@ -398,9 +398,12 @@ int local_tiles(int W, int H, int shard_index, int shard_count) {
   return 4 * ((total - shard_index + shard_count - 1) / shard_count);
 }
 
+// the shard layout (tile-major [n_tiles][64]) instead of the row-major frame: every multi-shard render, and a single shard on request
+bool tiled_layout(const nrf_context* c) { return c->opt.shard_count > 1 || c->opt.tile_major != 0; }
+
 int alloc_frame(nrf_context* c) {
   if (c->W <= 0 || c->H <= 0) return NRF_OK;
-  const bool tiled = c->opt.shard_count > 1;
+  const bool tiled = tiled_layout(c);
   c->n_local_tiles = local_tiles(c->W, c->H, c->opt.shard_index, c->opt.shard_count);
   int tps = 0;
   nrf_tiles_per_shard(c->W, c->H, c->opt.shard_count, &tps);
@@ -430,7 +433,7 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.shard_index = c->opt.shard_index;
   P.shard_count = c->opt.shard_count;
   P.n_local_tiles = c->n_local_tiles;
-  P.tile_major = c->opt.shard_count > 1;
+  P.tile_major = tiled_layout(c);
   P.bg_color = c->opt.bg_color;
   P.min_near = c->opt.min_near;
   P.dt_gamma = c->opt.dt_gamma;
@@ -737,6 +740,7 @@ void nrf_default_options(nrf_options* o) {
   o->shard_index = 0;
   o->shard_count = 1;
   o->fast_interp = 0;
+  o->tile_major = 0;
 }
 
 int nrf_level_table_compute(const nrf_model_desc* d, nrf_level_table* t) {
@@ -1345,7 +1349,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
   const bool bound = c->bound_rgba || c->bound_rgbd8 || c->bound_rgb8;
   if (!bound && n_views > c->max_views)
     return fail(NRF_E_STATE, "more views than the context's buffers hold: call nrf_set_max_views or nrf_bind_output");
-  if (c->bound_rgb8 && c->opt.shard_count != 1)
+  if (c->bound_rgb8 && tiled_layout(c))
     return fail(NRF_E_STATE, "8-bit planar output (nrf_bind_output_u8) needs a single-shard (row-major) frame");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   void* rgba = c->bound_rgba ? c->bound_rgba : c->d_rgba;
@@ -1372,7 +1376,7 @@ int nrf_render_views(nrf_context* c, int n_views, const float* cams, const float
     out->n_tiles = c->n_local_tiles;
     out->rgba = floats ? rgba : nullptr;
     out->depth = floats ? depth : nullptr;
-    out->tile_major = c->opt.shard_count > 1;
+    out->tile_major = tiled_layout(c);
     out->n_views = n_views;
     out->view_stride_px = (int64_t)c->n_out_px;
   }
@@ -1537,7 +1541,7 @@ int nrf_submit_host_u8(nrf_context* c, int n_views, const float* cams, const flo
   int rc = check_renderable(c, cams, poses, n_views);
   if (rc) return rc;
   if (!ticket) return fail(NRF_E_INVALID, "null argument");
-  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "host frames need a single-shard (row-major) frame");
+  if (tiled_layout(c)) return fail(NRF_E_STATE, "host frames need a single-shard (row-major) frame");
   const int si = c->hs_next;
   nrf_context::HostSlot& h = c->hs[si];
   // the slot's previous frames are overwritten (nerfhip.h: valid until the second next submit); a call nobody waited for
@@ -1818,7 +1822,7 @@ int nrf_read_view_f32(nrf_context* c, int view, float* rgba, float* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
   if (!c->last_rgba) return fail(NRF_E_STATE, "the last render went to a packed 8-bit buffer (nrf_bind_output_rgbd8): it is the caller's to read");
-  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_f32 needs a single-shard (row-major) frame");
+  if (tiled_layout(c)) return fail(NRF_E_STATE, "nrf_read_f32 needs a single-shard (row-major) frame");
   if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);
   if (rc) return rc;
@@ -1838,7 +1842,7 @@ int nrf_read_shard_f32(nrf_context* c, float* rgba, float* depth) {
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->last_stream));
-  const size_t n = c->opt.shard_count > 1 ? (size_t)c->n_local_tiles * 64 : (size_t)c->W * c->H;
+  const size_t n = tiled_layout(c) ? (size_t)c->n_local_tiles * 64 : (size_t)c->W * c->H;
   if (rgba) HIP_TRY(hipMemcpy(rgba, c->last_rgba, n * 16, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(hipMemcpy(depth, c->last_depth, n * 4, hipMemcpyDeviceToHost));
   return NRF_OK;
@@ -1848,7 +1852,7 @@ int nrf_read_view_u8(nrf_context* c, int view, uint8_t* rgb, uint8_t* depth) {
   if (!c) return fail(NRF_E_INVALID, "null context");
   if (!c->rendered) return fail(NRF_E_STATE, "nothing rendered yet");
   if (!c->last_rgba) return fail(NRF_E_STATE, "the last render went to a packed 8-bit buffer (nrf_bind_output_rgbd8): it is the caller's to read");
-  if (c->opt.shard_count != 1) return fail(NRF_E_STATE, "nrf_read_u8 needs a single-shard (row-major) frame");
+  if (tiled_layout(c)) return fail(NRF_E_STATE, "nrf_read_u8 needs a single-shard (row-major) frame");
   if (view < 0 || view >= c->last_views) return fail(NRF_E_INVALID, "view index out of range");
   int rc = set_device(c);
   if (rc) return rc;

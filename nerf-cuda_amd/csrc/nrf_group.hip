@@ -3,19 +3,32 @@
 // The reference renders on NGPU devices from one process: a std::thread per device, pixel-interleaved
 // shards, a D2H copy of every shard and a single-threaded de-interleave loop on the host
 // (R/src/nerf_render.cu:252-362).  Here every member context renders its strips of every view of the
-// batch on its own stream, copies the tile-major shard device-to-device to the first member (xGMI
-// peer-to-peer: point-to-point links, so the n-1 copies into device 0 run on n-1 different links)
-// and the first member untiles all views in one launch.  No host thread, no host copy, no RCCL
-// (RCCL is the exchange of the one-process-per-GPU form, bench.py).
+// batch on its own stream, ships the tile-major shard device-to-device to the first member and the
+// first member untiles all views in one launch.  No host thread, no host copy.  Two transports for
+// the one exchange step (nrf_group_set_gather / NRF_GROUP_GATHER):
+//   NRF_GATHER_PEER_COPY  hipMemcpyPeerAsync on the member's stream (xGMI peer-to-peer: point-to-point links, so the
+//                         n-1 copies into device 0 run on n-1 different links), an event per member, devices[0] waits
+//   NRF_GATHER_RCCL       one communicator per member (ncclCommInitAll: one process, n devices) and ONE group of
+//                         ncclSend (member i, on its stream, behind its render) / ncclRecv (devices[0], on its stream,
+//                         ahead of the untile) per call: a direct gather -- xGMI is point-to-point, a ring all-gather
+//                         would move n times the bytes over every link (BASELINE north_star "RCCL over xGMI
+//                         only for the final gather").  librccl is opened with dlopen on first use: a process that
+//                         never asks for it never loads it.  A one-member group runs the whole exchange in this mode
+//                         (tile-major shard, send-to-self, untile): what a one-GPU box can execute of it.
 // Host frames (nrf_group_submit_host_u8: what ngp::NerfRender::render_frame returns): the members render their shards
 // as PACKED 8-bit pixels (4 B/px on the links instead of 20), the first member untiles them straight into the planar
 // layout of the reference's Image, and one asynchronous copy per plane brings the batch into pinned host memory; two
 // slots, so that this copy overlaps the next call's render.
-// Built only on the public ABI plus HIP peer copies.
+// Built only on the public ABI plus HIP peer copies / RCCL point-to-point calls.
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is opened with dlopen (rccl_api)
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -38,11 +51,70 @@ int gfail(int code, const std::string& msg) {
     int _rc = (expr);       \
     if (_rc != NRF_OK) return _rc; \
   } while (0)
+
+// librccl's entry points (the point-to-point subset a direct gather needs), resolved once per process
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+const RcclApi& rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.so) break;
+    }
+    if (!api.so) {
+      const char* e = dlerror();
+      api.error = std::string("librccl could not be opened: ") + (e ? e : "?");
+      return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) {
+      void* p = dlsym(api.so, n);
+      if (!p) {
+        ok = false;
+        api.error = std::string("librccl lacks ") + n;
+      }
+      return p;
+    };
+    api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+      dlclose(api.so);
+      api.so = nullptr;
+    }
+  });
+  return api;
+}
+#define GNCCL(expr)                                                                                         \
+  do {                                                                                                      \
+    ncclResult_t _r = (expr);                                                                               \
+    if (_r != ncclSuccess) return gfail(NRF_E_HIP, std::string(#expr) + ": " + rccl_api().GetErrorString(_r)); \
+  } while (0)
 }  // namespace
 
 struct nrf_group {
   std::vector<int> devices;
   std::vector<nrf_context*> ctx;
+  int gather = NRF_GATHER_PEER_COPY;
+  std::vector<ncclComm_t> comm;     // NRF_GATHER_RCCL: member i's communicator (rank i of n)
+  int rccl_version = 0;
   std::vector<hipStream_t> stream;  // one per member, on its device
   std::vector<hipEvent_t> done;     // shard of member i has arrived on devices[0]
   nrf_options opt{};
@@ -68,6 +140,55 @@ struct nrf_group {
 };
 
 namespace {
+// does a call go through the exchange step (shards -> devices[0] -> untile)?  A lone member renders row-major frames itself --
+// unless the group was asked for the RCCL transport: then even one member runs the whole exchange
+bool exchanges(const nrf_group* g) { return g->ctx.size() > 1 || g->gather == NRF_GATHER_RCCL; }
+
+// The exchange step: for every segment s (a plane of the batch) member i's `bytes[s]` at src[s][i] (on its device, written by
+// work queued on its stream) go to dst[s] + i * bytes[s] on devices[0]; when this returns, work queued on stream[0]
+// afterwards sees all of it.
+struct Segment {
+  std::vector<const void*> src;  // per member
+  char* dst;
+  size_t bytes;
+};
+int ship_to_first(nrf_group* g, const std::vector<Segment>& segs) {
+  const size_t n = g->ctx.size();
+  if (g->gather == NRF_GATHER_RCCL) {
+    const RcclApi& R = rccl_api();
+    GNCCL(R.GroupStart());
+    for (size_t i = 0; i < n; ++i)
+      for (const Segment& sg : segs) {
+        ncclResult_t r = R.Send(sg.src[i], sg.bytes, ncclUint8, 0, g->comm[i], g->stream[i]);
+        if (r == ncclSuccess) r = R.Recv(sg.dst + i * sg.bytes, sg.bytes, ncclUint8, (int)i, g->comm[0], g->stream[0]);
+        if (r != ncclSuccess) {
+          (void)R.GroupEnd();
+          return gfail(NRF_E_HIP, std::string("ncclSend / ncclRecv: ") + R.GetErrorString(r));
+        }
+      }
+    GNCCL(R.GroupEnd());
+    return NRF_OK;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    GHIP(hipSetDevice(g->devices[i]));
+    for (const Segment& sg : segs)
+      GHIP(hipMemcpyPeerAsync(sg.dst + i * sg.bytes, g->devices[0], sg.src[i], g->devices[i], sg.bytes, g->stream[i]));
+    GHIP(hipEventRecord(g->done[i], g->stream[i]));
+  }
+  GHIP(hipSetDevice(g->devices[0]));
+  for (size_t i = 1; i < n; ++i) GHIP(hipStreamWaitEvent(g->stream[0], g->done[i], 0));
+  return NRF_OK;
+}
+
+void destroy_comms(nrf_group* g) {
+  for (size_t i = 0; i < g->comm.size(); ++i)
+    if (g->comm[i]) {
+      (void)hipSetDevice(g->devices[i]);
+      (void)rccl_api().CommDestroy(g->comm[i]);
+    }
+  g->comm.clear();
+}
+
 void free_buffers(nrf_group* g) {
   if (g->devices.empty()) return;
   (void)hipSetDevice(g->devices[0]);
@@ -98,11 +219,11 @@ void free_host_slots(nrf_group* g) {
 }
 
 int ensure_buffers(nrf_group* g, int n_views) {
-  if (n_views <= g->max_views && (g->frame_rgba || g->ctx.size() == 1)) return NRF_OK;
+  if (n_views <= g->max_views && (g->frame_rgba || !exchanges(g))) return NRF_OK;
   const size_t n = g->ctx.size();
   for (nrf_context* c : g->ctx) GTRY(nrf_set_max_views(c, n_views));
   g->max_views = n_views;
-  if (n == 1) return NRF_OK;  // a single member renders row-major frames itself
+  if (!exchanges(g)) return NRF_OK;  // a single member renders row-major frames itself
   free_buffers(g);
   GHIP(hipSetDevice(g->devices[0]));
   const size_t shard_px = (size_t)g->tps * 64, frame_px = (size_t)g->W * g->H;
@@ -160,7 +281,58 @@ int nrf_group_create(int n_devices, const int* devices, nrf_group** out) {
     nrf_group_destroy(g);
     return gfail(NRF_E_HIP, "nrf_group_create: stream / event creation failed");
   }
+  // NRF_GROUP_GATHER=rccl: the RCCL transport for callers that only know the reference's API (NerfRender(n), render_server's
+  // tile mode); anything else than "rccl" / "peer" is an error rather than a silent default
+  if (const char* e = std::getenv("NRF_GROUP_GATHER")) {
+    const std::string v(e);
+    if (v != "rccl" && v != "peer" && !v.empty()) {
+      nrf_group_destroy(g);
+      return gfail(NRF_E_INVALID, "NRF_GROUP_GATHER must be rccl or peer");
+    }
+    if (v == "rccl") {
+      const int rc = nrf_group_set_gather(g, NRF_GATHER_RCCL);
+      if (rc != NRF_OK) {
+        nrf_group_destroy(g);
+        return rc;
+      }
+    }
+  }
   *out = g;
+  return NRF_OK;
+}
+
+int nrf_group_set_gather(nrf_group* g, int mode) {
+  if (!g || (mode != NRF_GATHER_PEER_COPY && mode != NRF_GATHER_RCCL)) return gfail(NRF_E_INVALID, "nrf_group_set_gather: bad argument");
+  if (mode == g->gather) return NRF_OK;
+  const size_t n = g->ctx.size();
+  for (size_t i = 0; i < n; ++i) {  // nothing of the other transport is left in flight
+    GHIP(hipSetDevice(g->devices[i]));
+    GHIP(hipStreamSynchronize(g->stream[i]));
+  }
+  if (mode == NRF_GATHER_RCCL) {
+    const RcclApi& R = rccl_api();
+    if (!R.so) return gfail(NRF_E_UNSUPPORTED, "nrf_group_set_gather: " + R.error);
+    if (std::set<int>(g->devices.begin(), g->devices.end()).size() != n)
+      return gfail(NRF_E_UNSUPPORTED, "nrf_group_set_gather: RCCL needs one rank per DISTINCT device (a group that lists a device "
+                                      "twice is a rehearsal: it keeps the peer copies)");
+    std::vector<ncclComm_t> comm(n, nullptr);
+    GNCCL(R.CommInitAll(comm.data(), (int)n, g->devices.data()));
+    g->comm = comm;
+    (void)R.GetVersion(&g->rccl_version);
+  } else {
+    destroy_comms(g);
+  }
+  g->gather = mode;
+  // a lone member changes layout with the transport (row-major <-> its shard): options and buffers follow
+  GTRY(nrf_group_set_options(g, &g->opt));
+  if (g->W > 0) GTRY(nrf_group_set_resolution(g, g->W, g->H));
+  return NRF_OK;
+}
+
+int nrf_group_get_gather(const nrf_group* g, int* mode, int* rccl_version) {
+  if (!g) return gfail(NRF_E_INVALID, "null argument");
+  if (mode) *mode = g->gather;
+  if (rccl_version) *rccl_version = g->gather == NRF_GATHER_RCCL ? g->rccl_version : 0;
   return NRF_OK;
 }
 
@@ -172,6 +344,7 @@ int nrf_group_destroy(nrf_group* g) {
   }
   free_buffers(g);
   free_host_slots(g);
+  destroy_comms(g);
   if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
   for (auto& h : g->hs) {
     if (h.untiled) (void)hipEventDestroy(h.untiled);
@@ -208,6 +381,7 @@ int nrf_group_set_options(nrf_group* g, const nrf_options* o) {
     nrf_options m = *o;
     m.shard_index = (int)i;  // the partition is the group's business
     m.shard_count = (int)g->ctx.size();
+    m.tile_major = exchanges(g) ? 1 : 0;  // (what a lone member of an RCCL group needs said; implied for two and more)
     GTRY(nrf_set_options(g->ctx[i], &m));
   }
   return NRF_OK;
@@ -232,24 +406,23 @@ int nrf_group_render_views(nrf_group* g, int n_views, const float* cams, const f
   GTRY(ensure_buffers(g, n_views));
   const size_t n = g->ctx.size();
   g->last_views = n_views;
-  if (n == 1) {
+  if (!exchanges(g)) {
     GTRY(nrf_render_views(g->ctx[0], n_views, cams, poses, (void*)g->stream[0], out));
     GHIP(hipStreamSynchronize(g->stream[0]));
     return NRF_OK;
   }
   const size_t shard_px = (size_t)g->tps * 64;
-  for (size_t i = 0; i < n; ++i) {  // every device renders and ships its shards on its own stream
+  std::vector<Segment> segs(2);
+  segs[0] = {std::vector<const void*>(n), (char*)g->gathered_rgba, (size_t)n_views * shard_px * 16};
+  segs[1] = {std::vector<const void*>(n), (char*)g->gathered_depth, (size_t)n_views * shard_px * 4};
+  for (size_t i = 0; i < n; ++i) {  // every device renders its shards on its own stream
     nrf_frame f;
     GTRY(nrf_render_views(g->ctx[i], n_views, cams, poses, (void*)g->stream[i], &f));
-    GHIP(hipSetDevice(g->devices[i]));
-    char* dst_rgba = (char*)g->gathered_rgba + i * n_views * shard_px * 16;
-    char* dst_depth = (char*)g->gathered_depth + i * n_views * shard_px * 4;
-    GHIP(hipMemcpyPeerAsync(dst_rgba, g->devices[0], f.rgba, g->devices[i], (size_t)n_views * shard_px * 16, g->stream[i]));
-    GHIP(hipMemcpyPeerAsync(dst_depth, g->devices[0], f.depth, g->devices[i], (size_t)n_views * shard_px * 4, g->stream[i]));
-    GHIP(hipEventRecord(g->done[i], g->stream[i]));
+    segs[0].src[i] = f.rgba;
+    segs[1].src[i] = f.depth;
   }
+  GTRY(ship_to_first(g, segs));
   GHIP(hipSetDevice(g->devices[0]));
-  for (size_t i = 1; i < n; ++i) GHIP(hipStreamWaitEvent(g->stream[0], g->done[i], 0));
   GTRY(nrf_untile_views(g->ctx[0], g->gathered_rgba, (int)n, g->tps, 4, n_views, g->frame_rgba, (void*)g->stream[0]));
   GTRY(nrf_untile_views(g->ctx[0], g->gathered_depth, (int)n, g->tps, 1, n_views, g->frame_depth, (void*)g->stream[0]));
   GHIP(hipStreamSynchronize(g->stream[0]));
@@ -268,7 +441,7 @@ int nrf_group_render_views(nrf_group* g, int n_views, const float* cams, const f
 
 int nrf_group_read_view_f32(nrf_group* g, int view, float* rgba, float* depth) {
   if (!g || view < 0 || view >= g->last_views) return gfail(NRF_E_INVALID, "view index out of range");
-  if (g->ctx.size() == 1) return nrf_read_view_f32(g->ctx[0], view, rgba, depth);
+  if (!exchanges(g)) return nrf_read_view_f32(g->ctx[0], view, rgba, depth);
   const size_t px = (size_t)g->W * g->H;
   GHIP(hipSetDevice(g->devices[0]));
   if (rgba) GHIP(hipMemcpy(rgba, (const char*)g->frame_rgba + (size_t)view * px * 16, px * 16, hipMemcpyDeviceToHost));
@@ -278,7 +451,7 @@ int nrf_group_read_view_f32(nrf_group* g, int view, float* rgba, float* depth) {
 
 int nrf_group_read_view_u8(nrf_group* g, int view, uint8_t* rgb, uint8_t* depth) {
   if (!g || view < 0 || view >= g->last_views) return gfail(NRF_E_INVALID, "view index out of range");
-  if (g->ctx.size() == 1) return nrf_read_view_u8(g->ctx[0], view, rgb, depth);
+  if (!exchanges(g)) return nrf_read_view_u8(g->ctx[0], view, rgb, depth);
   const size_t px = (size_t)g->W * g->H;
   GHIP(hipSetDevice(g->devices[0]));
   // quantised into the Image layout on the device (nerf_render.cu:352-359 is a host loop); the copies go to the caller's memory
@@ -300,7 +473,7 @@ namespace {
 int group_submit_impl(nrf_group* g, nrf_group::HostSlot& h, int n_views, const float* cams, const float* poses, int flags) {
   const size_t n = g->ctx.size();
   h.with_depth = !(flags & NRF_HOST_RGB_ONLY);
-  if (n == 1) {  // one member: its own host-frame path (region-of-interest rows only, no untile)
+  if (!exchanges(g)) {  // one member: its own host-frame path (region-of-interest rows only, no untile)
     h.single = true;
     const int rc = nrf_submit_host_u8(g->ctx[0], n_views, cams, poses, flags, &h.member_ticket);
     h.pending = rc == NRF_OK;
@@ -339,18 +512,17 @@ int group_submit_impl(nrf_group* g, nrf_group::HostSlot& h, int n_views, const f
   }
   GHIP(hipSetDevice(g->devices[0]));
   GHIP(hipEventRecord(h.t0, g->stream[0]));
-  for (size_t i = 0; i < n; ++i) {  // every member renders its packed shard and ships it on its own stream
+  std::vector<Segment> segs(1);
+  segs[0] = {std::vector<const void*>(n), (char*)h.gathered, (size_t)n_views * shard_px * 4};
+  for (size_t i = 0; i < n; ++i) {  // every member renders its packed shard on its own stream
     GTRY(nrf_bind_output_rgbd8(g->ctx[i], g->shard8[i]));
     const int rc = nrf_render_views(g->ctx[i], n_views, cams, poses, (void*)g->stream[i], nullptr);
     (void)nrf_bind_output_rgbd8(g->ctx[i], nullptr);
     if (rc != NRF_OK) return rc;
-    GHIP(hipSetDevice(g->devices[i]));
-    GHIP(hipMemcpyPeerAsync((char*)h.gathered + i * n_views * shard_px * 4, g->devices[0], g->shard8[i], g->devices[i],
-                            (size_t)n_views * shard_px * 4, g->stream[i]));
-    GHIP(hipEventRecord(g->done[i], g->stream[i]));
+    segs[0].src[i] = g->shard8[i];
   }
+  GTRY(ship_to_first(g, segs));
   GHIP(hipSetDevice(g->devices[0]));
-  for (size_t i = 1; i < n; ++i) GHIP(hipStreamWaitEvent(g->stream[0], g->done[i], 0));
   uint8_t* d_rgb = (uint8_t*)h.d_buf;
   uint8_t* d_depth = d_rgb + (size_t)h.views * frame_px * 3;
   GTRY(nrf_untile_views_u8(g->ctx[0], h.gathered, (int)n, g->tps, n_views, d_rgb, d_depth, (void*)g->stream[0]));
@@ -383,7 +555,7 @@ int nrf_group_submit_host_u8(nrf_group* g, int n_views, const float* cams, const
     for (size_t i = 0; i < g->ctx.size(); ++i) {
       if (hipSetDevice(g->devices[i]) == hipSuccess && i < g->stream.size() && g->stream[i]) (void)hipStreamSynchronize(g->stream[i]);
     }
-    if (g->ctx.size() > 1 && hipSetDevice(g->devices[0]) == hipSuccess && g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    if (exchanges(g) && hipSetDevice(g->devices[0]) == hipSuccess && g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
     return rc;
   }
   h.n_views = n_views;

@@ -23,7 +23,8 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
-NRF_ABI_VERSION = 4
+NRF_ABI_VERSION = 5
+GATHER_PEER_COPY, GATHER_RCCL = 0, 1  # nrf_group_set_gather
 NRF_MAX_VIEWS = 128
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
 
@@ -88,6 +89,7 @@ class Options(C.Structure):
         ("shard_index", C.c_int32),
         ("shard_count", C.c_int32),
         ("fast_interp", C.c_int32),
+        ("tile_major", C.c_int32),
     ]
 
 
@@ -203,6 +205,8 @@ _SIGS = {
     "nrf_group_read_view_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_group_read_view_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "nrf_group_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
+    "nrf_group_get_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nrf_untile_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_tiles_per_shard": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "nrf_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -757,6 +761,17 @@ class NerfGroup:
 
     def load_model(self, desc):
         _check(self.lib.nrf_group_load_model(self.h, C.byref(desc)))
+
+    def set_gather(self, mode: int):
+        """The transport of the exchange step: GATHER_PEER_COPY (hipMemcpyPeerAsync) or GATHER_RCCL (ncclSend / ncclRecv to
+        devices[0]; a one-member group then runs the whole exchange too)."""
+        _check(self.lib.nrf_group_set_gather(self.h, int(mode)))
+
+    def gather(self):
+        """(mode, RCCL version code or 0)"""
+        m, v = C.c_int(), C.c_int()
+        _check(self.lib.nrf_group_get_gather(self.h, C.byref(m), C.byref(v)))
+        return int(m.value), int(v.value)
 
     def set_options(self, opts):
         _check(self.lib.nrf_group_set_options(self.h, C.byref(opts)))

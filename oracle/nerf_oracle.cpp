@@ -19,6 +19,9 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#ifdef __F16C__
+#include <immintrin.h>  // vcvtps2ph / vcvtph2ps: the same RNE bits as the software conversions below (tests/test_oracle_kat.py)
+#endif
 
 namespace {
 
@@ -29,8 +32,10 @@ int fail(int code, const std::string& msg) {
 }
 
 // ---------------------------------------------------------------- fp16 ----
-// IEEE binary16 <-> binary32, round-to-nearest-even, subnormals kept.
-inline uint16_t f2h(float f) {
+// IEEE binary16 <-> binary32, round-to-nearest-even, subnormals kept.  The software forms are the definition (and what a
+// build without F16C runs); with -mf16c (oracle/Makefile, when the build host has it) f2h / h2f are one instruction each --
+// the CPU baseline then measures the path, not a software-float emulator.
+inline uint16_t f2h_soft(float f) {
   uint32_t x;
   std::memcpy(&x, &f, 4);
   const uint32_t sign = (x >> 16) & 0x8000u;
@@ -62,7 +67,7 @@ inline uint16_t f2h(float f) {
   return (uint16_t)(sign | r);
 }
 
-inline float h2f(uint16_t h) {
+inline float h2f_soft(uint16_t h) {
   const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
   const uint32_t e = (h >> 10) & 0x1fu;
   const uint32_t m = h & 0x3ffu;
@@ -84,6 +89,68 @@ inline float h2f(uint16_t h) {
   std::memcpy(&f, &x, 4);
   return f;
 }
+
+#ifdef __F16C__
+inline uint16_t f2h(float f) { return (uint16_t)_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+#else
+inline uint16_t f2h(float f) { return f2h_soft(f); }
+inline float h2f(uint16_t h) { return h2f_soft(h); }
+#endif
+
+// The contraction switch (nrfo_set_contract): `a * b + c` with every operation rounded (the arithmetic contract shared with
+// the HIP path) or as ONE fused multiply-add, which is what nvcc makes of it by default (-fmad=true; R/CMakeLists.txt:71-79
+// sets no -fmad=false).  Rule applied at every site below: a product that feeds an add / subtract of the same expression
+// is fused; of two products in one sum the LEFT one is fused and the right one rounded first (LLVM's combine order:
+// fadd(fmul(a, b), z) -> fma(a, b, z) is tried before fadd(z, fmul(a, b))); a product whose value is cast in between
+// ((T)(weight * data), grid.h:260) is not.
+inline float mad(bool contract, float a, float b, float c) { return contract ? fmaf(a, b, c) : a * b + c; }
+
+// The same rule for whole formula tables (kernel_sh): a float that remembers being a product until it is used.  With
+// S = float a table is plain individually-rounded arithmetic; with S = Fx every `a*b + c`, `a*b - c`, `c + a*b`, `c - a*b`
+// becomes one fmaf.
+struct Fx;
+struct Prod {
+  float a, b;
+  float value() const { return a * b; }
+};
+struct Fx {
+  float v;
+  Fx() : v(0.0f) {}
+  Fx(float f) : v(f) {}
+  Fx(Prod p) : v(p.value()) {}
+};
+inline Prod operator*(Fx a, Fx b) { return {a.v, b.v}; }
+inline Prod operator*(float a, Fx b) { return {a, b.v}; }
+inline Prod operator*(Fx a, float b) { return {a.v, b}; }
+inline Prod operator*(Prod a, Fx b) { return {a.value(), b.v}; }
+inline Prod operator*(Prod a, float b) { return {a.value(), b}; }
+inline Prod operator*(Fx a, Prod b) { return {a.v, b.value()}; }
+inline Prod operator*(float a, Prod b) { return {a, b.value()}; }
+inline Prod operator*(Prod a, Prod b) { return {a.value(), b.value()}; }
+inline Fx operator+(Fx a, Fx b) { return a.v + b.v; }
+inline Fx operator-(Fx a, Fx b) { return a.v - b.v; }
+inline Fx operator+(float a, Fx b) { return a + b.v; }
+inline Fx operator-(float a, Fx b) { return a - b.v; }
+inline Fx operator+(Fx a, float b) { return a.v + b; }
+inline Fx operator-(Fx a, float b) { return a.v - b; }
+inline Fx operator-(Fx a) { return -a.v; }
+inline Fx operator+(Prod p, Fx c) { return fmaf(p.a, p.b, c.v); }
+inline Fx operator-(Prod p, Fx c) { return fmaf(p.a, p.b, -c.v); }
+inline Fx operator+(Prod p, float c) { return fmaf(p.a, p.b, c); }
+inline Fx operator-(Prod p, float c) { return fmaf(p.a, p.b, -c); }
+inline Fx operator+(Fx c, Prod p) { return fmaf(p.a, p.b, c.v); }
+inline Fx operator-(Fx c, Prod p) { return fmaf(-p.a, p.b, c.v); }
+inline Fx operator+(float c, Prod p) { return fmaf(p.a, p.b, c); }
+inline Fx operator-(float c, Prod p) { return fmaf(-p.a, p.b, c); }
+inline Fx operator+(Prod p, Prod q) { return fmaf(p.a, p.b, q.value()); }
+inline Fx operator-(Prod p, Prod q) { return fmaf(p.a, p.b, -q.value()); }
+struct ShOut {  // one coefficient of the table: takes whatever the formula's last operation produced
+  float v;
+  ShOut& operator=(float f) { v = f; return *this; }
+  ShOut& operator=(Fx f) { v = f.v; return *this; }
+  ShOut& operator=(Prod p) { v = p.value(); return *this; }
+};
 
 // fp16 addition: exact via fp32 (24 >= 2*11+2 bits, so double rounding is innocuous).
 inline uint16_t hadd(uint16_t a, uint16_t b) { return f2h(h2f(a) + h2f(b)); }
@@ -126,6 +193,8 @@ struct nrfo_model {
   std::vector<uint16_t> grid;                 // fp16 table
   std::vector<float> density_grid;
   uint32_t mlp_acc_block = 0;  // nrfo_set_mlp_accumulate: 0 = fp32 sums; n = fp16 accumulator updated every n products
+  bool contract = false;       // nrfo_set_contract: a * b + c as one fmaf wherever the reference's source has it in one expression
+  float scale_dev[16] = {};    // the level scale as the KERNEL computes it under contraction (grid.h:189): fmaf(exp2f(..), base, -1)
 };
 
 extern "C" {
@@ -133,6 +202,15 @@ extern "C" {
 const char* nrfo_last_error(void) { return g_err.c_str(); }
 uint16_t nrfo_f32_to_f16(float f) { return f2h(f); }
 float nrfo_f16_to_f32(uint16_t h) { return h2f(h); }
+uint16_t nrfo_f32_to_f16_soft(float f) { return f2h_soft(f); }
+float nrfo_f16_to_f32_soft(uint16_t h) { return h2f_soft(h); }
+const char* nrfo_fp16_backend(void) {
+#ifdef __F16C__
+  return "f16c";
+#else
+  return "software";
+#endif
+}
 int nrfo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -271,10 +349,17 @@ int nrfo_create(const nrf_model_desc* d, nrfo_model** out) {
     return fail(NRF_E_INVALID, "FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");
   if (d->density_n_output < 1 || d->density_n_output > 16)  // wider outputs go through CUTLASS in tcnn (out of scope)
     return fail(NRF_E_UNSUPPORTED, "oracle: density n_output_dims must be 1..16");
+#ifdef __F16C__
+  if (!__builtin_cpu_supports("f16c")) return fail(NRF_E_UNSUPPORTED, "this oracle was built with -mf16c and the CPU has no F16C: rebuild oracle/ here");
+#endif
   nrfo_model* m = new nrfo_model;
   m->d = *d;
   int rc = level_table(*d, m->lv);
   if (rc) { delete m; return rc; }
+  {
+    const float log2_pls = std::log2(d->per_level_scale);
+    for (uint32_t i = 0; i < d->n_levels; ++i) m->scale_dev[i] = fmaf(exp2f((float)i * log2_pls), (float)d->base_resolution, -1.0f);
+  }
   rc = dir_widths(*d, m->dir_raw, m->dir_width);
   if (rc) { delete m; return rc; }
   m->W = d->n_neurons;
@@ -335,6 +420,13 @@ int nrfo_set_mlp_accumulate(nrfo_model* m, int mode) {
   return NRF_OK;
 }
 
+// see `mad` above; the default (0) is the arithmetic contract shared with the HIP path
+int nrfo_set_contract(nrfo_model* m, int on) {
+  if (!m) return fail(NRF_E_INVALID, "null model");
+  m->contract = on != 0;
+  return NRF_OK;
+}
+
 // T/include/tiny-cuda-nn/encodings/grid.h:100-117
 uint32_t nrfo_grid_index(const nrfo_model* m, uint32_t level, uint32_t x, uint32_t y, uint32_t z) {
   const uint32_t hashmap_size = m->lv.offset[level + 1] - m->lv.offset[level];
@@ -358,12 +450,12 @@ namespace {
 void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
   const uint32_t L = m->d.n_levels, F = m->d.n_features_per_level;
   for (uint32_t level = 0; level < L; ++level) {
-    const float scale = m->lv.scale[level];
+    // (the table geometry -- resolution, offsets -- is host arithmetic either way, grid.h:899-931; the kernel recomputes `scale`)
+    const float scale = m->contract ? m->scale_dev[level] : m->lv.scale[level];
     float pos[3];
     uint32_t pg[3];
     for (int dim = 0; dim < 3; ++dim) {
-      float v = p01[dim] * scale;
-      v = v + 0.5f;
+      float v = mad(m->contract, p01[dim], scale, 0.5f);  // pos_fract, common_device.h:416: input * scale + 0.5f
       const int tmp = (int)floorf(v);
       pg[dim] = (uint32_t)tmp;
       float fr = v - (float)tmp;
@@ -405,10 +497,11 @@ void encode_grid_one(const nrfo_model* m, const float p01[3], uint16_t* out) {
 // kernel_sh's polynomial table, T/include/tiny-cuda-nn/encodings/spherical_harmonics.h:66-152 (degree <= 8): the
 // published real-SH formulae as that file states them, each evaluated in C++ operator order with every fp32
 // operation individually rounded.
-void sh_coefficients(uint32_t degree, float x, float y, float z, float* c) {
-  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-  const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
-  const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
+template <typename S>
+void sh_coefficients(uint32_t degree, S x, S y, S z, ShOut* c) {
+  const S xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  const S x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+  const S x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
   c[0] = 0.28209479177387814f;
   if (degree <= 1) return;
   c[1] = -0.48860251190291987f * y;
@@ -490,10 +583,11 @@ void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
   if (d.dir_encoding == NRF_DIR_SH) {
     uint16_t* o = out;
     for (uint32_t j = 0; j < pad; ++j) *o++ = f2h(1.0f);  // SH pads in FRONT (:57-64)
-    const float x = d01[0] * 2.f - 1.f, y = d01[1] * 2.f - 1.f, z = d01[2] * 2.f - 1.f;
-    float c[64];
-    sh_coefficients(d.sh_degree, x, y, z, c);
-    for (uint32_t j = 0; j < m->dir_raw; ++j) o[j] = f2h(c[j]);
+    const float x = d01[0] * 2.f - 1.f, y = d01[1] * 2.f - 1.f, z = d01[2] * 2.f - 1.f;  // (x 2: exact, fused or not)
+    ShOut c[64];
+    if (m->contract) sh_coefficients<Fx>(d.sh_degree, Fx(x), Fx(y), Fx(z), c);
+    else sh_coefficients<float>(d.sh_degree, x, y, z, c);
+    for (uint32_t j = 0; j < m->dir_raw; ++j) o[j] = f2h(c[j].v);
   } else if (d.dir_encoding == NRF_DIR_FREQUENCY) {
     const float PI = 3.14159265358979323846f;
     const uint32_t nf = d.n_frequencies;
@@ -502,7 +596,7 @@ void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
       const uint32_t log2_frequency = (j / 2) % nf;
       const float phase_shift = (float)(j % 2) * (PI / 2);
       const float x = scalbnf(d01[feat], (int)log2_frequency);
-      const float input = x * PI + phase_shift;
+      const float input = mad(m->contract, x, PI, phase_shift);  // frequency.h:88
       out[j] = f2h(sinf(input));  // reference uses __sinf (approximate); tolerance applies
     }
     for (uint32_t j = m->dir_raw; j < m->dir_width; ++j) out[j] = f2h(1.0f);  // trailing pad
@@ -584,10 +678,8 @@ void network_one(const nrfo_model* m, float density_scale, const float xyz[3], c
   const float wpos = (float)(1.0 / (2 * (double)m->d.bound));  // `1.0/(2 * m_bound)` -> float arg
   float p01[3], d01[3];
   for (int c = 0; c < 3; ++c) {
-    float v = wpos * xyz[c];
-    p01[c] = v + 0.5f;
-    float u = 0.5f * dir[c];
-    d01[c] = u + 0.5f;
+    p01[c] = mad(m->contract, wpos, xyz[c], 0.5f);  // linear_transformer, common_device.cuh:34: weight * input + bias
+    d01[c] = mad(m->contract, 0.5f, dir[c], 0.5f);
   }
   uint16_t feat[128], dirfeat[128], out4[4];
   encode_grid_one(m, p01, feat);
@@ -605,15 +697,15 @@ inline float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)
 
 // set_rays_d (render_utils.h:31-52): Eigen's fixed-size reductions are
 // unrolled as a + (b + c) (redux_novec_unroller splits [0,1) | [1,3)).
-inline void ray_dir(const float R[9], const float cam[4], int px, int py, float d[3]) {
+inline void ray_dir(const float R[9], const float cam[4], int px, int py, float d[3], bool fm = false) {
   const float i = (float)((double)px + 0.5);
   const float j = (float)((double)py + 0.5);
   const float zs = 1;
   const float xs = (i - cam[2]) / cam[0] * zs;
   const float ys = (j - cam[3]) / cam[1] * zs;
-  const float n = sqrtf(xs * xs + (ys * ys + zs * zs));
+  const float n = sqrtf(mad(fm, xs, xs, mad(fm, ys, ys, zs * zs)));
   const float v[3] = {xs / n, ys / n, zs / n};
-  for (int r = 0; r < 3; ++r) d[r] = R[3 * r + 0] * v[0] + (R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2]);
+  for (int r = 0; r < 3; ++r) d[r] = mad(fm, R[3 * r + 0], v[0], mad(fm, R[3 * r + 1], v[1], R[3 * r + 2] * v[2]));
 }
 
 // kernel_near_far_from_aabb, render_utils.h:353-391
@@ -656,12 +748,13 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
   const float dt_min = 2 * 1.7320508075688772f / 1024;  // MIN_STEPSIZE :181-183
   const float dt_max = 2 * bound / (float)H;
   const float Hm1 = (float)(H - 1);
+  const bool fm = m->contract;  // nrfo_set_contract: :595-597 `ox + t * dx`, :609-614 `x * mip_rbound + 1`, :643-645 `(..) * mip_bound - x`
   uint32_t step = 0;
   float last_t = t;
   while (t < far && step < n_step) {
-    const float x = clampf(ox + t * dx, -bound, bound);
-    const float y = clampf(oy + t * dy, -bound, bound);
-    const float z = clampf(oz + t * dz, -bound, bound);
+    const float x = clampf(mad(fm, t, dx, ox), -bound, bound);
+    const float y = clampf(mad(fm, t, dy, oy), -bound, bound);
+    const float z = clampf(mad(fm, t, dz, oz), -bound, bound);
     // mip_from_pos :148-155
     const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
     int exponent;
@@ -670,9 +763,9 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
     const float mip_bound = fminf(exp2f((float)level), bound);
     const float mip_rbound = 1 / mip_bound;
     // `0.5 * (x*mip_rbound + 1) * H` is double arithmetic on a float operand, narrowed to float
-    const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, Hm1);
-    const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, Hm1);
-    const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, Hm1);
+    const int nx = (int)clampf((float)(0.5 * (double)mad(fm, x, mip_rbound, 1) * (double)H), 0.0f, Hm1);
+    const int ny = (int)clampf((float)(0.5 * (double)mad(fm, y, mip_rbound, 1) * (double)H), 0.0f, Hm1);
+    const int nz = (int)clampf((float)(0.5 * (double)mad(fm, z, mip_rbound, 1) * (double)H), 0.0f, Hm1);
     const uint32_t index = (uint32_t)level * H * H * H + (uint32_t)nx * H * H + (uint32_t)ny * H + (uint32_t)nz;
     const float density = grid[index];
     if (density > density_thresh) {
@@ -686,9 +779,10 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
       last_t = t;
       step++;
     } else {
-      const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / Hm1 * 2 - 1) * mip_bound - x) * rdx;
-      const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / Hm1 * 2 - 1) * mip_bound - y) * rdy;
-      const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / Hm1 * 2 - 1) * mip_bound - z) * rdz;
+      // (`n + 0.5f + 0.5f * sign` and `q / (H - 1) * 2 - 1` hold products by 0.5 and 2: exact, fused or not)
+      const float tx = mad(fm, ((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) / Hm1 * 2 - 1, mip_bound, -x) * rdx;
+      const float ty = mad(fm, ((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) / Hm1 * 2 - 1, mip_bound, -y) * rdy;
+      const float tz = mad(fm, ((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) / Hm1 * 2 - 1, mip_bound, -z) * rdz;
       const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
       do {
         const float dt = clampf(t * dt_gamma, dt_min, dt_max);
@@ -701,8 +795,11 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
 
 // kernel_composite_rays for one ray, render_utils.h:679-749.  st = (ws, depth, r, g, b).
 // Returns the new rays_t (-1 = dead).
+// fm (nrfo_set_contract): `d += weight * t` and the three colour sums as fused multiply-adds, and `weight_sum += weight` as
+// fmaf(alpha, T, weight_sum) -- the product `alpha * T` has other uses, which the NVPTX back end fuses all the same
+// (enableAggressiveFMAFusion); `weight` itself stays the rounded product.
 inline float composite_one(const float* sigmas, const float* rgbs, const float* deltas,
-                           uint32_t n_step, float t, float* st) {
+                           uint32_t n_step, float t, float* st, bool fm = false) {
   float weight_sum = st[0], dd = st[1], r = st[2], g = st[3], b = st[4];
   uint32_t step = 0;
   while (step < n_step) {
@@ -710,12 +807,12 @@ inline float composite_one(const float* sigmas, const float* rgbs, const float* 
     const float alpha = 1.0f - expf(-sigmas[step] * deltas[2 * step]);  // reference: __expf
     const float T = 1 - weight_sum;
     const float weight = alpha * T;
-    weight_sum += weight;
+    weight_sum = fm ? fmaf(alpha, T, weight_sum) : weight_sum + weight;
     t += deltas[2 * step + 1];
-    dd += weight * t;
-    r += weight * rgbs[3 * step + 0];
-    g += weight * rgbs[3 * step + 1];
-    b += weight * rgbs[3 * step + 2];
+    dd = mad(fm, weight, t, dd);
+    r = mad(fm, weight, rgbs[3 * step + 0], r);
+    g = mad(fm, weight, rgbs[3 * step + 1], g);
+    b = mad(fm, weight, rgbs[3 * step + 2], b);
     if ((double)T < 1e-4) break;  // `T < 1e-4` compares against a double literal
     step++;
   }
@@ -731,7 +828,17 @@ struct RayState {
   float o[3], d[3], near, far;
   float st[5];
   float t;
+  uint32_t n_emitted;  // samples the march emitted for this ray
+  uint64_t hash;       // FNV-1a over the (dt, t - last_t) bits of every emitted sample: equal hashes <=> the same sample set
 };
+inline void note_samples(RayState& r, const float* delta, uint32_t cnt) {
+  for (uint32_t k = 0; k < 2 * cnt; ++k) {
+    uint32_t bits;
+    std::memcpy(&bits, delta + k, 4);
+    for (int b = 0; b < 4; ++b) r.hash = (r.hash ^ ((bits >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
+  }
+  r.n_emitted += cnt;
+}
 
 // The loop of R/src/nerf_render.cu:269-338 over one group of rays.
 // n_total plays the role of N (n_step = clamp(N/num_alive,1,8)).
@@ -771,14 +878,46 @@ void render_group(const nrfo_model* m, const nrf_options* opt, std::vector<RaySt
       float xyz[8 * 3], delta[8 * 2], sig[8], rgb[8 * 3];
       for (int k = 0; k < n_step; ++k) delta[2 * k] = delta[2 * k + 1] = 0.0f;  // deviation D-1
       const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, (uint32_t)n_step, xyz, delta);
+      note_samples(r, delta, cnt);
       for (uint32_t k = 0; k < cnt; ++k) network_one(m, opt->density_scale, xyz + 3 * k, r.d, sig + k, rgb + 3 * k);
       for (uint32_t k = cnt; k < (uint32_t)n_step; ++k) sig[k] = rgb[3 * k] = rgb[3 * k + 1] = rgb[3 * k + 2] = 0.0f;
-      r.t = composite_one(sig, rgb, delta, (uint32_t)n_step, r.t, r.st);
+      r.t = composite_one(sig, rgb, delta, (uint32_t)n_step, r.t, r.st, m->contract);
       round_samples += cnt;
     }
     samples += round_samples;
     rounds++;
     step += n_step;  // :336
+  }
+  *n_samples += samples;
+  *n_rounds += rounds;
+}
+
+// The PER_RAY schedule without the rounds: with n_step == 1 nothing a ray does depends on any other ray (the alive list
+// only decides WHEN it is served), so every ray runs the loop of nerf_render.cu:269-338 to its own end -- march one sample,
+// evaluate, composite, until it dies or max_steps iterations have passed -- under a dynamic schedule: no barrier per
+// round, no serial compaction.  Bit-identical to render_group(.., fixed_n_step = 1) (tests/test_config1.py); what a CPU
+// implementation of the path would do, and what bench.py times as `cpu_baseline`.  n_rounds = the rounds the global loop
+// would have run = the longest ray's iteration count.
+void render_rays_independent(const nrfo_model* m, const nrf_options* opt, std::vector<RayState>& rays, uint64_t* n_samples,
+                             uint64_t* n_rounds) {
+  const int64_t N = (int64_t)rays.size();
+  uint64_t samples = 0, rounds = 0;
+#pragma omp parallel for schedule(dynamic, 32) reduction(+ : samples) reduction(max : rounds)
+  for (int64_t i = 0; i < N; ++i) {
+    RayState& r = rays[i];
+    r.t = r.near;                   // init_step0
+    if (!(r.near < r.far)) continue;  // never enters the alive list (skip_missed)
+    uint64_t it = 0;
+    while (it < (uint64_t)opt->max_steps && r.t >= 0) {
+      float xyz[3], delta[2] = {0.0f, 0.0f}, sig = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, 1u, xyz, delta);
+      note_samples(r, delta, cnt);
+      if (cnt) network_one(m, opt->density_scale, xyz, r.d, &sig, rgb);
+      r.t = composite_one(&sig, rgb, delta, 1u, r.t, r.st, m->contract);
+      samples += cnt;
+      ++it;
+    }
+    if (it > rounds) rounds = it;
   }
   *n_samples += samples;
   *n_rounds += rounds;
@@ -829,7 +968,7 @@ int nrfo_generate_rays(const nrfo_model* m, const float cam[4], const float pose
     for (int px = 0; px < W; ++px) {
       const size_t i = (size_t)py * W + px;
       float d[3], nr, fr;
-      ray_dir(R, cam, px, py, d);
+      ray_dir(R, cam, px, py, d, m->contract);
       near_far(m->d.aabb, org, d, o->min_near, &nr, &fr);
       if (rays_o) { rays_o[3 * i] = org[0]; rays_o[3 * i + 1] = org[1]; rays_o[3 * i + 2] = org[2]; }
       if (rays_d) { rays_d[3 * i] = d[0]; rays_d[3 * i + 1] = d[1]; rays_d[3 * i + 2] = d[2]; }
@@ -904,9 +1043,10 @@ int nrfo_composite(const float* sigmas, const float* rgbs, const float* deltas, 
   return NRF_OK;
 }
 
-int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H,
-                const nrf_options* o, int schedule, int n_threads, float* rgba, float* depth,
-                nrf_stats* stats) {
+}  // extern "C"
+namespace {
+int render_impl(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o, int schedule,
+                int n_threads, float* rgba, float* depth, nrf_stats* stats, uint32_t* ray_samples, uint64_t* ray_hash) {
   if (!m || !cam || !pose || !o || !rgba || !depth || W <= 0 || H <= 0) return fail(NRF_E_INVALID, "bad argument");
   if (o->perturb) return fail(NRF_E_UNSUPPORTED, "perturb not implemented");
 #ifdef _OPENMP
@@ -923,29 +1063,37 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
 
   auto init_ray = [&](RayState& r, int px, int py) {
     r.o[0] = org[0]; r.o[1] = org[1]; r.o[2] = org[2];
-    ray_dir(R, cam, px, py, r.d);
+    ray_dir(R, cam, px, py, r.d, m->contract);
     near_far(m->d.aabb, r.o, r.d, o->min_near, &r.near, &r.far);
     for (float& v : r.st) v = 0.0f;  // zero fills nerf_render.cu:262-264
+    r.n_emitted = 0;
+    r.hash = 0xcbf29ce484222325ull;
   };
   // get_image_and_depth, render_utils.h:257-264; deviation D-3: a ray that
   // misses the aabb (near == far) gets depth 0 instead of 0/0.
   auto finish = [&](const RayState& r, int px, int py) {
     const size_t i = (size_t)py * W + px;
     const float bg = o->bg_color;
-    rgba[4 * i + 0] = r.st[2] + (1 - r.st[0]) * bg;
-    rgba[4 * i + 1] = r.st[3] + (1 - r.st[0]) * bg;
-    rgba[4 * i + 2] = r.st[4] + (1 - r.st[0]) * bg;
+    rgba[4 * i + 0] = mad(m->contract, 1 - r.st[0], bg, r.st[2]);  // image + (1 - weights_sum) * bg_color
+    rgba[4 * i + 1] = mad(m->contract, 1 - r.st[0], bg, r.st[3]);
+    rgba[4 * i + 2] = mad(m->contract, 1 - r.st[0], bg, r.st[4]);
     rgba[4 * i + 3] = r.st[0];
+    if (ray_samples) ray_samples[i] = r.n_emitted;
+    if (ray_hash) ray_hash[i] = r.hash;
     const float span = r.far - r.near;
     depth[i] = span > 0.0f ? fmaxf(r.st[1] - r.near, 0.0f) / span : 0.0f;
   };
 
+  const bool per_ray_rounds = schedule == -NRFO_SCHED_PER_RAY;  // (nrfo_render_per_ray_rounds)
+  if (per_ray_rounds) schedule = NRFO_SCHED_PER_RAY;
   if (schedule == NRFO_SCHED_REFERENCE || schedule == NRFO_SCHED_PER_RAY) {
     std::vector<RayState> rays((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int py = 0; py < H; ++py)
       for (int px = 0; px < W; ++px) init_ray(rays[(size_t)py * W + px], px, py);
-    render_group(m, o, rays, true, schedule == NRFO_SCHED_PER_RAY, schedule == NRFO_SCHED_PER_RAY ? 1 : 0, &n_samples, &n_rounds);
+    if (per_ray_rounds) render_group(m, o, rays, true, true, 1, &n_samples, &n_rounds);
+    else if (schedule == NRFO_SCHED_PER_RAY) render_rays_independent(m, o, rays, &n_samples, &n_rounds);
+    else render_group(m, o, rays, true, false, 0, &n_samples, &n_rounds);
 #pragma omp parallel for schedule(static)
     for (int py = 0; py < H; ++py)
       for (int px = 0; px < W; ++px) finish(rays[(size_t)py * W + px], px, py);
@@ -992,6 +1140,27 @@ int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], i
   omp_set_num_threads(saved);
 #endif
   return NRF_OK;
+}
+}  // namespace
+extern "C" {
+
+int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o, int schedule,
+                int n_threads, float* rgba, float* depth, nrf_stats* stats) {
+  return render_impl(m, cam, pose, W, H, o, schedule, n_threads, rgba, depth, stats, nullptr, nullptr);
+}
+
+// The same render, also returning per ray (row-major [H][W]) the number of samples its march emitted and a hash of their
+// (dt, t - last_t) bits: two renders whose hashes agree for a ray took the same samples along it.
+int nrfo_render_rays(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o, int schedule,
+                     int n_threads, float* rgba, float* depth, nrf_stats* stats, uint32_t* ray_samples, uint64_t* ray_hash) {
+  return render_impl(m, cam, pose, W, H, o, schedule, n_threads, rgba, depth, stats, ray_samples, ray_hash);
+}
+
+// the PER_RAY schedule through the global round loop (render_group with n_step fixed to 1), as rounds 1-4 ran it: kept as the
+// cross-check of render_rays_independent
+int nrfo_render_per_ray_rounds(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o,
+                               float* rgba, float* depth, nrf_stats* stats) {
+  return render_impl(m, cam, pose, W, H, o, -NRFO_SCHED_PER_RAY, 0, rgba, depth, stats, nullptr, nullptr);
 }
 
 // NerfRender::generate_density_grid, R/src/nerf_render.cu:388-429, completed as nerfhip.h nrf_generate_density_grid

@@ -58,9 +58,24 @@ void nrfo_widths(const nrfo_model* m, uint32_t* feat_width, uint32_t* dir_width)
 enum { NRFO_ACC_FP32 = 0, NRFO_ACC_FP16_STEP = 1, NRFO_ACC_FP16_K4 = 4, NRFO_ACC_FP16_K8 = 8, NRFO_ACC_FP16_K16 = 16 };
 int nrfo_set_mlp_accumulate(nrfo_model* m, int mode);
 
-/* fp16 helpers (round-to-nearest-even, IEEE binary16) */
+/* FMA contraction.  0 (default): every fp32 operation individually rounded -- the contract shared with the HIP path.
+ * 1: `a * b + c` evaluated as ONE fused multiply-add wherever the reference's device source has it in one expression
+ * (nvcc's default -fmad=true; R/CMakeLists.txt:71-79 sets no -fmad=false): set_rays_d's norm and rotation
+ * (render_utils.h:43-47), `ox + t * dx` (:595-597), `x * mip_rbound + 1` (:609-614), `(..) * mip_bound - x` (:643-645),
+ * linear_transformer (common_device.cuh:34), pos_fract `input * scale + 0.5f` (T/.../common_device.h:416) and the level scale
+ * (grid.h:189), kernel_sh's polynomials (spherical_harmonics.h:66-152), frequency_encoding (frequency.h:88), the sums of
+ * kernel_composite_rays (:712-720) and get_image_and_depth (:258-260).  Not fused: products cast before they are added
+ * (grid.h:260), host code (nerf_matrix_to_ngp, the offset table).  Exists to MEASURE the distance between the contract and
+ * what the reference binary computes; which of two products of a sum a compiler fuses is its choice (here: the left). */
+int nrfo_set_contract(nrfo_model* m, int on);
+
+/* fp16 helpers (round-to-nearest-even, IEEE binary16).  nrfo_f32_to_f16 / nrfo_f16_to_f32 are what the oracle computes
+ * with (F16C instructions when built with -mf16c, see nrfo_fp16_backend); the *_soft forms are the bit-level definition. */
 uint16_t nrfo_f32_to_f16(float f);
 float nrfo_f16_to_f32(uint16_t h);
+uint16_t nrfo_f32_to_f16_soft(float f);
+float nrfo_f16_to_f32_soft(uint16_t h);
+const char* nrfo_fp16_backend(void); /* "f16c" or "software" */
 
 /* render_utils.h:68-77 */
 void nrfo_nerf_matrix_to_ngp(const float pose[16], float scale, float out[16]);
@@ -94,6 +109,14 @@ uint32_t nrfo_march_trip_starts(float bound, uint32_t cascade, uint32_t H, float
 int nrfo_render(const nrfo_model* m, const float cam[4], const float pose[16], int W,
                 int H, const nrf_options* o, int schedule, int n_threads, float* rgba,
                 float* depth, nrf_stats* stats);
+/* nrfo_render + per ray ([H][W]) the number of samples its march emitted and a hash of their (dt, t - last_t) bits */
+int nrfo_render_rays(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o,
+                     int schedule, int n_threads, float* rgba, float* depth, nrf_stats* stats, uint32_t* ray_samples,
+                     uint64_t* ray_hash);
+/* NRFO_SCHED_PER_RAY runs every ray to its end on its own (no rounds, dynamic schedule: the timed CPU baseline); this is the
+ * same schedule through the global round loop of nerf_render.cu:269-338 with n_step fixed to 1 -- the cross-check.        */
+int nrfo_render_per_ray_rounds(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H,
+                               const nrf_options* o, float* rgba, float* depth, nrf_stats* stats);
 /* NerfRender::generate_density_grid (nerf_render.cu:388-429) as nerfhip.h's nrf_generate_density_grid completes it:
  * grid [cascade * H^3] (x-major cells), mean_density = mean(max(g, 0))                                           */
 int nrfo_density_grid(const nrfo_model* m, int n_iterations, float decay, float* grid, float* mean_density);

@@ -105,3 +105,29 @@ def test_self_launched_two_rank_rehearsal_config5_replicas():
     assert out["config"]["views_per_step"] == 8 and out["config"]["views_per_rank_and_step"] == 4
     assert out["sharded_frame_equals_unsharded"] is True and "800x800" in out["config"]["workload"]
     assert out["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_forced_single_rank_runs_the_real_rccl_exchange():
+    """`--force-dist --backend nccl` on the one GPU of the box: a one-rank RCCL communicator
+    (init_process_group("nccl", device_id=...)), the shard rendered tile-major and packed, dist.gather of int32 device tensors
+    through RCCL, untile_views with shard_count 1, the one-stream render / exchange hand-off with two steps in flight,
+    and the check of the gathered + untiled frames against unsharded renders.  What a one-GPU box can execute of the N > 1
+    path (the reference: R/src/nerf_render.cu:345-359) -- config 3 (tile-sharded) and config 5 (replicas)."""
+    out = _bench_line(["--gpus", "1", "--force-dist", "--backend", "nccl", "--check", "--steps", "3", "--warmup", "1",
+                       "--views-per-step", "3"])
+    d = out["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["forced_single_rank"] is True and d["rccl_version"]
+    assert out["sharded_frame_equals_unsharded"] is True
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "tile1" and out["config"]["gather"] == "rgbd8"
+    assert out["config"]["steps_in_flight"] == 2 and out["value"] > 0
+    assert "api" not in out and "cpu_baseline" not in out  # the exchange rehearsal carries no extras
+    # float planes on the wire instead of packed pixels
+    out = _bench_line(["--gpus", "1", "--force-dist", "--backend", "nccl", "--check", "--steps", "2", "--warmup", "1",
+                       "--views-per-step", "2", "--gather-format", "f32", "--width", "328", "--height", "200"])
+    assert out["distributed"]["backend"] == "nccl" and out["sharded_frame_equals_unsharded"] is True
+    # config 5: whole frames per rank, gather of images, no untile
+    out = _bench_line(["--gpus", "1", "--force-dist", "--backend", "nccl", "--config", "5", "--check", "--steps", "2",
+                       "--warmup", "1", "--views-per-step", "4"])
+    assert out["distributed"]["backend"] == "nccl" and out["config"]["parallelism"] == "replica1"
+    assert out["sharded_frame_equals_unsharded"] is True

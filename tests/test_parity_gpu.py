@@ -694,6 +694,135 @@ def test_device_group_on_distinct_devices(ctx):
         g.close()
 
 
+def _group_case(ctx, n):
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    W, H = 328, 200  # ragged strips (41 tiles per row) and rows (25 tile rows)
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    poses = np.stack([syn.orbit_pose(70.0 * i, 25.0) for i in range(n)])
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    ctx.set_max_views(n)
+    ctx.render_views(cams, poses)
+    want = [ctx.read_view_f32(i) for i in range(n)]
+    want_u8 = [ctx.read_view_u8(i) for i in range(n)]
+    want_samples = ctx.stats().n_composited
+    ctx.set_max_views(1)
+    return desc, keep, W, H, cams, poses, want, want_u8, want_samples
+
+
+def _check_group(g, n, cams, poses, want, want_u8, want_samples, what):
+    f = g.render_views(cams, poses)
+    assert f.n_views == n and f.tile_major == 0
+    assert g.stats().n_composited == want_samples
+    for i in range(n):
+        rgba, depth = g.read_view_f32(i)
+        np.testing.assert_array_equal(rgba, want[i][0], err_msg=what)
+        np.testing.assert_array_equal(depth, want[i][1], err_msg=what)
+        rgb8, d8 = g.read_view_u8(i)
+        np.testing.assert_array_equal(rgb8, want_u8[i][0], err_msg=what)
+    for rep in range(3):  # both host-frame slots, and the first one again
+        rgb8, d8 = g.render_host_u8(cams, poses)
+        for i in range(n):
+            np.testing.assert_array_equal(rgb8[i], want_u8[i][0], err_msg=f"{what}, host frame {i}, pass {rep}")
+            np.testing.assert_array_equal(d8[i], want_u8[i][1])
+
+
+def test_device_group_rccl_gather_one_member(ctx):
+    """nrf_group_set_gather(NRF_GATHER_RCCL) (csrc/nrf_group.hip ship_to_first): ncclCommInitAll + one group of
+    ncclSend / ncclRecv to devices[0] per call in place of hipMemcpyPeerAsync (the reference: cudaMemcpyAsync D2H per GPU,
+    R/src/nerf_render.cu:345-359).  With ONE member -- all this box has -- the group still runs the whole exchange in this
+    mode: the member renders its shard tile-major (nrf_options.tile_major), RCCL moves it (a send to self), devices[0]
+    untiles.  Float planes, u8 images, host frames and sample counts must be a single context's, bit for bit; switching
+    the transport back and forth between calls as well; a group that lists a device twice is refused."""
+    n = 4
+    desc, keep, W, H, cams, poses, want, want_u8, want_samples = _group_case(ctx, n)
+    g = nh.NerfGroup([0])
+    g.load_model(desc)
+    g.set_resolution(W, H)
+    assert g.gather() == (nh.GATHER_PEER_COPY, 0)
+    _check_group(g, n, cams, poses, want, want_u8, want_samples, "peer copies (a lone member: no exchange)")
+    g.set_gather(nh.GATHER_RCCL)
+    mode, version = g.gather()
+    assert mode == nh.GATHER_RCCL and version >= 20000, (mode, version)
+    _check_group(g, n, cams, poses, want, want_u8, want_samples, "RCCL")
+    g.set_gather(nh.GATHER_PEER_COPY)
+    _check_group(g, n, cams, poses, want, want_u8, want_samples, "peer copies again")
+    g.set_gather(nh.GATHER_RCCL)  # (a second communicator in one process)
+    g.set_resolution(W, H)
+    _check_group(g, n, cams, poses, want, want_u8, want_samples, "RCCL again")
+    g.close()
+    g2 = nh.NerfGroup([0, 0])
+    with pytest.raises(nh.NerfHipError, match="DISTINCT"):
+        g2.set_gather(nh.GATHER_RCCL)
+    g2.load_model(desc)
+    g2.set_resolution(W, H)
+    _check_group(g2, n, cams, poses, want, want_u8, want_samples, "two members on one device stay on peer copies")
+    g2.close()
+
+
+def test_device_group_rccl_gather_on_distinct_devices(ctx):
+    """The RCCL transport across DIFFERENT devices (xGMI): runs wherever at least two GPUs are visible (the driver's 8-GPU
+    node); skipped on a one-GPU box."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two visible GPUs")
+    n = 3
+    desc, keep, W, H, cams, poses, want, want_u8, want_samples = _group_case(ctx, n)
+    for members in sorted({2, min(n_dev, 4), min(n_dev, 8)}):
+        g = nh.NerfGroup(list(range(members)))
+        g.load_model(desc)
+        g.set_resolution(W, H)
+        g.set_gather(nh.GATHER_RCCL)
+        _check_group(g, n, cams, poses, want, want_u8, want_samples, f"RCCL, {members} members")
+        g.close()
+
+
+def test_single_shard_in_the_shard_layout(ctx):
+    """nrf_options.tile_major: one shard (shard_count 1) rendered tile-major + nrf_untile_views with shard_count 1 == the
+    row-major frame, float planes and packed pixels (what bench.py --force-dist and a one-member RCCL group render)."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    W, H, n = 328, 200, 3
+    cams = np.stack([syn.default_camera(W, H)] * n)
+    poses = np.stack([syn.orbit_pose(100.0 * i, 15.0) for i in range(n)])
+    ctx.load_model(desc)
+    ctx.set_options(nh.default_options())
+    ctx.set_resolution(W, H)
+    ctx.set_max_views(n)
+    ctx.render_views(cams, poses)
+    want = [ctx.read_view_f32(i) for i in range(n)]
+    want_u8 = [ctx.read_view_u8(i) for i in range(n)]
+    o = nh.default_options()
+    o.tile_major = 1
+    ctx.set_options(o)
+    tps = nh.tiles_per_shard(W, H, 1)
+    f = ctx.render_views(cams, poses)
+    assert f.tile_major == 1 and f.n_tiles == tps and f.view_stride_px == tps * 64
+    with pytest.raises(nh.NerfHipError):
+        ctx.read_view_f32(0)  # a shard layout is not a row-major frame
+    out = torch.empty((n, H, W, 4), device="cuda")
+    outd = torch.empty((n, H, W), device="cuda")
+    ctx.untile_views(f.rgba, 1, tps, 4, n, out.data_ptr())
+    ctx.untile_views(f.depth, 1, tps, 1, n, outd.data_ptr())
+    sync()
+    for i in range(n):
+        np.testing.assert_array_equal(out[i].cpu().numpy(), want[i][0])
+        np.testing.assert_array_equal(outd[i].cpu().numpy(), want[i][1])
+    packed = torch.zeros((n, tps * 64), dtype=torch.int32, device="cuda")
+    ctx.bind_output_rgbd8(packed.data_ptr())
+    ctx.render_views(cams, poses)
+    ctx.bind_output_rgbd8(None)
+    rgb8 = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    d8 = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
+    ctx.untile_views_u8(packed.data_ptr(), 1, tps, n, rgb8.data_ptr(), d8.data_ptr())
+    sync()
+    for i in range(n):
+        np.testing.assert_array_equal(rgb8[i].cpu().numpy(), want_u8[i][0])
+        np.testing.assert_array_equal(d8[i].cpu().numpy(), want_u8[i][1])
+    ctx.set_options(nh.default_options())
+    ctx.set_max_views(1)
+
+
 @pytest.mark.parametrize("radius,az,el,fl_scale", [(0.9, 40, 10, 1.0), (0.3, 200, 35, 0.4), (2.2, 310, 80, 3.0), (1.5, 0, -89, 1.0)])
 def test_region_of_interest_cull_is_conservative(ctx, small, radius, az, el, fl_scale):
     """The per-view pixel rectangle outside of which strips are filled with the background without
