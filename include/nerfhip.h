@@ -197,6 +197,9 @@ typedef struct nrf_stats {
   uint64_t n_composited; /* samples that entered a ray's compositing sum: what the reference's own per-ray schedule emits
                            (n_samples also counts the samples a ray queues behind its terminating one; how many those are
                            depends on how rays are batched into rounds, this count does not)                           */
+  float shader_clock_mhz; /* the core clock the last launch of the persistent render kernel ran at, measured in the launch:
+                           d(s_memtime) / d(s_memrealtime) x 100 MHz between the entry and the exit of one wave per workgroup,
+                           summed over the workgroups; 0 when the last render did not run that kernel                    */
 } nrf_stats;
 
 typedef struct nrf_context nrf_context;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1139,11 +1140,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   }
   c->model_loaded = true;
   // the code objects of the render kernel's families are loaded here, not by the first frame (once per process and device)
-  static bool preloaded[64] = {false};
-  if (c->device >= 0 && c->device < 64 && !preloaded[c->device]) {
-    preload_kernels(true);
-    preloaded[c->device] = true;
-  }
+  // (group members and server workers load models concurrently: one flag per device, taken under a lock)
+  static std::once_flag preloaded[64];
+  if (c->device >= 0 && c->device < 64) std::call_once(preloaded[c->device], [] { preload_kernels(true); });
   return NRF_OK;
 }
 
@@ -1738,7 +1737,9 @@ int nrf_debug_counters(nrf_context* c, unsigned long long out[16]) {
 }
 
 // Diagnostic (not part of include/nerfhip.h): which kernel instance renders the loaded model -- 0 register-resident,
-// 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons), 4 its wide form for SH degree 5..8; + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
+// 1 generic, 2 wide, 3 the register-resident instance of another width (16 / 32 / 128 neurons) or depth, 4 its wide form for SH
+// degree 5..8, 5 a GRID instance (base.json's MLPs behind another grid: F = 2 with fewer than 16 levels, F = 4 / 8, Smoothstep);
+// + 16 when the persistent form is used (tests assert that a model runs where it is meant to).
 extern "C" int nrf_debug_instance(nrf_context* c) {
   if (!c || !c->model_loaded) return -1;
   return (c->dm.wide_sh ? 4 : (c->dm.hot_grid ? 5 : (c->dm.hot_width ? 3 : (c->dm.generic ? 1 : (c->dm.wide ? 2 : 0))))) + (c->dm.persistent ? 16 : 0);
@@ -1799,13 +1800,15 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   int rc = set_device(c);
   if (rc) return rc;
   HIP_TRY(hipEventSynchronize(c->ev1));
-  unsigned long long raw[COUNTER_SLOTS * 16], cnt[4] = {0, 0, 0, 0};
+  unsigned long long raw[COUNTER_SLOTS * 16], cnt[6] = {0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpy(raw, call_slot(c, c->call_index), COUNTER_BYTES, hipMemcpyDeviceToHost));
   for (int sl = 0; sl < COUNTER_SLOTS; ++sl) {
     cnt[0] += raw[sl * 16];
     cnt[1] += raw[sl * 16 + 1];
     cnt[2] += raw[sl * 16 + 11];
     cnt[3] += raw[sl * 16 + 7];
+    cnt[4] += raw[sl * 16 + 12];
+    cnt[5] += raw[sl * 16 + 13];
   }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1815,6 +1818,10 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   s->n_network_evals = cnt[2];
   s->n_composited = cnt[3];
   s->render_ms = ms;
+  s->shader_clock_mhz = 0.f;
+#ifndef NRF_PHASE_TIMING  // (a diagnostic build keeps other quantities in these two counters)
+  if (cnt[5] > 0) s->shader_clock_mhz = (float)((double)cnt[4] / (double)cnt[5] * 100.0);
+#endif
   return NRF_OK;
 }
 

@@ -47,22 +47,30 @@ __global__ __launch_bounds__(256) void gen_encode_grid_kernel(const DevModel M, 
     if (M.hot_grid != 0u) {
       // the model's frames come from a GRID instance of the render kernel (nrf_render.h grid_features): this entry point then runs
       // THAT instance's gathers and interpolation, so that the bit-exact encode test covers them (tests/test_generic_gpu.py)
+      // -- including the specialisation grid_features picks for the level: the render kernel's lane group g holds the levels
+      // 4 * jl + g, and step jl takes the dense (1) / hashed (2) form of the index arithmetic when all of its levels are
       float fr[3];
       uint32_t o[4] = {0u, 0u, 0u, 0u};
+      const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
       if (M.hot_grid == 2u) {
         uint32_t v[8];
-        level_gather<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        else level_gather<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
         if (M.grid_smooth) smoothstep_fractions(fr);
         o[0] = level_interp<false>(v, fr);
       } else if (M.hot_grid == 4u) {
         uint32_t v[16], q[2];
-        level_gather_wide<0, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (uni == 2u) level_gather_wide<2, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        else if (uni == 1u) level_gather_wide<1, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        else level_gather_wide<0, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
         if (M.grid_smooth) smoothstep_fractions(fr);
         level_interp_wide<2>(v, fr, q);
         o[0] = q[0]; o[1] = q[1];
       } else {
         uint32_t v[32];
-        level_gather_wide<0, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        if (uni == 2u) level_gather_wide<2, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        else if (uni == 1u) level_gather_wide<1, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+        else level_gather_wide<0, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
         if (M.grid_smooth) smoothstep_fractions(fr);
         level_interp_wide<4>(v, fr, o);
       }

@@ -24,7 +24,7 @@ hipError_t launch_persistent_hot(const PersistLaunch& L) {
 }
 
 // the HIP runtime loads a translation unit's code object at the first launch of one of its kernels: touch one here, so that
-// nrf_create pays for it and not the first frame (preload_kernels, nrf_kernels.hip)
+// nrf_load_model pays for it (once per process and device) and not the first frame (preload_kernels, nrf_kernels.hip)
 void preload_hot() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_persistent_kernel<NET_HOT, MARCH_UNIT, persist_waves(NET_HOT), false, false, false>));

@@ -1072,8 +1072,9 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
 // SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
 __host__ __device__ constexpr int persist_waves(int net) { return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE) ? 12 : 16); }
-constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80;  // q_begin of every view + the total; the workgroup's block counter; HelpLds
-static_assert(sizeof(HelpLds) <= 80, "HelpLds lives behind the scheduler word");
+constexpr int LDS_CLOCK_BYTES = 16;  // wave 0's entry stamps (core-clock counter, 100 MHz counter), see shader_clock_mhz
+constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80 + LDS_CLOCK_BYTES;  // q_begin of every view + the total; the workgroup's block counter; HelpLds; the clock stamps
+static_assert(sizeof(HelpLds) + LDS_CLOCK_BYTES <= 80 + LDS_CLOCK_BYTES, "HelpLds and the clock stamps live behind the scheduler word");
 
 // The kernel's by-value arguments as they lie in the kernarg segment (the tile loop re-reads them per tile through a
 // pointer the compiler cannot see through: otherwise every field of the three structs is hoisted out of the loop and
@@ -1119,7 +1120,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   // ---- staged once per workgroup (= once per CU and launch)
   if constexpr (!GEN) stage_fragments<NET>(M, lm.wl);
   if constexpr (GEN && WLDS) {  // the generic instance's fragments, behind everything else (16-byte aligned)
-    uint4* w_lds = reinterpret_cast<uint4*>(smem + ((reinterpret_cast<unsigned char*>(hl + 1) - smem + 15) & ~(size_t)15));
+    uint4* w_lds = reinterpret_cast<uint4*>(smem + ((reinterpret_cast<unsigned char*>(hl + 1) + LDS_CLOCK_BYTES - smem + 15) & ~(size_t)15));
     for (uint32_t i = threadIdx.x; i < M.gen_frag_bytes / 16u; i += blockDim.x) w_lds[i] = M.wfrag[i];
     lm.gen.wfrag = w_lds;
   }
@@ -1138,6 +1139,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   }
   if (threadIdx.x < 16) hl->mail[threadIdx.x] = 0u;
   __syncthreads();
+#ifndef NRF_PHASE_TIMING
+  // The shader clock this launch ran at (nrf_stats::shader_clock_mhz; what gather rates per clock are priced with): wave 0 of
+  // every workgroup stamps the core-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) here and when
+  // it leaves for good; the entry pair waits in LDS (no register is held for it), the two differences are summed over the
+  // workgroups in the statistics counters: clock = sum d(memtime) / sum d(memrealtime) x 100 MHz.  Two stamps per launch and
+  // workgroup: nothing executes in the tile loop for it.
+  unsigned* clk_lds = reinterpret_cast<unsigned*>(hl + 1);
+  if (wave == 0) {
+    unsigned long long t0, r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    if (lane == 0) {
+      clk_lds[0] = (unsigned)t0;
+      clk_lds[1] = (unsigned)(t0 >> 32);
+      clk_lds[2] = (unsigned)r0;
+      clk_lds[3] = (unsigned)(r0 >> 32);
+    }
+  }
+#endif
 
   const MarchConst mc = march_const(M, P.dt_gamma);
   TileStats ts;
@@ -1456,6 +1475,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void render_persistent_kernel(const 
   }
 #endif
   counters += (blockIdx.x % COUNTER_SLOTS) * 16;
+#ifndef NRF_PHASE_TIMING
+  if (wave == 0) {  // (see the entry stamps)
+    unsigned long long t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    if (lane == 0) {
+      const unsigned long long t0 = (unsigned long long)clk_lds[0] | ((unsigned long long)clk_lds[1] << 32);
+      const unsigned long long r0 = (unsigned long long)clk_lds[2] | ((unsigned long long)clk_lds[3] << 32);
+      atomicAdd(&counters[12], t1 - t0);
+      atomicAdd(&counters[13], r1 - r0);
+    }
+  }
+#endif
   if (lane == 0 && ts.n_rounds != 0) {
     atomicAdd(&counters[0], (unsigned long long)ts.n_samples);
     atomicAdd(&counters[1], (unsigned long long)ts.n_rounds);

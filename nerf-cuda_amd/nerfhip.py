@@ -131,6 +131,7 @@ class Stats(C.Structure):
         ("n_network_evals", C.c_uint64),
         ("render_ms", C.c_float),
         ("n_composited", C.c_uint64),
+        ("shader_clock_mhz", C.c_float),
     ]
 
 

@@ -204,6 +204,30 @@ uint16_t nrfo_f32_to_f16(float f) { return f2h(f); }
 float nrfo_f16_to_f32(uint16_t h) { return h2f(h); }
 uint16_t nrfo_f32_to_f16_soft(float f) { return f2h_soft(f); }
 float nrfo_f16_to_f32_soft(uint16_t h) { return h2f_soft(h); }
+// the conversions in use against their bit-level definition: every 16-bit pattern one way, every `stride`-th 32-bit pattern
+// the other (stride 1: all 2^32); returns the number of disagreements (NaNs must agree in their bits as well)
+uint64_t nrfo_fp16_selfcheck(uint32_t stride) {
+  uint64_t bad = 0;
+  for (uint32_t h = 0; h < 65536u; ++h) {
+    const float a = h2f((uint16_t)h), b = h2f_soft((uint16_t)h);
+    uint32_t ab, bb;
+    std::memcpy(&ab, &a, 4);
+    std::memcpy(&bb, &b, 4);
+    // a SIGNALLING half NaN (never produced by f2h) comes back quieted from the instruction, untouched from the software form
+    if (a != a && b != b) { ab |= 0x00400000u; bb |= 0x00400000u; }
+    if (ab != bb) ++bad;
+  }
+  if (stride == 0) stride = 1;
+  const int64_t n = (int64_t)((0xffffffffull + stride) / stride);
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t x = (uint32_t)((uint64_t)i * stride);
+    float f;
+    std::memcpy(&f, &x, 4);
+    if (f2h(f) != f2h_soft(f)) ++bad;
+  }
+  return bad;
+}
 const char* nrfo_fp16_backend(void) {
 #ifdef __F16C__
   return "f16c";
@@ -1132,6 +1156,7 @@ int render_impl(const nrfo_model* m, const float cam[4], const float pose[16], i
     stats->n_rounds = n_rounds;
     stats->n_network_evals = n_samples;  // D-5: the oracle evaluates live samples only, no tile padding
     stats->render_ms = 0.0f;
+    stats->shader_clock_mhz = 0.0f;
     // the per-ray schedule emits exactly the samples a ray composites; the other schedules (n_step > 1) also evaluate
     // samples behind a ray's terminating one and do not count the composited ones apart: 0 = not counted
     stats->n_composited = schedule == NRFO_SCHED_PER_RAY ? n_samples : 0;

@@ -76,6 +76,8 @@ float nrfo_f16_to_f32(uint16_t h);
 uint16_t nrfo_f32_to_f16_soft(float f);
 float nrfo_f16_to_f32_soft(uint16_t h);
 const char* nrfo_fp16_backend(void); /* "f16c" or "software" */
+/* conversions in use vs the software definition: all 2^16 halves, every stride-th of the 2^32 floats; returns mismatches */
+uint64_t nrfo_fp16_selfcheck(uint32_t stride);
 
 /* render_utils.h:68-77 */
 void nrfo_nerf_matrix_to_ngp(const float pose[16], float scale, float out[16]);

@@ -41,6 +41,17 @@ def lib():
     L.nrfo_widths.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.nrfo_widths.restype = None
     L.nrfo_set_mlp_accumulate.argtypes = [vp, C.c_int]
+    L.nrfo_set_contract.argtypes = [vp, C.c_int]
+    L.nrfo_f32_to_f16_soft.argtypes = [C.c_float]
+    L.nrfo_f32_to_f16_soft.restype = C.c_uint16
+    L.nrfo_f16_to_f32_soft.argtypes = [C.c_uint16]
+    L.nrfo_f16_to_f32_soft.restype = C.c_float
+    L.nrfo_fp16_backend.restype = C.c_char_p
+    L.nrfo_fp16_selfcheck.argtypes = [C.c_uint32]
+    L.nrfo_fp16_selfcheck.restype = C.c_uint64
+    L.nrfo_render_rays.argtypes = [vp, fp, fp, C.c_int, C.c_int, C.POINTER(nh.Options), C.c_int, C.c_int, vp, vp,
+                                   C.POINTER(nh.Stats), vp, vp]
+    L.nrfo_render_per_ray_rounds.argtypes = [vp, fp, fp, C.c_int, C.c_int, C.POINTER(nh.Options), vp, vp, C.POINTER(nh.Stats)]
     L.nrfo_f32_to_f16.argtypes = [C.c_float]
     L.nrfo_f32_to_f16.restype = C.c_uint16
     L.nrfo_f16_to_f32.argtypes = [C.c_uint16]
@@ -92,13 +103,15 @@ def _fp(a):
 
 
 class Oracle:
-    def __init__(self, desc: nh.ModelDesc, accumulate: int = ACC_FP32):
+    def __init__(self, desc: nh.ModelDesc, accumulate: int = ACC_FP32, contract: bool = False):
         self.L = lib()
         h = C.c_void_p()
         _ck(self.L.nrfo_create(C.byref(desc), C.byref(h)))
         self.h = h
         if accumulate != ACC_FP32:
             self.set_mlp_accumulate(accumulate)
+        if contract:
+            self.set_contract(True)
         fw, dw = C.c_uint32(), C.c_uint32()
         self.L.nrfo_widths(h, C.byref(fw), C.byref(dw))
         self.feat_width, self.dir_width = int(fw.value), int(dw.value)  # padded encoding widths (MLP input widths)
@@ -173,6 +186,35 @@ class Oracle:
         _ck(self.L.nrfo_density_grid(self.h, int(n_iterations), C.c_float(decay), grid.ctypes.data, C.byref(mean)))
         return grid, float(mean.value)
 
+    def set_contract(self, on: bool):
+        """`a * b + c` as one fused multiply-add wherever the reference's device source has it in one expression (nvcc's
+        default contraction); False (default): every operation rounded, the contract shared with the HIP path."""
+        _ck(self.L.nrfo_set_contract(self.h, int(bool(on))))
+
+    def render_rays(self, cam, pose, W, H, opts=None, schedule=SCHED_PER_RAY, n_threads=0):
+        """render() + per ray the number of samples its march emitted and a hash of their (dt, t - last_t) bits."""
+        opts = opts or nh.default_options()
+        cam, pose = _f32(cam).reshape(4), _f32(pose).reshape(16)
+        rgba = np.empty((H, W, 4), np.float32)
+        depth = np.empty((H, W), np.float32)
+        counts = np.empty((H, W), np.uint32)
+        hashes = np.empty((H, W), np.uint64)
+        st = nh.Stats()
+        _ck(self.L.nrfo_render_rays(self.h, _fp(cam), _fp(pose), W, H, C.byref(opts), schedule, n_threads, rgba.ctypes.data,
+                                    depth.ctypes.data, C.byref(st), counts.ctypes.data, hashes.ctypes.data))
+        return rgba, depth, st, counts, hashes
+
+    def render_per_ray_rounds(self, cam, pose, W, H, opts=None):
+        """SCHED_PER_RAY through the reference's global round loop (n_step fixed to 1): the cross-check of the independent-ray form."""
+        opts = opts or nh.default_options()
+        cam, pose = _f32(cam).reshape(4), _f32(pose).reshape(16)
+        rgba = np.empty((H, W, 4), np.float32)
+        depth = np.empty((H, W), np.float32)
+        st = nh.Stats()
+        _ck(self.L.nrfo_render_per_ray_rounds(self.h, _fp(cam), _fp(pose), W, H, C.byref(opts), rgba.ctypes.data, depth.ctypes.data,
+                                              C.byref(st)))
+        return rgba, depth, st
+
     def render(self, cam, pose, W, H, opts=None, schedule=SCHED_REFERENCE, n_threads=0):
         opts = opts or nh.default_options()
         cam, pose = _f32(cam).reshape(4), _f32(pose).reshape(16)
@@ -227,6 +269,10 @@ def quantize_u8(rgba, depth):
     d8 = np.empty(depth.shape, np.uint8)
     lib().nrfo_quantize_u8(rgba.ctypes.data, depth.ctypes.data, n, rgb8.ctypes.data, d8.ctypes.data)
     return rgb8, d8
+
+
+def fp16_backend() -> str:
+    return lib().nrfo_fp16_backend().decode()
 
 
 def f16(x):

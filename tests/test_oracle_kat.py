@@ -175,3 +175,13 @@ def test_quantize_u8_saturates():
     rgb8, d8 = op.quantize_u8(rgba, depth)
     assert rgb8.tolist() == [[0, 0, 127], [255, 255, 0], [254, 254, 255]]
     assert d8.tolist() == [63, 255, 0]
+
+
+def test_fp16_instructions_equal_the_software_definition():
+    """oracle/Makefile builds with -mf16c where the host has it (one instruction per conversion: the timed CPU baseline is
+    then not a software-float emulator).  The instruction forms against the bit-level software definition: all 2^16 halves
+    and every third of the 2^32 floats (NaN payloads included)."""
+    assert op.fp16_backend() in ("f16c", "software")
+    assert op.lib().nrfo_fp16_selfcheck(3) == 0
+    for x in (0.0, -0.0, 1.0, 65504.0, 65520.0, 2.0 ** -24, 2.0 ** -25, 3.0e-8, float("inf"), -1.5):
+        assert op.lib().nrfo_f32_to_f16(x) == op.lib().nrfo_f32_to_f16_soft(x)

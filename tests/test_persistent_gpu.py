@@ -297,3 +297,19 @@ def test_shard_without_a_strip_renders_nothing(model, env):
     desc, _ = model
     out = _render(desc, 11, 42, _poses("orbit", 2), env, shard=(7, 8))
     assert out[2] == 0 and np.all(out[0] == 7.0)  # no sample, no pixel touched
+
+
+@pytest.mark.parametrize("W,H,n", [(333, 211, 5), (640, 360, 3)])
+def test_transmittance_sample_cap_never_changes_a_pixel(W, H, n):
+    """The per-round sample queue by transmittance (FrameParams::sample_cap; the default 2 for launches of three views and
+    more, 0 = the full queue of eight for one or two): a ray queues fewer samples per round the less it can still absorb.
+    Per-ray semantics must not depend on it -- launches of 3+ views with NRF_SAMPLE_CAP = 0, 1, 2 (read at nrf_create:
+    separate contexts) give bit-identical float planes and equal composited-sample counts, at float-bit level (the golden
+    hashes and single-view references only ever exercise cap 0)."""
+    desc, keep, _ = models.build_model(log2_hashmap_size=19, H=128)
+    poses = _poses("orbit", n)
+    ref = _render(desc, W, H, poses, {"NRF_SAMPLE_CAP": "0"})
+    for cap in ("1", "2"):
+        _same(_render(desc, W, H, poses, {"NRF_SAMPLE_CAP": cap}), ref, (W, H, "cap " + cap))
+    # and the default context (cap 2 for this launch) is the same again
+    _same(_render(desc, W, H, poses, {}), ref, (W, H, "default"))
