@@ -467,6 +467,13 @@ int nrf_rb_clear_frame(nrf_render_buffer* rb, void* stream);               /* cl
 int nrf_rb_accumulate(nrf_render_buffer* rb, float exposure, void* stream);/* accumulate(): running mean     */
 int nrf_rb_tonemap(nrf_render_buffer* rb, float exposure, const float background_color[4],
                    int output_color_space, void* stream);                  /* tonemap()                      */
+/* accumulate() + tonemap() of the reference's per-frame sequence (main.cu:87-129, render_buffer.cu:590-627) as ONE pass over
+ * the planes: reads the frame (and the mean so far, unless this is the first sample), writes the new mean and the developed
+ * surface -- 64 B per pixel instead of 96 for the two calls; the planes hold the same bits as after nrf_rb_accumulate +
+ * nrf_rb_tonemap.  rgba8 (optional, device, uint32 [h][w]): the surface as 8-bit r | g << 8 | b << 16 | a << 24 (saturating,
+ * NaN -> 0: the library's 8-bit rule), what a display or an encoder takes; NULL: not written.                       */
+int nrf_rb_present(nrf_render_buffer* rb, float exposure, const float background_color[4],
+                   int output_color_space, void* rgba8, void* stream);
 /* host_to_accumulate_buffer(): rgb u8 [n][3] -> accumulate RGBA = rgb/255, a = 1 (render_buffer.h:231-241) */
 /* overlay_depth() (render_buffer.cu:431-477, 690-714): turbo-coloured depth (device float plane of
  * image_width x image_height, e.g. nrf_frame.depth) blended over the surface with weight alpha.     */

@@ -682,7 +682,7 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
                          : M.hot_grid ? (size_t)render_persistent_lds_fixed_bytes(0u, 0u, 0u, 16) : (size_t)render_persistent_lds_width_bytes((int)M.hot_width);
     if (fixed + tables <= 160u * 1024u) {
       M.persistent = 1;
-      M.persist_waves = M.wide_sh ? 8 : 16;
+      M.persist_waves = M.wide_sh ? 8 : (M.hot_width == 128 ? 12 : 16);  // nrf_render.h persist_waves(net)
       M.gen_weights_lds = 0;
       M.lds_dilated_words = (uint32_t)dilated.size();
       width_instance = true;
@@ -695,8 +695,15 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
     // (NRF_GEN_WLDS=0 at nrf_create: never stage the fragments)
     const bool allow_wlds = c->allow_gen_wlds;
     M.gen_weights_lds = 0;
-    for (int waves : {render_persistent_waves(M.generic, M.wide), 8}) {
-      if (waves == 8 && !M.generic) break;  // (only the generic instance has a second workgroup size)
+    // (the wide instance with the generic march -- a grid size or bound that is no power of two -- is compiled for 8 waves:
+    //  launch_render's choice of the march form, nrf_kernels_wide.hip)
+    int eb = 0;
+    const bool pow2_h = (M.H & (M.H - 1)) == 0;
+    const bool unit_march = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
+    const bool pow2_march = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+    const bool wide_generic_march = M.wide && !M.generic && !unit_march && !pow2_march;
+    for (int waves : {wide_generic_march ? WIDE_GENERIC_MARCH_WAVES : render_persistent_waves(M.generic, M.wide), 8}) {
+      if (waves == 8 && !M.generic && !wide_generic_march) break;  // (only the generic instance has a second workgroup size)
       const size_t fixed = (size_t)render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) + tables;
       for (int wlds : {1, 0}) {
         if (wlds && (!M.generic || !allow_wlds)) continue;
@@ -977,11 +984,12 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                        d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
                        (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                        d->sigma_activation == NRF_ACT_EXPONENTIAL && c->allow_width_instances;
-  // ... and for its grid: F = 2 with fewer than 16 levels, F = 4 / 8 with at most 32 features in all, Linear or Smoothstep, every
+  // ... and for its grid: F = 2 with fewer than 16 levels, F = 4 / 8 with at most 32 features in all, Linear, Smoothstep or -- any F = 2 /
+  // 4 / 8 grid of at most 32 features, the 16 x 2 one included -- Nearest (round 5: one gather per level, grid.h:215-232), every
   // level dense / power-of-two hashed / LV_ADD_POW2 -- the GRID instances (NET_GRID2 / 4 / 8) keep base.json's MLPs in registers
   const bool hot_grid_ok = !generic_grid && (F == 2 || F == 4 || F == 8) && !(F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR) && L * F <= 32 &&
                            Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 && dir_w == 16 &&
-                           (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP) &&
+                           (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP || d->interpolation == NRF_INTERP_NEAREST) &&
                            d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
                            (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                            d->sigma_activation == NRF_ACT_EXPONENTIAL && c->allow_width_instances;
@@ -1122,6 +1130,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   c->model_hot_grid = hot_grid;
   M.hot_grid = hot_grid;
   M.grid_smooth = d->interpolation == NRF_INTERP_SMOOTHSTEP ? 1u : 0u;
+  M.grid_nearest = d->interpolation == NRF_INTERP_NEAREST ? 1u : 0u;
   c->model_wide_sh = wide_sh;
   M.wide_sh = wide_sh ? 1u : 0u;
   M.dir_w = dir_w;
@@ -1273,7 +1282,12 @@ int render_views_impl(nrf_context* c, int n_views, const float* cams, const floa
   P.skip_outside = skip_outside;
   // one or two views alone are latency-bound, not throughput-bound: their last tiles end sooner when every ray queues its full
   // eight samples per round, and the few samples evaluated for nothing cost nobody anything (0.904 against 0.914 ms per 1080p view)
-  if (n_views <= 2 && !c->sample_cap_forced) P.sample_cap = 0;
+  // ... unless the launch has fewer tiles than the chip has waves: it is ALL tail (idle waves take rays off the rendering ones from
+  // the first round on, and every split group queues its own eight samples per ray behind a terminating one) -- small frames
+  // keep the transmittance-dependent queue, which holds their evaluated samples within 15 % of the composited ones
+  // (tests/test_parity_gpu.py, test_generic_gpu.py, test_golden.py; pixels cannot depend on it: tests/test_persistent_gpu.py)
+  const bool all_tail = (long long)c->n_local_tiles * n_views < (long long)c->dm.n_cus * std::max(1u, c->dm.persist_waves);
+  if (n_views <= 2 && !c->sample_cap_forced && !all_tail) P.sample_cap = 0;
   c->call_index = (c->call_index + 1) % CALL_RING;
   char* counters = call_slot(c, c->call_index);
   unsigned* plan = (c->plan_max_pos > 0 && prog == nullptr) ? (unsigned*)((char*)c->d_plan + (size_t)c->call_index * PLAN_BYTES) : nullptr;

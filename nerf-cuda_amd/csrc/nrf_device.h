@@ -151,6 +151,7 @@ struct DevModel {
                             // features in all, Linear or Smoothstep -- in front of base.json's MLPs: the register-resident GRID instance
                             // (NET_GRID2 / 4 / 8, persistent kernel only; fragments in wfrag_hot with that grid's K order)
   uint32_t grid_smooth;     // the grid interpolates with Smoothstep (GRID instances)
+  uint32_t grid_nearest;    // InterpolationType::Nearest (grid.h:215-232): the entry at floor(pos), no weights -- ONE gather per level (GRID instances)
   uint32_t wide_sh;         // SphericalHarmonics of degree 5..8 on the base.json shape: NET_WIDE_SH renders the frames (persistent kernel)
   uint32_t dir_w;           // padded width of the direction encoding (16 .. 80)
 };
@@ -896,6 +897,34 @@ __device__ __forceinline__ void level_interp_wide(const uint32_t (&v)[8 * DW], c
   }
 #pragma unroll
   for (int e = 0; e < DW; ++e) out[e] = h2_bits(acc[e]);
+}
+
+// InterpolationType::Nearest (T/.../grid.h:215-232): a level's features ARE the entry at floor(pos) -- one aligned gather of the
+// whole entry (4 / 8 / 16 bytes for F = 2 / 4 / 8), no weights, no arithmetic on the values.  The index is corner 0 of
+// level_offsets (the other seven are dead code here).
+template <int UNI, int DW>
+__device__ __forceinline__ void level_nearest(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                              float py, float pz, uint32_t (&out)[DW]) {
+  static_assert(DW == 1 || DW == 2 || DW == 4, "F = 2, 4 or 8");
+  uint32_t off[8];
+  float frac[3];
+  level_offsets<UNI, DW == 1 ? 2 : (DW == 2 ? 3 : 4)>(L, px, py, pz, off, frac);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (DW == 1) {
+    out[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[0], 0, 0);
+  } else if constexpr (DW == 2) {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off[0], 0, 0);
+    out[0] = w.x;
+    out[1] = w.y;
+  } else {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[0], 0, 0);
+    out[0] = w.x;
+    out[1] = w.y;
+    out[2] = w.z;
+    out[3] = w.w;
+  }
 }
 
 // Smoothstep interpolation (grid.h InterpolationType::Smoothstep): val * val * (3 - 2 val) on the fractions, T/.../common_device.h:379-381

@@ -52,7 +52,22 @@ __global__ __launch_bounds__(256) void gen_encode_grid_kernel(const DevModel M, 
       float fr[3];
       uint32_t o[4] = {0u, 0u, 0u, 0u};
       const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
-      if (M.hot_grid == 2u) {
+      if (M.grid_nearest) {
+        if (M.hot_grid == 2u) {
+          uint32_t q[1];
+          if (uni == 2u) level_nearest<2, 1>(M.grid, M.grid_bytes, lvs[level], px, py, pz, q);
+          else level_nearest<0, 1>(M.grid, M.grid_bytes, lvs[level], px, py, pz, q);
+          o[0] = q[0];
+        } else if (M.hot_grid == 4u) {
+          uint32_t q[2];
+          if (uni == 2u) level_nearest<2, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, q);
+          else level_nearest<0, 2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, q);
+          o[0] = q[0]; o[1] = q[1];
+        } else {
+          if (uni == 2u) level_nearest<2, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, o);
+          else level_nearest<0, 4>(M.grid, M.grid_bytes, lvs[level], px, py, pz, o);
+        }
+      } else if (M.hot_grid == 2u) {
         uint32_t v[8];
         if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
         else level_gather<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
@@ -126,8 +141,12 @@ struct RegFrags {  // the lane's weight fragments, held in registers for the ker
   const half8_t* w;
   __device__ __forceinline__ half8_t operator()(int f) const { return w[f]; }
 };
-template <bool REPEAT>
-__global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
+// OCC: workgroups of 4 waves per compute unit the registers are budgeted for (3: 168 VGPRs, 2: 256); NAMED: the three row
+// buffers rotate by name (loop unrolled three times) instead of by copying registers -- see below.  The shipped form is
+// chosen in launch_mlp_forward (NRF_MLP_FORM for A/B runs).
+constexpr int MLP_FORM_DEFAULT = 30;
+template <bool REPEAT, int OCC = 3, bool NAMED = false>
+__global__ __launch_bounds__(256, OCC) void mlp_forward_kernel(const DevModel M, const uint4* __restrict__ feat,
                                                           const uint2* __restrict__ dirfeat, uint32_t n,
                                                           half_t* __restrict__ out, uint32_t repeat) {
   constexpr int T = MLP_TILES, CH = 16 * T;
@@ -138,8 +157,12 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
   const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t n_chunks = (n + CH - 1) / CH;
-  uint4 fv[T], fnext[T], fnext2[T];
-  uint2 dv[T], dnext[T], dnext2[T];
+  // Three row buffers in rotation: while chunk i is evaluated out of one, chunk i + 1 waits in the second and the loads of chunk
+  // i + 2 fly into the third.  The rotation is by NAME (the loop is unrolled three times, each copy with its own roles), not by
+  // copying registers: a copy `next = next2` at the loop's end makes the wave wait for loads it has only just issued
+  // (s_waitcnt vmcnt(0) at every latch: round 4's form -- the prefetch reached one chunk ahead, not two).
+  uint4 fb[3][T];
+  uint2 db[3][T];
   if (n == 0) return;
   // rows past the end (the last chunk's padding, the prefetches beyond the last chunk) read row n - 1 instead: no
   // predication, no zero fill (85 v_mov per trip before) -- their results are never stored
@@ -152,10 +175,9 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
       d[t] = dirfeat[(size_t)s * 4 + g];  // entries 4g..4g+3
     }
   };
-  load_chunk(wave_global, fv, dv);
-  load_chunk(wave_global + n_waves, fnext, dnext);
-  for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
-    load_chunk(chunk + 2 * n_waves, fnext2, dnext2);  // two chunks ahead: in flight during the MFMAs of this one and the next
+  // one chunk: its rows are in (fv, dv); the loads of the chunk two steps ahead go to (fl, dl)
+  auto step = [&](uint32_t chunk, uint4 (&fv)[T], uint2 (&dv)[T], uint4 (&fl)[T], uint2 (&dl)[T]) {
+    load_chunk(chunk + 2 * n_waves, fl, dl);  // in flight during the MFMAs of this chunk and the next
     half8_t f[T];
     half4_t df[T];
 #pragma unroll
@@ -191,13 +213,31 @@ __global__ __launch_bounds__(256, 3) void mlp_forward_kernel(const DevModel M, c
       const uint32_t sigma_bits = (uint32_t)__builtin_bit_cast(unsigned short, o.sigma);
       if (s < n) *reinterpret_cast<uint2*>(out + 4 * (size_t)s) = make_uint2(rg_row, (bx_row & 0xffffu) | (sigma_bits << 16));
     }
+  };
+  load_chunk(wave_global, fb[0], db[0]);
+  load_chunk(wave_global + n_waves, fb[1], db[1]);
+  if constexpr (!NAMED) {  // rotation by copies (rounds 1-4)
+    for (uint32_t chunk = wave_global; chunk < n_chunks; chunk += n_waves) {
+      step(chunk, fb[0], db[0], fb[2], db[2]);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      fv[t] = fnext[t];
-      dv[t] = dnext[t];
-      fnext[t] = fnext2[t];
-      dnext[t] = dnext2[t];
+      for (int t = 0; t < T; ++t) {
+        fb[0][t] = fb[1][t];
+        db[0][t] = db[1][t];
+        fb[1][t] = fb[2][t];
+        db[1][t] = db[2][t];
+      }
     }
+    return;
+  }
+  for (uint32_t chunk = wave_global; chunk < n_chunks;) {
+    step(chunk, fb[0], db[0], fb[2], db[2]);
+    chunk += n_waves;
+    if (chunk >= n_chunks) break;
+    step(chunk, fb[1], db[1], fb[0], db[0]);
+    chunk += n_waves;
+    if (chunk >= n_chunks) break;
+    step(chunk, fb[2], db[2], fb[1], db[1]);
+    chunk += n_waves;
   }
 }
 
@@ -806,10 +846,25 @@ hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* d
     return hipGetLastError();
   }
   const uint64_t chunks = ((uint64_t)n + 16 * MLP_TILES - 1) / (16 * MLP_TILES);
-#define NRF_LAUNCH_MLP(R)                                                                                                \
-  hipLaunchKernelGGL((mlp_forward_kernel<R>), dim3(grid_for(chunks, 4, 256 * 3)), dim3(256), 0, st, M,                  \
+  // the kernel's form: workgroups per CU its registers are budgeted for x how the prefetch buffers rotate (mlp_forward_kernel).
+  // NRF_MLP_FORM = 30 (3 per CU, copies: rounds 1-4) | 20 | 21 (2 per CU, by name) -- A/B runs; default: MLP_FORM_DEFAULT.
+  // (3 per CU by name needs 176 registers: built, it spilled 8-11 of them -- not shipped)
+  static const int form = [] {
+    const char* e = std::getenv("NRF_MLP_FORM");
+    const int f = e ? std::atoi(e) : MLP_FORM_DEFAULT;
+    return (f == 30 || f == 20 || f == 21) ? f : MLP_FORM_DEFAULT;
+  }();
+#define NRF_LAUNCH_MLP(R, OCC, NAMED)                                                                                     \
+  hipLaunchKernelGGL((mlp_forward_kernel<R, OCC, NAMED>), dim3(grid_for(chunks, 4, 256 * OCC)), dim3(256), 0, st, M,      \
                      (const uint4*)feat, (const uint2*)dirfeat, n, (half_t*)out, repeat)
-  if (repeat > 1) NRF_LAUNCH_MLP(true); else NRF_LAUNCH_MLP(false);
+#define NRF_LAUNCH_MLP_FORM(R)                                                                                            \
+  do {                                                                                                                    \
+    if (form == 20) NRF_LAUNCH_MLP(R, 2, false);                                                                          \
+    else if (form == 21) NRF_LAUNCH_MLP(R, 2, true);                                                                      \
+    else NRF_LAUNCH_MLP(R, 3, false);                                                                                     \
+  } while (0)
+  if (repeat > 1) NRF_LAUNCH_MLP_FORM(true); else NRF_LAUNCH_MLP_FORM(false);
+#undef NRF_LAUNCH_MLP_FORM
 #undef NRF_LAUNCH_MLP
   return hipGetLastError();
 }

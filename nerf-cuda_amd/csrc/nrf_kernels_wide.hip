@@ -10,7 +10,7 @@ hipError_t launch_persistent_wide(const PersistLaunch& L) {
   } else {
     if (L.unit) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_UNIT);
     else if (L.pow2) NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_POW2);
-    else NRF_LAUNCH_PERSISTENT(NET_WIDE, MARCH_GENERIC);
+    else NRF_LAUNCH_PERSISTENT_W(NET_WIDE, MARCH_GENERIC, WIDE_GENERIC_MARCH_WAVES, false);  // (nrf_api.hip sets persist_waves alike)
   }
   return hipGetLastError();
 }

@@ -12,6 +12,7 @@ struct ViewBatch;
 // the persistent kernel's work-queue counters follow the statistics counters (counters + COUNTER_BYTES); queues_are_zero:
 // the caller has just cleared them together with the statistics
 constexpr int RENDER_QUEUE_BYTES = 8 * 4;
+constexpr int WIDE_GENERIC_MARCH_WAVES = 8;  // waves of the persistent workgroup of NET_WIDE with the generic march (nrf_render.h persist_waves)
 hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatch& VB, void* rgba, void* depth, void* counters,
                          hipStream_t st, bool first_launch, unsigned* plan = nullptr, unsigned plan_cap = 0);
 // a call's plan buffer (plan_price_kernel / plan_sort_kernel): 4 header words + a price and an order entry per queue position

@@ -119,36 +119,60 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 template <int GF>
 __device__ __forceinline__ void grid_features(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]) {
   constexpr int LPL = 8 / GF, DW = GF / 2;  // levels per lane, dwords per entry
-  uint32_t gv[LPL][8 * DW];
-  float gf[LPL][3];
+  if (M.grid_nearest) {  // wave-uniform.  Nearest (grid.h:215-232): one gather per level, the entry is the result
 #pragma unroll
-  for (int jl = 0; jl < LPL; ++jl) {
-    const uint32_t lv = (uint32_t)(4 * jl + g);
-    if (lv < M.n_levels) {  // (masked lanes cost the texture path nothing)
-      const LevelParams L = lvs[lv];
-      const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;  // the group's existing levels are all dense (1) / all hashed (2): wave-uniform
-      if constexpr (GF == 2) {
-        // (all three specialisations side by side over four masked levels cost this instance 8 VGPRs of spills: the hashed and the mixed form)
-        if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-      } else {
-        if (uni == 2u) level_gather_wide<2, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else if (uni == 1u) level_gather_wide<1, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else level_gather_wide<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-      }
-      if (M.grid_smooth) smoothstep_fractions(gf[jl]);  // wave-uniform
-    }
-  }
-#pragma unroll
-  for (int jl = 0; jl < LPL; ++jl) {
-    const uint32_t lv = (uint32_t)(4 * jl + g);
-    if (lv < M.n_levels) {
-      if constexpr (GF == 2) fb[jl] = level_interp<false>(gv[jl], gf[jl]);
-      else {
+    for (int jl = 0; jl < LPL; ++jl) {
+      const uint32_t lv = (uint32_t)(4 * jl + g);
+      if (lv < M.n_levels) {
+        const LevelParams L = lvs[lv];
+        const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
         uint32_t o[DW];
-        level_interp_wide<DW>(gv[jl], gf[jl], o);
+        if (uni == 2u) level_nearest<2, DW>(M.grid, M.grid_bytes, L, px, py, pz, o);
+        else level_nearest<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, o);
 #pragma unroll
         for (int e = 0; e < DW; ++e) fb[DW * jl + e] = o[e];
+      }
+    }
+    return;
+  }
+  // F = 2 holds four levels per lane: their gathers go out in two batches of two (16 dwords in flight, not 32).  All four at
+  // once -- masked per level, with two index forms side by side -- spilled 8 to 21 VGPRs in these instances; a grid of up
+  // to eight levels never reaches the second batch.
+  constexpr int BATCH = GF == 2 ? 2 : LPL;
+#pragma unroll
+  for (int j0 = 0; j0 < LPL; j0 += BATCH) {
+    uint32_t gv[BATCH][8 * DW];
+    float gf[BATCH][3];
+#pragma unroll
+    for (int jb = 0; jb < BATCH; ++jb) {
+      const int jl = j0 + jb;
+      const uint32_t lv = (uint32_t)(4 * jl + g);
+      if (lv < M.n_levels) {  // (masked lanes cost the texture path nothing)
+        const LevelParams L = lvs[lv];
+        const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;  // the group's existing levels are all dense (1) / all hashed (2): wave-uniform
+        if constexpr (GF == 2) {
+          if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+          else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+        } else {
+          if (uni == 2u) level_gather_wide<2, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+          else if (uni == 1u) level_gather_wide<1, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+          else level_gather_wide<0, DW>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+        }
+        if (M.grid_smooth) smoothstep_fractions(gf[jb]);  // wave-uniform
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < BATCH; ++jb) {
+      const int jl = j0 + jb;
+      const uint32_t lv = (uint32_t)(4 * jl + g);
+      if (lv < M.n_levels) {
+        if constexpr (GF == 2) fb[jl] = level_interp<false>(gv[jb], gf[jb]);
+        else {
+          uint32_t o[DW];
+          level_interp_wide<DW>(gv[jb], gf[jb], o);
+#pragma unroll
+          for (int e = 0; e < DW; ++e) fb[DW * jl + e] = o[e];
+        }
       }
     }
   }
@@ -1070,8 +1094,13 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
 // workgroup visits every class once); no wave waits for another one after the staging barrier, except -- for the
 // length of one device atomic -- for the wave of its workgroup that is fetching the next strip.
 // waves of the persistent workgroup: what the instance's registers allow per SIMD (x 4 SIMDs) -- hot: <= 128 VGPRs, 4 per
-// SIMD; wide: <= 168, 3; generic: 3 per SIMD when the LDS rows of 12 waves fit beside the march tables, else 2
-__host__ __device__ constexpr int persist_waves(int net) { return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE) ? 12 : 16); }
+// SIMD; wide and the 128-neuron form: <= 168, 3 (round 5: at 4 per SIMD NET_W128 spilled a register); generic: 3 per SIMD when
+// the LDS rows of 12 waves fit beside the march tables, else 2.  NET_WIDE with the generic march runs 8 (WIDE_GENERIC_MARCH_WAVES:
+// at 12 it spilled 1-6 registers) -- no shipped instance has scratch (tests/test_abi_cpu.py).
+__host__ __device__ constexpr int persist_waves(int net) {
+  return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE || net == NET_W128) ? 12 : 16);
+}
+// (WIDE_GENERIC_MARCH_WAVES: nrf_launch.h -- the host sizes the workgroup with it as well)
 constexpr int LDS_CLOCK_BYTES = 16;  // wave 0's entry stamps (core-clock counter, 100 MHz counter), see shader_clock_mhz
 constexpr int LDS_QUEUE_BYTES = (MAX_VIEWS + 2) * 4 + 80 + LDS_CLOCK_BYTES;  // q_begin of every view + the total; the workgroup's block counter; HelpLds; the clock stamps
 static_assert(sizeof(HelpLds) + LDS_CLOCK_BYTES <= 80 + LDS_CLOCK_BYTES, "HelpLds and the clock stamps live behind the scheduler word");

@@ -1,9 +1,17 @@
-// nrf_renderbuffer.hip -- the presentation chain of the reference's CudaRenderBuffer on gfx950:
-// accumulate (running mean over spp), tonemap (background blend, exposure, curve, sRGB).
-// Reference: R/src/render_buffer.cu:224-259 (accumulate_kernel), :261-342 (tonemap), :529-556
-// (tonemap_kernel), :590-627 (host methods); colour helpers R/include/nerf-cuda/common_device.cuh:38-60.
-// Both kernels are pure HBM streams (32 B read + 16 B written per pixel); one thread per pixel,
-// 16-byte accesses.
+// nrf_renderbuffer.hip -- the presentation chain behind the reference's CudaRenderBuffer on gfx950.
+//
+// What the reference does with a rendered frame (R/src/render_buffer.cu): fold it into a running mean over samples per
+// pixel (accumulate, :224-259, :590-609), then develop that mean for display -- background blend, exposure, film curve,
+// transfer function (tonemap, :261-342, :529-556, :611-627) -- two launches that each read and write whole planes
+// (32 B read + 16 B written per pixel, twice).  Here the chain is ONE streaming pass, `present_kernel`: per pixel it reads
+// the frame (and the mean so far, unless this is the first sample: nothing is cleared, nothing is read), writes the new
+// mean, develops it in registers and writes the surface -- plus, on request, the surface as packed 8-bit RGBA, which is what
+// a display or an encoder takes.  64 B per pixel (48 for the first sample) instead of 96 (+ a 16 B clear).  The two halves
+// stay available on their own (nrf_rb_accumulate / nrf_rb_tonemap: the reference's call shape) as instances of the same
+// kernel, so the fused pass is bit-identical to the two calls by construction.
+// Everything that does not depend on the pixel is settled on the host once per call: 2^exposure, the background in the
+// render colour space, the coefficients of the film curve (`FilmCurve`: identity, Reinhard, or a ratio of two quadratics --
+// ACES and Hable differ only in six numbers).  A pure stream over 16-byte pixels: one lane per pixel, grid-stride.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -18,87 +26,139 @@ namespace {
 thread_local std::string g_rb_err;
 extern "C" const char* nrf_last_error(void);
 
-__host__ __device__ inline float srgb_to_linear1(float srgb) {
-  return srgb <= 0.04045f ? srgb / 12.92f : powf((srgb + 0.055f) / 1.055f, 2.4f);
-}
-__host__ __device__ inline float linear_to_srgb1(float linear) {
-  return linear < 0.0031308f ? 12.92f * linear : 1.055f * powf(linear, 0.41666f) - 0.055f;
+// the sRGB transfer pair as the reference states it (R/include/nerf-cuda/common_device.cuh:38-60: note the 0.41666 exponent)
+__host__ __device__ inline float decode_srgb(float v) { return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); }
+__host__ __device__ inline float encode_srgb(float v) { return v < 0.0031308f ? 12.92f * v : 1.055f * powf(v, 0.41666f) - 0.055f; }
+
+// A film curve, reduced on the host to what the pixel loop needs.  RATIONAL: y = (x^2 n2 + n1 x + n0) / (d2 x^2 + d1 x + d0)
+// on max(x, 0) per channel (operation order as written: it is part of the contract with the oracle); LUMA: Reinhard's
+// x / (1 + Y) on max(x, 0) with Y the Rec. 709 luminance.
+enum : int { CURVE_NONE = 0, CURVE_RATIONAL = 1, CURVE_LUMA = 2 };
+struct FilmCurve {
+  int kind;
+  float n2, n1, n0, d2, d1, d0;
+};
+FilmCurve film_curve(int tonemap) {  // render_buffer.cu:261-318, the constants of its two rational curves
+  FilmCurve f{CURVE_NONE, 0, 0, 0, 0, 0, 0};
+  if (tonemap == NRF_TM_ACES) {  // Narkowicz's fit, pre-scaled by 0.6
+    f = {CURVE_RATIONAL, 0.6f * 0.6f * 2.51f, 0.6f * 0.03f, 0.0f, 0.6f * 0.6f * 2.43f, 0.6f * 0.59f, 0.14f};
+  } else if (tonemap == NRF_TM_HABLE) {  // Hable's filmic operator, normalised so that the white point 11.2 maps to 1
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f, white = 11.2f;
+    float n2 = A * F - A * E, n1 = C * B * F - B * E, n0 = 0.0f;
+    float d2 = A * F, d1 = B * F;
+    const float d0 = D * F * F;
+    const float at_white_n = n2 * (white * white) + n1 * white + n0;
+    const float at_white_d = d2 * (white * white) + d1 * white + d0;
+    const float norm = at_white_d / at_white_n;
+    f = {CURVE_RATIONAL, 4.0f * n2 * norm, 2.0f * n1 * norm, n0 * norm, 4.0f * d2, 2.0f * d1, d0};
+  } else if (tonemap == NRF_TM_REINHARD) {
+    f.kind = CURVE_LUMA;
+  }
+  return f;
 }
 
-__device__ inline void tonemap_curve(float c[3], int curve) {  // render_buffer.cu:261-318
-  if (curve == NRF_TM_IDENTITY) return;
-  for (int i = 0; i < 3; ++i) c[i] = fmaxf(c[i], 0.f);
-  float k0, k1, k2, k3, k4, k5;
-  if (curve == NRF_TM_ACES) {
-    k0 = 0.6f * 0.6f * 2.51f; k1 = 0.6f * 0.03f; k2 = 0.0f;
-    k3 = 0.6f * 0.6f * 2.43f; k4 = 0.6f * 0.59f; k5 = 0.14f;
-  } else if (curve == NRF_TM_HABLE) {
-    const float A = 0.15f, B = 0.50f, Cc = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
-    k0 = A * F - A * E; k1 = Cc * B * F - B * E; k2 = 0.0f;
-    k3 = A * F; k4 = B * F; k5 = D * F * F;
-    const float Wt = 11.2f;
-    const float nom = k0 * (Wt * Wt) + k1 * Wt + k2;
-    const float denom = k3 * (Wt * Wt) + k4 * Wt + k5;
-    const float white_scale = denom / nom;
-    k0 = 4.0f * k0 * white_scale; k1 = 2.0f * k1 * white_scale; k2 = k2 * white_scale;
-    k3 = 4.0f * k3; k4 = 2.0f * k4;
-  } else {  // Reinhard
-    const float Y = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2];
-    const float s = 1.f / (Y + 1.0f);
-    for (int i = 0; i < 3; ++i) c[i] = c[i] * s;
-    return;
+// one call's pixel-independent state
+struct PresentArgs {
+  int n;
+  float samples_so_far;  // the mean in the accumulate plane is over this many frames (0: the plane's content is ignored)
+  float gain;            // 2^exposure
+  float4 backdrop;       // the background colour in the RENDER colour space, alpha untouched
+  int render_space, display_space;  // NRF_CS_*
+  int clamp_display;
+  FilmCurve film;
+};
+
+// fold one frame sample into the mean over `k` earlier ones: (mean * k + x) / (k + 1)
+__device__ __forceinline__ float fold1(float mean, float x, float k) { return (mean * k + x) / (k + 1); }
+__device__ __forceinline__ float4 fold_sample(float4 mean, float4 x, const PresentArgs& A) {
+  const float k = A.samples_so_far;
+  if (A.render_space == NRF_CS_VISPOSNEG) {  // a signed quantity kept as (positive part, negative part) in r, g; b is left alone
+    const float signed_mean = fold1(mean.x - mean.y, x.x - x.y, k);
+    mean.x = fmaxf(signed_mean, 0.0f);
+    mean.y = fmaxf(-signed_mean, 0.0f);
+  } else {
+    if (A.render_space == NRF_CS_SRGB) {  // the mean is kept in display-referred values
+      x.x = encode_srgb(x.x);
+      x.y = encode_srgb(x.y);
+      x.z = encode_srgb(x.z);
+    }
+    mean.x = fold1(mean.x, x.x, k);
+    mean.y = fold1(mean.y, x.y, k);
+    mean.z = fold1(mean.z, x.z, k);
   }
-  for (int i = 0; i < 3; ++i) {
-    const float sq = c[i] * c[i];
-    c[i] = (sq * k0 + k1 * c[i] + k2) / (k3 * sq + k4 * c[i] + k5);
-  }
+  mean.w = fold1(mean.w, x.w, k);
+  return mean;
 }
 
-__global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __restrict__ frame, float4* __restrict__ accum,
-                                                         float sample_count, int color_space) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 color = frame[i];
-    float4 tmp = accum[i];
-    if (color_space == NRF_CS_VISPOSNEG) {
-      const float val = color.x - color.y;
-      float tmp_val = tmp.x - tmp.y;
-      tmp_val = (tmp_val * sample_count + val) / (sample_count + 1);
-      tmp.x = fmaxf(tmp_val, 0.0f);
-      tmp.y = fmaxf(-tmp_val, 0.0f);
+// the mean as it goes to the display: over the backdrop, exposed, through the film curve, in the display's transfer function
+__device__ __forceinline__ float4 develop(float4 mean, const PresentArgs& A) {
+  const float uncovered = (1 - mean.w) * A.backdrop.w;
+  float c[3] = {mean.x + A.backdrop.x * uncovered, mean.y + A.backdrop.y * uncovered, mean.z + A.backdrop.z * uncovered};
+  const float alpha = mean.w + uncovered;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (A.render_space == NRF_CS_SRGB) c[k] = decode_srgb(c[k]);
+    c[k] *= A.gain;
+  }
+  if (A.film.kind != CURVE_NONE) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = fmaxf(c[k], 0.f);
+    if (A.film.kind == CURVE_LUMA) {
+      const float scale = 1.f / ((0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]) + 1.0f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c[k] = c[k] * scale;
     } else {
-      if (color_space == NRF_CS_SRGB) {
-        color.x = linear_to_srgb1(color.x); color.y = linear_to_srgb1(color.y); color.z = linear_to_srgb1(color.z);
+      const FilmCurve& f = A.film;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float sq = c[k] * c[k];
+        c[k] = (sq * f.n2 + f.n1 * c[k] + f.n0) / (f.d2 * sq + f.d1 * c[k] + f.d0);
       }
-      tmp.x = (tmp.x * sample_count + color.x) / (sample_count + 1);
-      tmp.y = (tmp.y * sample_count + color.y) / (sample_count + 1);
-      tmp.z = (tmp.z * sample_count + color.z) / (sample_count + 1);
     }
-    tmp.w = (tmp.w * sample_count + color.w) / (sample_count + 1);
-    accum[i] = tmp;
   }
+  float4 out = make_float4(c[0], c[1], c[2], alpha);
+  if (A.display_space == NRF_CS_SRGB) {
+    out.x = encode_srgb(out.x);
+    out.y = encode_srgb(out.y);
+    out.z = encode_srgb(out.z);
+  }
+  if (A.clamp_display) {
+    out.x = fminf(fmaxf(out.x, 0.f), 1.f);
+    out.y = fminf(fmaxf(out.y, 0.f), 1.f);
+    out.z = fminf(fmaxf(out.z, 0.f), 1.f);
+    out.w = fminf(fmaxf(out.w, 0.f), 1.f);
+  }
+  return out;
 }
 
-__global__ __launch_bounds__(256) void tonemap_kernel(int n, float exposure, float4 bg, const float4* __restrict__ accum,
-                                                      int color_space, int output_color_space, int curve,
-                                                      bool clamp_output_color, float4* __restrict__ surface) {
-  // The background color is represented in SRGB, so convert to linear if that's not the rendering space.
-  if (color_space != NRF_CS_SRGB) { bg.x = srgb_to_linear1(bg.x); bg.y = srgb_to_linear1(bg.y); bg.z = srgb_to_linear1(bg.z); }
-  const float gain = powf(2.0f, exposure);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 color = accum[i];
-    const float weight = (1 - color.w) * bg.w;
-    float c[3] = {color.x + bg.x * weight, color.y + bg.y * weight, color.z + bg.z * weight};
-    color.w += weight;
-    if (color_space == NRF_CS_SRGB) for (int k = 0; k < 3; ++k) c[k] = srgb_to_linear1(c[k]);
-    for (int k = 0; k < 3; ++k) c[k] *= gain;
-    tonemap_curve(c, curve);
-    if (output_color_space == NRF_CS_SRGB) for (int k = 0; k < 3; ++k) c[k] = linear_to_srgb1(c[k]);
-    float4 o = make_float4(c[0], c[1], c[2], color.w);
-    if (clamp_output_color) {
-      o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
-      o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+// the library's 8-bit rule (nrf_render.h quant_u8, the reference's (unsigned char)(255.0 * x) made safe: saturating, NaN -> 0)
+__device__ __forceinline__ uint32_t to_u8(float v) {
+  const double s = 255.0 * (double)v;
+  if (!(s > 0.0)) return 0u;
+  if (s >= 255.0) return 255u;
+  return (uint32_t)s;
+}
+
+// FOLD: frame -> mean; DEVELOP: mean -> surface (+ PACK8: the surface as r | g << 8 | b << 16 | a << 24); both: one pass
+enum : int { PASS_FOLD = 1, PASS_DEVELOP = 2 };
+template <int PASSES, bool PACK8>
+__global__ __launch_bounds__(256) void present_kernel(const PresentArgs A, const float4* __restrict__ frame, float4* __restrict__ mean_plane,
+                                                      float4* __restrict__ surface, uint32_t* __restrict__ rgba8) {
+  const bool first = A.samples_so_far == 0.0f;  // wave-uniform: the mean plane is write-only for the first sample
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
+    float4 mean;
+    if constexpr ((PASSES & PASS_FOLD) != 0) {
+      const float4 x = frame[i];
+      mean = fold_sample(first ? make_float4(0.f, 0.f, 0.f, 0.f) : mean_plane[i], x, A);
+      mean_plane[i] = mean;
+    } else {
+      mean = mean_plane[i];
     }
-    surface[i] = o;
+    if constexpr ((PASSES & PASS_DEVELOP) != 0) {
+      const float4 out = develop(mean, A);
+      surface[i] = out;
+      if constexpr (PACK8) rgba8[i] = to_u8(out.x) | (to_u8(out.y) << 8) | (to_u8(out.z) << 16) | (to_u8(out.w) << 24);
+    }
   }
 }
 
@@ -216,13 +276,42 @@ int nrf_rb_clear_frame(nrf_render_buffer* rb, void* stream) {
   return NRF_OK;
 }
 
+}  // extern "C"
+namespace {
+// the whole launch of one call: grid sized for the plane, every pixel-independent value fixed here
+template <int PASSES>
+int launch_present(nrf_render_buffer* rb, hipStream_t st, float exposure, const float bg[4], int display_space, void* rgba8) {
+  PresentArgs A{};
+  A.n = rb->W * rb->H;
+  A.samples_so_far = (float)rb->spp;
+  A.gain = powf(2.0f, exposure);
+  A.render_space = rb->color_space;
+  A.display_space = display_space;
+  A.clamp_display = 0;
+  A.film = film_curve(rb->curve);
+  A.backdrop = bg ? make_float4(bg[0], bg[1], bg[2], bg[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rb->color_space != NRF_CS_SRGB) {  // backgrounds are given display-referred: into the render space once, on the host
+    A.backdrop.x = decode_srgb(A.backdrop.x);
+    A.backdrop.y = decode_srgb(A.backdrop.y);
+    A.backdrop.z = decode_srgb(A.backdrop.z);
+  }
+  const dim3 grid(rb_grid(A.n)), block(256);
+  if (rgba8) hipLaunchKernelGGL((present_kernel<PASSES, true>), grid, block, 0, st, A, (const float4*)rb->frame, (float4*)rb->accum,
+                                (float4*)rb->surface, (uint32_t*)rgba8);
+  else hipLaunchKernelGGL((present_kernel<PASSES, false>), grid, block, 0, st, A, (const float4*)rb->frame, (float4*)rb->accum,
+                          (float4*)rb->surface, (uint32_t*)nullptr);
+  RB_TRY(hipGetLastError());
+  return NRF_OK;
+}
+}  // namespace
+extern "C" {
+
 int nrf_rb_accumulate(nrf_render_buffer* rb, float exposure, void* stream) {
   (void)exposure;  // unused in the reference as well (render_buffer.cu:595)
   RB_READY();
-  if (rb->spp == 0) RB_TRY(hipMemsetAsync(rb->accum, 0, (size_t)n * 16, st));
-  hipLaunchKernelGGL(accumulate_kernel, dim3(rb_grid(n)), dim3(256), 0, st, n, (const float4*)rb->frame, (float4*)rb->accum,
-                     (float)rb->spp, rb->color_space);
-  RB_TRY(hipGetLastError());
+  (void)n;
+  const int rc = launch_present<PASS_FOLD>(rb, st, 0.0f, nullptr, NRF_CS_LINEAR, nullptr);
+  if (rc != NRF_OK) return rc;
   ++rb->spp;
   if (!stream) RB_TRY(hipStreamSynchronize(st));
   return NRF_OK;
@@ -231,9 +320,20 @@ int nrf_rb_accumulate(nrf_render_buffer* rb, float exposure, void* stream) {
 int nrf_rb_tonemap(nrf_render_buffer* rb, float exposure, const float bg[4], int output_color_space, void* stream) {
   if (!bg || output_color_space < 0 || output_color_space > 2) return rb_fail(NRF_E_INVALID, "bad argument");
   RB_READY();
-  hipLaunchKernelGGL(tonemap_kernel, dim3(rb_grid(n)), dim3(256), 0, st, n, exposure, make_float4(bg[0], bg[1], bg[2], bg[3]),
-                     (const float4*)rb->accum, rb->color_space, output_color_space, rb->curve, false, (float4*)rb->surface);
-  RB_TRY(hipGetLastError());
+  (void)n;
+  const int rc = launch_present<PASS_DEVELOP>(rb, st, exposure, bg, output_color_space, nullptr);
+  if (rc != NRF_OK) return rc;
+  if (!stream) RB_TRY(hipStreamSynchronize(st));
+  return NRF_OK;
+}
+
+int nrf_rb_present(nrf_render_buffer* rb, float exposure, const float bg[4], int output_color_space, void* rgba8, void* stream) {
+  if (!bg || output_color_space < 0 || output_color_space > 2) return rb_fail(NRF_E_INVALID, "bad argument");
+  RB_READY();
+  (void)n;
+  const int rc = launch_present<PASS_FOLD | PASS_DEVELOP>(rb, st, exposure, bg, output_color_space, rgba8);
+  if (rc != NRF_OK) return rc;
+  ++rb->spp;
   if (!stream) RB_TRY(hipStreamSynchronize(st));
   return NRF_OK;
 }

@@ -50,6 +50,10 @@ class RenderBuffer {
   void tonemap(float exposure, const float background_color[4], EColorSpace output_color_space, void* stream = nullptr) {
     ok(nrf_rb_tonemap(m_rb, exposure, background_color, (int)output_color_space, stream));
   }
+  // accumulate() + tonemap() as one pass over the planes (nrf_rb_present); rgba8: optional device uint32 [h][w]
+  void present(float exposure, const float background_color[4], EColorSpace output_color_space, void* rgba8 = nullptr, void* stream = nullptr) {
+    ok(nrf_rb_present(m_rb, exposure, background_color, (int)output_color_space, rgba8, stream));
+  }
   // overlay_depth(), render_buffer.h:259-268: `depth` is a device float plane of `resolution` (e.g. depth_buffer())
   void overlay_depth(float alpha, const float* depth, float depth_scale, const Vector2i& resolution, int fov_axis, float zoom,
                      const float screen_center[2], void* stream = nullptr) {

@@ -223,6 +223,7 @@ _SIGS = {
     "nrf_rb_clear_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nrf_rb_accumulate": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "nrf_rb_tonemap": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "nrf_rb_present": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_rb_overlay_depth": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.POINTER(C.c_float), C.c_void_p]),
     "nrf_rb_host_to_accumulate_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -955,6 +956,12 @@ class RenderBuffer:
     def tonemap(self, exposure, background_color, output_color_space, stream=None):
         bg = np.ascontiguousarray(background_color, np.float32).reshape(4)
         _check(self.lib.nrf_rb_tonemap(self.h, C.c_float(exposure), _fptr(bg), output_color_space, C.c_void_p(stream or 0)))
+
+    def present(self, exposure, background_color, output_color_space, rgba8_ptr=None, stream=None):
+        """accumulate() + tonemap() in one pass over the planes (nrf_rb_present); rgba8_ptr: optional device uint32 [h][w]."""
+        bg = np.ascontiguousarray(background_color, np.float32).reshape(4)
+        _check(self.lib.nrf_rb_present(self.h, C.c_float(exposure), _fptr(bg), output_color_space, C.c_void_p(rgba8_ptr or 0),
+                                       C.c_void_p(stream or 0)))
 
     def overlay_depth(self, alpha, depth_ptr, depth_scale, image_width, image_height, fov_axis=0, zoom=1.0,
                       screen_center=(0.5, 0.5), stream=None):

@@ -22,6 +22,9 @@ SHAPES = [
     ("F = 8 x 4 levels (GRID instance)", dict(n_features_per_level=8, n_levels=4)),
     ("F = 2 x 8 levels (GRID instance)", dict(n_levels=8)),
     ("F = 2 x 16 levels, Smoothstep (GRID instance)", dict(interpolation="Smoothstep")),
+    ("F = 2 x 16 levels, Nearest (GRID instance, round 5)", dict(interpolation="Nearest")),
+    ("F = 4 x 8 levels, Nearest (GRID instance, round 5)", dict(n_features_per_level=4, n_levels=8, interpolation="Nearest")),
+    ("F = 2 x 16 levels, Nearest, NRF_WIDTH_INSTANCES=0 (generic)", dict(interpolation="Nearest", _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("F = 4 x 8 levels, Smoothstep, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_features_per_level=4, n_levels=8, interpolation="Smoothstep", _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("F = 2 x 8 levels, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_levels=8, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("SH degree 6 (wide-SH form when persistent)", dict(sh_degree=6)),

@@ -16,7 +16,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 root, out = sys.argv[1], sys.argv[2]
 views = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-rows, mlp_rows = [], []
+rows, mlp_rows, mlp_res_rows = [], [], []
 for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rec = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
@@ -26,6 +26,8 @@ for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
         elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<false>", "mlp_forward_kernel<0>", "mlp_forward_kernelILb0E")) and "gen_mlp" not in r["Kernel_Name"]:
             # (rocprofv3 leaves this symbol mangled: its _Float16 parameter)
             mlp_rows.append(rec)  # the fused-MLP stage kernel, HBM-fed (scripts/mlp_steady.py under --pmc: profile_gpu.sh `mlp_*` passes)
+        elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<true", "mlp_forward_kernel<1", "mlp_forward_kernelILb1E")) and "gen_mlp" not in r["Kernel_Name"]:
+            mlp_res_rows.append(rec)  # the same kernel's register-resident loop (every chunk evaluated 64 times: no HBM stream)
 # the batched launches of the timed region: the persistent kernel's grid is the same for every launch (one workgroup per
 # CU), so the single-view replays are told apart by their duration
 longest = max(r[4] for r in rows)
@@ -104,6 +106,15 @@ if mlp_rows:
     mm = {k: statistics.mean(v) for k, v in mc_.items()}
     mlp = {"kernel": "nrf::mlp_forward_kernel<false>", "launch": "nrf_mlp_forward on 2^24 resident samples (scripts/mlp_steady.py)",
            **mfma_block(mm, mm["_ms"], 20480, 1 << 24)}
+mlp_res = None
+if mlp_res_rows:  # nrf_mlp_forward_repeat(2^22 samples x 64): the MFMA chain with its re-packing, fed from registers
+    mr_ = collections.defaultdict(list)
+    for name, g_, counter, value, ms in mlp_res_rows:
+        mr_[counter].append(value)
+        mr_["_ms"].append(ms)
+    mr = {k: statistics.mean(v) for k, v in mr_.items()}
+    mlp_res = {"kernel": "nrf::mlp_forward_kernel<true>", "launch": "nrf_mlp_forward_repeat: 2^22 resident samples, every chunk evaluated 64 times from registers (scripts/mlp_steady.py)",
+               **mfma_block(mr, mr["_ms"], 20480, (1 << 22) * 64)}
 ta_busy = g("TA_TA_BUSY_sum") / max(g("GRBM_GUI_ACTIVE") / 8 * 256, 1)  # 256 texture addressers (one per CU)
 wave_cycles = max(g("SQ_WAVE_CYCLES"), 1)
 doc = {
@@ -129,6 +140,7 @@ doc = {
     "l2_hit_rate": round(g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1), 4),
     "mfma": mfma_block(c, statistics.mean(agg[grid]["_ms"])),
     "mlp_forward_kernel": mlp,
+    "mlp_forward_kernel_register_resident": mlp_res,
     "limiter": {
         # two units are loaded about equally; `frac` is the busier one's figure, both are given
         "resource": ("VALU issue port, with the texture-address (gather) path close behind" if cycles / max(simd_cycles, 1) > ta_busy

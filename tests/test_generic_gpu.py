@@ -130,11 +130,13 @@ def test_generic_shape_stage_by_stage_and_frame(ctx, name):
     st = ctx.stats()
     wantf, wdepth, wst = o.render(cam, pose, W, H, schedule=op.SCHED_PER_RAY)
     # evaluated samples: a ray queues up to 8 per round, so a few lie behind its terminating one; how many depends on timing
-    # since tail splitting (a tiny frame is ALL tail: idle waves take rays every round), and a view rendered alone keeps the
-    # full queue (the transmittance-dependent cap is for launches of three views and more: nrf_api.hip).  Guarded with a margin
-    # above what was measured on these 72x48 frames (5-14 %; Nearest, whose blocky densities end rays on one opaque sample:
-    # 28 %) instead of the worst case of 7 per ray, which guards nothing; the composited samples are the oracle's own
-    assert st.n_composited <= st.n_samples <= 1.5 * st.n_composited + 256, (name, st.n_samples, st.n_composited)
+    # since tail splitting (a tiny frame is ALL tail: idle waves take rays every round).  Since round 5 a launch with fewer
+    # tiles than the chip has waves keeps the transmittance-dependent queue (nrf_api.hip render_views_impl), and the guard is
+    # the measured margin, per instance (profiles/r05/waste_small.txt, these 72x48 frames, five renders each): 0-6 % for every
+    # shape but Nearest, whose blocky densities end most rays on their FIRST sample -- queued with seven more while T was
+    # still 1: 39 %.  The composited samples are the oracle's own.
+    margin = 1.50 if name == "nearest" else 1.15
+    assert st.n_composited <= st.n_samples <= margin * st.n_composited + 64, (name, st.n_samples, st.n_composited)
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.01 * wst.n_composited + 16
     assert np.abs(rgba - wantf).max() <= 2.0 / 255.0 and models.psnr(rgba, wantf) >= 45.0, name
     assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
@@ -386,6 +388,10 @@ GRID_SHAPES = {  # base.json's MLPs behind another grid: the GRID instances (NET
     "g4_6s": dict(n_features_per_level=4, n_levels=6, interpolation="Smoothstep"), "g8_2": dict(n_features_per_level=8, n_levels=2),
     "g4_3s": dict(n_features_per_level=4, n_levels=3, interpolation="Smoothstep"), "g2_5": dict(n_levels=5), "g2_11": dict(n_levels=11),
     "g2_16s": dict(interpolation="Smoothstep"), "g2_8": dict(n_levels=8), "g4_8_sig": dict(n_features_per_level=4, n_levels=8, rgb_output_activation="Sigmoid"),
+    # round 5: Nearest interpolation (grid.h:215-232: the entry at floor(pos), one gather per level) in the GRID instances --
+    # the base 16 x 2 grid, and F = 4 / 8
+    "g2_16n": dict(interpolation="Nearest"), "g4_8n": dict(n_features_per_level=4, n_levels=8, interpolation="Nearest"),
+    "g8_3n": dict(n_features_per_level=8, n_levels=3, interpolation="Nearest"), "g2_7n": dict(n_levels=7, interpolation="Nearest"),
 }
 
 
@@ -402,7 +408,7 @@ def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shap
 
     # "d<a>_<b>": 64 neurons with a / b hidden layers in the density / rgb MLP (base.json: 1 / 2) -- the DEPTH instance
     # (mlp_tiles_depth: a runtime number of 64 -> 64 layers, the same in-lane chaining), reported as a width instance too
-    # "g<F>_<L>[s]": base.json's MLPs behind a grid of F features x L levels (s: Smoothstep) -- the GRID instances (round 4):
+    # "g<F>_<L>[s|n]": base.json's MLPs behind a grid of F features x L levels (s: Smoothstep, n: Nearest) -- the GRID instances (round 4):
     # F = 2 with fewer than 16 levels, F = 4 / 8 as 8- / 16-byte gathers; additionally the encode entry point (which runs the
     # instance's own gathers for such a model) is compared with the oracle BIT FOR BIT
     if shape[0] == "g":
@@ -482,3 +488,34 @@ def test_other_widths_and_sh_degrees_render_in_a_register_resident_instance(shap
             assert np.abs(depth - wdepth).max() <= 2.0 / 255.0
         assert np.abs(frames["1"][v][0] - frames["0"][v][0]).max() <= 2.0 / 255.0
     assert frames["1"][0][0][..., 3].max() > 0.5  # the object is in view
+
+
+def test_wide_instance_with_the_generic_march():
+    """NET_WIDE (Frequency directions of 32-80 values) on a grid whose bound is no power of two: the generic march form, which
+    runs 8-wave workgroups since round 5 (at 12 it spilled registers; nrf_launch.h WIDE_GENERIC_MARCH_WAVES).  The persistent
+    form against the per-strip kernel bit for bit, and against the oracle at the frame tolerance."""
+    import os
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, bound=3.0, cascade=2, dir_otype="Frequency", n_frequencies=4)
+    o = op.Oracle(desc)
+    W, H = 200, 136
+    cam, poses = syn.default_camera(W, H), [syn.orbit_pose(215, 25), syn.orbit_pose(70, -15)]
+    frames = {}
+    for env in ("1", "0"):
+        os.environ["NRF_PERSISTENT"] = env
+        try:
+            c = nh.NerfHip(0)
+        finally:
+            os.environ.pop("NRF_PERSISTENT", None)
+        c.load_model(desc)
+        c.lib.nrf_debug_instance.argtypes = [C.c_void_p]
+        assert c.lib.nrf_debug_instance(c.h) == 2 + (16 if env == "1" else 0)  # the wide instance, persistent or per strip
+        c.set_resolution(W, H)
+        c.set_max_views(2)
+        c.render_views([cam] * 2, poses)
+        frames[env] = [c.read_view_f32(v) for v in range(2)]
+        c.close()
+    for v, p in enumerate(poses):
+        np.testing.assert_array_equal(frames["1"][v][0], frames["0"][v][0])
+        np.testing.assert_array_equal(frames["1"][v][1], frames["0"][v][1])
+        want, wdepth, _ = o.render(cam, p, W, H, schedule=op.SCHED_PER_RAY)
+        assert np.abs(frames["1"][v][0] - want).max() <= 2.0 / 255.0 and models.psnr(frames["1"][v][0], want) >= 45.0

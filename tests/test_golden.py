@@ -123,8 +123,10 @@ def test_frame_fingerprints_unchanged():
         if n_composited is not None:  # the samples that reach a ray's compositing sum: deterministic, recorded, equal
             assert int(st.n_composited) == int(n_composited), (row, st.n_composited)
         # the evaluated ones depend on the batching of rays into rounds: at most a measured margin above the composited ones
-        # (a view alone queues its full eight samples per ray and round: measured <= 3 % at 800x800 and above, 10 % at 333x211)
-        assert st.n_composited <= st.n_samples <= (1.10 if W * H >= 800 * 800 else 1.30) * st.n_composited + 256, (row, st.n_samples, st.n_composited)
+        # (measured, profiles/r05/waste_small.txt: <= 5.4 % at 800x800 and above -- a view alone queues its full eight samples per
+        #  ray and round there --, <= 2 % at 333x211 and 640x360 and <= 9 % for the config-4 shape at 201x133, which are launches
+        #  of fewer tiles than the chip has waves and keep the transmittance-dependent queue)
+        assert st.n_composited <= st.n_samples <= (1.10 if W * H >= 800 * 800 else 1.15) * st.n_composited + 64, (row, st.n_samples, st.n_composited)
         assert hashlib.sha1(rgba.tobytes()).hexdigest()[:16] == h_rgba, row
         assert hashlib.sha1(depth.tobytes()).hexdigest()[:16] == h_depth, row
     c.close()

@@ -263,9 +263,10 @@ def test_render_frame_matches_oracle(ctx, small, W, H, az, el):
     assert models.psnr(rgba, want) >= 45.0
     # the kernel batches up to 8 samples per ray and round, so it may evaluate a few samples past a ray's termination that
     # the one-sample-at-a-time oracle never emits: how many depends on timing (tail splitting hands rays to idle waves, and a
-    # tiny frame is all tail).  A margin above what was measured on these frames (<= 15 %) guards it; the deterministic worst
-    # case of 7 per ray guards nothing.  (The full-size test below holds a 1080p view to 10 % and a 16-view launch to 4 %.)
-    assert st.n_composited <= st.n_samples <= 1.5 * st.n_composited + 256, (st.n_samples, st.n_composited)
+    # tiny frame is all tail -- which is why it keeps the transmittance-dependent queue since round 5).  Measured on these
+    # frames: 0.7-2.9 % (profiles/r05/waste_small.txt); guarded at 15 % (+ 32 samples: the 8x8 frame composites 628).
+    # (The full-size test below holds a 1080p view to 10 % and a 16-view launch to 4 %.)
+    assert st.n_composited <= st.n_samples <= 1.15 * st.n_composited + 32, (st.n_samples, st.n_composited)
     # ... while the samples that reach a ray's compositing sum are the oracle's own (per-ray schedule), up to the rays whose
     # termination test falls the other way within the MLP tolerance
     assert abs(int(st.n_composited) - int(wst.n_composited)) <= 0.002 * wst.n_composited + 8 and wst.n_composited == wst.n_samples

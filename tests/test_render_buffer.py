@@ -139,3 +139,83 @@ def test_overlay_depth_matches_oracle(alpha, fov_axis, zoom, center):
     want = op.rb_overlay_depth(before, alpha, depth, 0.9, fov_axis, zoom, center)
     np.testing.assert_allclose(after, want, rtol=0, atol=1e-6)
     rb.close()
+
+
+def _upload(frame_p, frame):
+    import ctypes as C
+    import torch
+    t = torch.from_numpy(frame).cuda()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(frame_p, t.data_ptr(), frame.nbytes, 3) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cs,ocs,curve,exposure", [(0, 1, 1, 0.5), (0, 0, 0, 0.0), (1, 1, 2, -1.0), (0, 1, 3, 2.0), (2, 0, 0, 0.0), (0, 0, 2, 1.25)])
+def test_present_is_accumulate_plus_tonemap_in_one_pass(cs, ocs, curve, exposure):
+    """nrf_rb_present (one pass: frame -> mean -> surface -> packed 8-bit) against nrf_rb_accumulate + nrf_rb_tonemap (the
+    reference's two calls, R/src/render_buffer.cu:590-627): the mean plane and the surface must hold the same BITS after
+    every sample -- the first one included, for which the fused pass neither clears nor reads the mean plane (it is poisoned
+    here) -- and rgba8 must be the library's 8-bit rule applied to the surface."""
+    torch = pytest.importorskip("torch")
+    W, H = 131, 57
+    two, one = nh.RenderBuffer(0), nh.RenderBuffer(0)
+    for rb in (two, one):
+        rb.resize(W, H)
+        rb.set_color_space(cs)
+        rb.set_tonemap_curve(curve)
+    f2, _, _, _ = two.buffers()
+    f1, _, a1, _ = one.buffers()
+    _upload(a1, np.full((H * W, 4), np.nan, np.float32))  # whatever the mean plane holds before the first sample is ignored
+    rgba8 = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(7 + cs + 3 * curve)
+    bg = [0.3, 0.6, 0.9, 0.8]
+    for spp in range(3):
+        frame = (rng.random((H * W, 4), dtype=np.float32) * np.float32(1.6) - np.float32(0.1)).astype(np.float32)
+        _upload(f2, frame)
+        _upload(f1, frame)
+        two.accumulate(0.0)
+        two.tonemap(exposure, bg, ocs)
+        one.present(exposure, bg, ocs, rgba8.data_ptr())
+        assert one.spp() == two.spp() == spp + 1
+        acc2, sur2 = two.read()
+        acc1, sur1 = one.read()
+        np.testing.assert_array_equal(acc1.view(np.uint32), acc2.view(np.uint32))
+        np.testing.assert_array_equal(sur1.view(np.uint32), sur2.view(np.uint32))
+        rgb8, a8 = op.quantize_u8(sur1.reshape(-1, 4), sur1.reshape(-1, 4)[:, 3].copy())
+        want = (rgb8[:, 0].astype(np.uint32) | (rgb8[:, 1].astype(np.uint32) << 8) | (rgb8[:, 2].astype(np.uint32) << 16) |
+                (a8.astype(np.uint32) << 24))
+        np.testing.assert_array_equal(rgba8.cpu().numpy().view(np.uint32).reshape(-1), want)
+    one.present(exposure, bg, ocs)  # without the 8-bit plane
+    assert one.spp() == 4
+    two.close()
+    one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3])
+def test_present_is_bit_exact_against_the_oracle_where_no_power_function_is_involved(curve):
+    """Linear render and display spaces: every operation of the chain is an individually rounded fp32 add / multiply / divide /
+    max on both sides, and what does not depend on the pixel (2^exposure, the background's sRGB decode, the curve's
+    coefficients) is computed on the host with the oracle's own libm: bit-exact.  (With sRGB on either side the device's
+    powf differs from libm's in the last place: test_hip_matches_oracle states that tolerance.)"""
+    W, H = 96, 40
+    rb = nh.RenderBuffer(0)
+    rb.resize(W, H)
+    rb.set_color_space(nh.CS_LINEAR)
+    rb.set_tonemap_curve(curve)
+    frame_p, _, _, _ = rb.buffers()
+    rng = np.random.default_rng(curve)
+    acc_ref = np.zeros((H * W, 4), np.float32)
+    bg = [0.25, 0.5, 0.75, 0.6]
+    for spp in range(3):
+        frame = (rng.random((H * W, 4), dtype=np.float32) * np.float32(2.5)).astype(np.float32)
+        _upload(frame_p, frame)
+        rb.present(0.75, bg, nh.CS_LINEAR)
+        acc_ref = op.rb_accumulate(frame, acc_ref, spp, nh.CS_LINEAR)
+        acc, sur = rb.read()
+        np.testing.assert_array_equal(acc.reshape(-1, 4), acc_ref)
+        np.testing.assert_array_equal(sur.reshape(-1, 4), op.rb_tonemap(acc_ref, 0.75, bg, nh.CS_LINEAR, nh.CS_LINEAR, curve))
+    rb.close()
