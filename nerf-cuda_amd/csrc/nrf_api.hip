@@ -134,7 +134,7 @@ void pack_fragments(const std::vector<_Float16>& w16, uint32_t rgb_in, std::vect
 // GRID instances (nrf_render.h grid_features): base.json's MLPs behind a grid of F features per level, feat_w = its padded width
 // (16 or 32).  The hot layout (fragments 0 .. N_FRAGS - 1) with the first density layer's K order of that grid: lane group g
 // holds, in this order, the features of the levels {g, 4 + g, ...} it encodes --
-//   F = 2: kmap(g, j) = 2 (4 (j >> 1) + g) + (j & 1)     F = 4: 4 (4 (j >> 2) + g) + (j & 3)     F = 8: 8 g + j
+//   F = 2: kmap(g, j) = 2 (4 (j >> 1) + g) + (j & 1)     F = 4: 4 (4 (j >> 2) + g) + (j & 3)     F = 8: 8 g + j     F = 1: 4 j + g (j < 4)
 // -- and zero columns where the grid has no level (k >= feat_w, or a padded feature of feat_w itself).
 void pack_fragments_grid(const std::vector<_Float16>& w16, uint32_t feat_w, uint32_t rgb_in, uint32_t F, std::vector<_Float16>& frags) {
   frags.assign((size_t)N_FRAGS * 64 * 8, (_Float16)0.0f);
@@ -154,6 +154,7 @@ void pack_fragments_grid(const std::vector<_Float16>& w16, uint32_t feat_w, uint
   const int Fi = (int)F;
   for (int m = 0; m < 4; ++m)
     put(FRAG_D0 + m, D0, (int)feat_w, m, [Fi](int g, int j) {
+      if (Fi == 1) return j < 4 ? 4 * j + g : (1 << 20);  // one feature per level: level 4 j + g; the lane's upper four are zero columns
       return Fi == 2 ? 2 * (4 * (j >> 1) + g) + (j & 1) : (Fi == 4 ? 4 * (4 * (j >> 2) + g) + (j & 3) : 8 * g + j);
     });
   for (int s = 0; s < 2; ++s) put(FRAG_D1 + s, D1, 64, 0, [&](int g, int j) { return khid(s, g, j); });
@@ -987,7 +988,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   // ... and for its grid: F = 2 with fewer than 16 levels, F = 4 / 8 with at most 32 features in all, Linear, Smoothstep or -- any F = 2 /
   // 4 / 8 grid of at most 32 features, the 16 x 2 one included -- Nearest (round 5: one gather per level, grid.h:215-232), every
   // level dense / power-of-two hashed / LV_ADD_POW2 -- the GRID instances (NET_GRID2 / 4 / 8) keep base.json's MLPs in registers
-  const bool hot_grid_ok = !generic_grid && (F == 2 || F == 4 || F == 8) && !(F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR) && L * F <= 32 &&
+  const bool hot_grid_ok = !generic_grid && (F == 1 || F == 2 || F == 4 || F == 8) && !(F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR) && L * F <= 32 &&
                            Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 && dir_w == 16 &&
                            (d->interpolation == NRF_INTERP_LINEAR || d->interpolation == NRF_INTERP_SMOOTHSTEP || d->interpolation == NRF_INTERP_NEAREST) &&
                            d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU && d->density_output_activation == NRF_ACT_NONE &&
@@ -1055,8 +1056,9 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   };
-  // byte-offset constants of level_gather / level_gather_wide: an entry is 2 F bytes (F = 1 never takes these paths)
-  const uint32_t sh_b = F == 8 ? 4u : (F == 4 ? 3u : 2u);
+  // byte-offset constants of level_gather / level_gather_wide / level_gather_f1: an entry is 2 F bytes (the generic instance's
+  // literal index arithmetic, gen_level, does not read them)
+  const uint32_t sh_b = F == 8 ? 4u : (F == 4 ? 3u : (F == 1 ? 1u : 2u));
   for (LevelParams& L : lp) {
     const bool hashed_pow2 = L.mode == LV_HASH_POW2;
     L.off_b = L.offset << sh_b;

@@ -147,7 +147,7 @@ struct DevModel {
   uint32_t hot_width;       // 0, 16, 32 or 128 -- or 64: the DEPTH instance (64 neurons, other numbers of hidden layers: depth_xd / depth_xr)
   uint32_t depth_xd, depth_xr;  // hot_width == 64: 64 -> 64 layers of the density MLP (hidden layers - 1) and of the rgb MLP (hidden layers - 1)
   const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4; wide_sh: the wide layout (N_FRAGS_WIDE_ALL fragments)
-  uint32_t hot_grid;        // 0, or F = 2 / 4 / 8: a grid other than base.json's 16 x 2 -- fewer than 16 levels at F = 2, F = 4 / 8 with up to 32
+  uint32_t hot_grid;        // 0, or F = 1 / 2 / 4 / 8 (F = 1: round 5): a grid other than base.json's 16 x 2 -- fewer than 16 levels at F = 2, F = 4 / 8 with up to 32
                             // features in all, Linear or Smoothstep -- in front of base.json's MLPs: the register-resident GRID instance
                             // (NET_GRID2 / 4 / 8, persistent kernel only; fragments in wfrag_hot with that grid's K order)
   uint32_t grid_smooth;     // the grid interpolates with Smoothstep (GRID instances)
@@ -897,6 +897,28 @@ __device__ __forceinline__ void level_interp_wide(const uint32_t (&v)[8 * DW], c
   }
 #pragma unroll
   for (int e = 0; e < DW; ++e) out[e] = h2_bits(acc[e]);
+}
+
+// ---- grids with ONE feature per level (F = 1): an entry is a single half, a corner a 2-byte gather (buffer_load_ushort) at the
+// same index arithmetic with a shift of 1.  The value rides in the LOW half of a dword whose high half is zero, so level_interp
+// serves unchanged: its high accumulator stays +0 and the low one is the feature, rounded as grid.h:236-262 rounds it.
+template <int UNI>
+__device__ __forceinline__ void level_gather_f1(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                                float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
+  uint32_t off[8];
+  level_offsets<UNI, 1>(L, px, py, pz, off, frac);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off[c], 0, 0);
+}
+template <int UNI>
+__device__ __forceinline__ uint32_t level_nearest_f1(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                                     float py, float pz) {
+  uint32_t off[8];
+  float frac[3];
+  level_offsets<UNI, 1>(L, px, py, pz, off, frac);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off[0], 0, 0);
 }
 
 // InterpolationType::Nearest (T/.../grid.h:215-232): a level's features ARE the entry at floor(pos) -- one aligned gather of the

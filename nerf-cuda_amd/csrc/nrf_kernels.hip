@@ -52,6 +52,22 @@ __global__ __launch_bounds__(256) void gen_encode_grid_kernel(const DevModel M, 
       float fr[3];
       uint32_t o[4] = {0u, 0u, 0u, 0u};
       const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
+      if (M.hot_grid == 1u) {  // F = 1: one half per (sample, level)
+        uint32_t r;
+        if (M.grid_nearest) {
+          r = uni == 2u ? level_nearest_f1<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz) : level_nearest_f1<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+        } else {
+          uint32_t v[8];
+          if (uni == 2u) level_gather_f1<2>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+          else level_gather_f1<0>(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+          if (M.grid_smooth) smoothstep_fractions(fr);
+          r = level_interp<false>(v, fr);
+        }
+        reinterpret_cast<unsigned short*>(row)[level] = (unsigned short)(r & 0xffffu);
+        if (level == 0)
+          for (uint32_t j = G.feat_raw; j < G.feat_w; ++j) row[j] = (half_t)0.0f;
+        continue;
+      }
       if (M.grid_nearest) {
         if (M.hot_grid == 2u) {
           uint32_t q[1];

@@ -1,4 +1,4 @@
-// nrf_kernels_grid.hip -- persistent render kernel, GRID instances: base.json's MLPs behind another hash grid (F = 2 with fewer than 16 levels, F = 4 / 8; Linear or Smoothstep)
+// nrf_kernels_grid.hip -- persistent render kernel, GRID instances: base.json's MLPs behind another hash grid (F = 1, F = 2 with fewer than 16 levels, F = 4 / 8; Linear, Smoothstep or Nearest)
 // (one family of render-kernel instances per translation unit: nrf_render.h)
 #include "nrf_render.h"
 
@@ -13,7 +13,8 @@ namespace nrf {
 
 hipError_t launch_persistent_grid(const PersistLaunch& L) {
   const uint32_t f = L.M->hot_grid;
-  if (f == 2) NRF_LAUNCH_GRID(NET_GRID2);
+  if (f == 1) NRF_LAUNCH_GRID(NET_GRID1);
+  else if (f == 2) NRF_LAUNCH_GRID(NET_GRID2);
   else if (f == 4) NRF_LAUNCH_GRID(NET_GRID4);
   else NRF_LAUNCH_GRID(NET_GRID8);
   return hipGetLastError();

@@ -53,8 +53,10 @@ constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // NET_GRID2 / 4 / 8: base.json's MLPs behind another grid -- F = 2 with fewer than 16 levels, F = 4 / 8 with up to 32 features in all,
 // Linear or Smoothstep (grid_features) -- persistent kernel only
 enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6, NET_DEPTH = 7,
-             NET_GRID2 = 8, NET_GRID4 = 9, NET_GRID8 = 10 };
-__host__ __device__ constexpr int net_grid_f(int net) { return net == NET_GRID2 ? 2 : (net == NET_GRID4 ? 4 : (net == NET_GRID8 ? 8 : 0)); }
+             NET_GRID2 = 8, NET_GRID4 = 9, NET_GRID8 = 10, NET_GRID1 = 11 };
+__host__ __device__ constexpr int net_grid_f(int net) {
+  return net == NET_GRID2 ? 2 : (net == NET_GRID4 ? 4 : (net == NET_GRID8 ? 8 : (net == NET_GRID1 ? 1 : 0)));
+}
 constexpr int SH_ROW_HALVES = 72;                     // a ray's row: up to 64 direction values + 8 halves of padding (rows 4 banks apart)
 constexpr int LDS_SHROW_BYTES = 64 * SH_ROW_HALVES * 2;  // 9216 per wave
 __host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 16 : (net == NET_W32 ? 32 : (net == NET_W128 ? 128 : 64)); }
@@ -116,8 +118,50 @@ __device__ __forceinline__ unsigned long long stamp_rt() {
 // The lane's 8 grid features (4 dwords) of a GRID instance: lane group g encodes the levels {g, 4 + g, ...} it can hold -- 4 levels
 // of F = 2, 2 of F = 4, 1 of F = 8 -- features in tcnn's order level-major; levels the grid does not have are zero (the padding of
 // the grid encoding is ZERO, grid.h:959-969).  K order of the first density layer: nrf_api.hip pack_fragments_grid.
+// F = 1 (NET_GRID1, round 5): lane group g holds the ONE feature of each of its levels {g, 4 + g, 8 + g, 12 + g} -- four halves, the
+// lane's other four features are zero columns (feat_w = 16: pack_fragments_grid) --, two levels to a dword, two levels in flight.
+__device__ __forceinline__ void grid_features_f1(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]) {
+#pragma unroll
+  for (int j0 = 0; j0 < 4; j0 += 2) {
+    uint32_t gv[2][8];
+    float gf[2][3];
+    uint32_t r[2] = {0u, 0u};
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int jl = j0 + jb;
+      const uint32_t lv = (uint32_t)(4 * jl + g);
+      if (lv < M.n_levels) {
+        const LevelParams L = lvs[lv];
+        const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
+        if (M.grid_nearest) {
+          r[jb] = uni == 2u ? level_nearest_f1<2>(M.grid, M.grid_bytes, L, px, py, pz) : level_nearest_f1<0>(M.grid, M.grid_bytes, L, px, py, pz);
+        } else {
+          if (uni == 2u) level_gather_f1<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+          else level_gather_f1<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jb], gf[jb]);
+          if (M.grid_smooth) smoothstep_fractions(gf[jb]);
+        }
+      }
+    }
+    if (!M.grid_nearest) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const uint32_t lv = (uint32_t)(4 * (j0 + jb) + g);
+        if (lv < M.n_levels) r[jb] = level_interp<false>(gv[jb], gf[jb]);
+      }
+    }
+    fb[j0 >> 1] = (r[0] & 0xffffu) | (r[1] << 16);
+  }
+}
+
+template <int GF>
+__device__ __forceinline__ void grid_features_f248(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]);
 template <int GF>
 __device__ __forceinline__ void grid_features(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]) {
+  if constexpr (GF == 1) grid_features_f1(M, lvs, px, py, pz, g, fb);
+  else grid_features_f248<GF>(M, lvs, px, py, pz, g, fb);
+}
+template <int GF>
+__device__ __forceinline__ void grid_features_f248(const DevModel& M, const LevelParams* lvs, float px, float py, float pz, int g, uint32_t (&fb)[4]) {
   constexpr int LPL = 8 / GF, DW = GF / 2;  // levels per lane, dwords per entry
   if (M.grid_nearest) {  // wave-uniform.  Nearest (grid.h:215-232): one gather per level, the entry is the result
 #pragma unroll

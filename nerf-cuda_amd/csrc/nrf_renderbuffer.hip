@@ -26,9 +26,20 @@ namespace {
 thread_local std::string g_rb_err;
 extern "C" const char* nrf_last_error(void);
 
-// the sRGB transfer pair as the reference states it (R/include/nerf-cuda/common_device.cuh:38-60: note the 0.41666 exponent)
-__host__ __device__ inline float decode_srgb(float v) { return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); }
-__host__ __device__ inline float encode_srgb(float v) { return v < 0.0031308f ? 12.92f * v : 1.055f * powf(v, 0.41666f) - 0.055f; }
+// the sRGB transfer pair as the reference states it (R/include/nerf-cuda/common_device.cuh:38-60: note the 0.41666 exponent).
+// On the device the power is 2^(e log2 x) on the two transcendental instructions (v_log_f32, v_exp_f32; the argument is
+// positive on this branch): within 2e-6 of libm's powf over the range a colour takes -- the general powf made the chain
+// ALU-bound (32-52 us per 1080p plane against 20 us for the same stream without it, profiles/r05/rb_bench.txt).  The host
+// forms (the background colour, once per call) stay libm's, which is the oracle's.
+__host__ __device__ inline float pow_positive(float x, float e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
+#else
+  return powf(x, e);
+#endif
+}
+__host__ __device__ inline float decode_srgb(float v) { return v <= 0.04045f ? v / 12.92f : pow_positive((v + 0.055f) / 1.055f, 2.4f); }
+__host__ __device__ inline float encode_srgb(float v) { return v < 0.0031308f ? 12.92f * v : 1.055f * pow_positive(v, 0.41666f) - 0.055f; }
 
 // A film curve, reduced on the host to what the pixel loop needs.  RATIONAL: y = (x^2 n2 + n1 x + n0) / (d2 x^2 + d1 x + d0)
 // on max(x, 0) per channel (operation order as written: it is part of the contract with the oracle); LUMA: Reinhard's

@@ -22,6 +22,8 @@ SHAPES = [
     ("F = 8 x 4 levels (GRID instance)", dict(n_features_per_level=8, n_levels=4)),
     ("F = 2 x 8 levels (GRID instance)", dict(n_levels=8)),
     ("F = 2 x 16 levels, Smoothstep (GRID instance)", dict(interpolation="Smoothstep")),
+    ("F = 1 x 16 levels (GRID instance, round 5)", dict(n_features_per_level=1)),
+    ("F = 1 x 16 levels, NRF_WIDTH_INSTANCES=0 (generic)", dict(n_features_per_level=1, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("F = 2 x 16 levels, Nearest (GRID instance, round 5)", dict(interpolation="Nearest")),
     ("F = 4 x 8 levels, Nearest (GRID instance, round 5)", dict(n_features_per_level=4, n_levels=8, interpolation="Nearest")),
     ("F = 2 x 16 levels, Nearest, NRF_WIDTH_INSTANCES=0 (generic)", dict(interpolation="Nearest", _env={"NRF_WIDTH_INSTANCES": "0"})),

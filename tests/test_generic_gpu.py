@@ -392,6 +392,9 @@ GRID_SHAPES = {  # base.json's MLPs behind another grid: the GRID instances (NET
     # the base 16 x 2 grid, and F = 4 / 8
     "g2_16n": dict(interpolation="Nearest"), "g4_8n": dict(n_features_per_level=4, n_levels=8, interpolation="Nearest"),
     "g8_3n": dict(n_features_per_level=8, n_levels=3, interpolation="Nearest"), "g2_7n": dict(n_levels=7, interpolation="Nearest"),
+    # round 5: ONE feature per level (NET_GRID1: 2-byte gathers, two levels to a dword) -- Linear, Smoothstep, Nearest
+    "g1_16": dict(n_features_per_level=1), "g1_9s": dict(n_features_per_level=1, n_levels=9, interpolation="Smoothstep"),
+    "g1_13n": dict(n_features_per_level=1, n_levels=13, interpolation="Nearest"), "g1_3": dict(n_features_per_level=1, n_levels=3),
 }
 
 
