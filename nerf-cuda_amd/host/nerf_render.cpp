@@ -44,6 +44,7 @@ uint32_t activation(const mpk::Value& block, const char* key, const char* dflt) 
   if (s == "sine") return NRF_ACT_SINE;
   throw std::runtime_error{"Invalid activation name: " + s};
 }
+std::string blob_of(const mpk::Value& v, const std::string& what);  // (below: the two binary forms tcnn reads)
 }  // namespace
 
 void NerfRender::check(int rc, const char* what) const {
@@ -154,8 +155,9 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
     }
     const std::string bkey = std::string(key) + "_binary", tkey = std::string(key) + "_type";
     if (!snapshot.contains(bkey.c_str())) throw std::runtime_error{std::string("snapshot.") + what + " is missing"};
-    const mpk::Value& b = snapshot.at(bkey.c_str());
-    if (b.type != mpk::Value::Bin) throw std::runtime_error{"snapshot." + bkey + " must be a binary blob"};
+    mpk::Value b;
+    b.type = mpk::Value::Bin;
+    b.str = blob_of(snapshot.at(bkey.c_str()), "snapshot." + bkey);
     const std::string type = snapshot.value(tkey.c_str(), "__half");
     std::vector<float> out;
     if (type == "float") {
@@ -220,6 +222,19 @@ float half_bits_to_float(uint16_t h) {
   std::memcpy(&f, &bits, 4);
   return f;
 }
+// A binary value of a snapshot as bytes: tcnn writes its parameters as a nlohmann binary_t (msgpack `bin`,
+// gpu_memory_to_json_binary) and reads either that or, from a text JSON, the object {"bytes": [..], "subtype": ..}
+// (T/include/tiny-cuda-nn/gpu_memory_json.h:37-72).  Both forms are accepted.
+std::string blob_of(const mpk::Value& v, const std::string& what) {
+  if (v.type == mpk::Value::Bin) return v.str;
+  if (v.type == mpk::Value::Map && v.contains("bytes") && v.at("bytes").type == mpk::Value::NumArray) {
+    const std::vector<float>& n = v.at("bytes").nums;
+    std::string out(n.size(), '\0');
+    for (size_t i = 0; i < n.size(); ++i) out[i] = (char)(unsigned char)((unsigned)n[i] & 0xffu);
+    return out;
+  }
+  throw std::runtime_error{what + ": Invalid json type: must be either binary or object"};  // gpu_memory_json.h:70
+}
 std::vector<float> blob_to_floats(const std::string& blob, bool is_float, const char* what) {
   std::vector<float> out;
   if (is_float) {
@@ -269,9 +284,8 @@ void NerfRender::load_ngp_snapshot(const mpk::Value& config) {
   uint32_t n_ngp = 0;
   for (uint32_t v = aabb_scale; v; v >>= 1) ++n_ngp;  // K + 1 cascades
   const uint64_t H3 = (uint64_t)H * H * H, cells = H3 * n_ngp;
-  if (!snapshot.contains("density_grid_binary") || snapshot.at("density_grid_binary").type != mpk::Value::Bin)
-    throw std::runtime_error{"instant-ngp snapshot: density_grid_binary is missing"};
-  const std::string& blob = snapshot.at("density_grid_binary").str;
+  if (!snapshot.contains("density_grid_binary")) throw std::runtime_error{"instant-ngp snapshot: density_grid_binary is missing"};
+  const std::string blob = blob_of(snapshot.at("density_grid_binary"), "snapshot.density_grid_binary");
   const std::string gtype = snapshot.value("density_grid_type", blob.size() == 4 * cells ? "float" : "__half");
   const std::vector<float> ngp = blob_to_floats(blob, gtype == "float", "snapshot.density_grid_binary");
   if (ngp.size() < cells) throw std::runtime_error{"Incompatible number of grid cascades."};
@@ -313,9 +327,13 @@ void NerfRender::load_ngp_snapshot(const mpk::Value& config) {
           out[((size_t)x * H + y) * H + z] = v;
         }
   }
-  if (!snapshot.contains("params_binary") || snapshot.at("params_binary").type != mpk::Value::Bin)
-    throw std::runtime_error{"instant-ngp snapshot: params_binary is missing"};
-  m_params = blob_to_floats(snapshot.at("params_binary").str, snapshot.value("params_type", "__half") == "float", "snapshot.params_binary");
+  if (!snapshot.contains("params_binary")) throw std::runtime_error{"instant-ngp snapshot: params_binary is missing"};
+  m_params = blob_to_floats(blob_of(snapshot.at("params_binary"), "snapshot.params_binary"), snapshot.value("params_type", "__half") == "float",
+                            "snapshot.params_binary");
+  // tcnn's Trainer::serialize writes `n_params` beside the blob (T/include/tiny-cuda-nn/trainer.h:267-279): a file whose two disagree is corrupt
+  if (snapshot.contains("n_params") && (uint64_t)snapshot.value("n_params", (double)0) != (uint64_t)m_params.size())
+    throw std::runtime_error{"snapshot.params_binary holds " + std::to_string(m_params.size()) + " values, snapshot.n_params says " +
+                             std::to_string((uint64_t)snapshot.value("n_params", (double)0))};
   // what reset_network cannot derive from the reference's own rules
   static const mpk::Value no_enc = empty_map;
   const mpk::Value& enc = config.contains("encoding") ? config.at("encoding") : no_enc;

@@ -322,6 +322,17 @@ def morton3d(x, y, z):
     return (expand(x) | (expand(y) << np.uint64(1)) | (expand(z) << np.uint64(2))).astype(np.uint32)
 
 
+def blob_bytes(value, what: str) -> bytes:
+    """A binary value of a snapshot as bytes.  tcnn writes its parameters with `gpu_memory_to_json_binary` (a nlohmann
+    binary_t: msgpack `bin`) and READS either that or, from a text JSON, the object `{"bytes": [..], "subtype": ..}`
+    (T/include/tiny-cuda-nn/gpu_memory_json.h:37-72): both are accepted here."""
+    if isinstance(value, (bytes, bytearray, memoryview)):
+        return bytes(value)
+    if isinstance(value, dict) and "bytes" in value:
+        return bytes(bytearray(int(v) & 0xff for v in value["bytes"]))
+    raise RuntimeError(f"{what}: Invalid json type: must be either binary or object")  # gpu_memory_json.h:70
+
+
 def is_ngp_snapshot(config: dict) -> bool:
     snap = config.get("snapshot", {})
     return isinstance(snap, dict) and ("nerf" in snap or isinstance(snap.get("aabb"), dict))
@@ -342,7 +353,7 @@ def ngp_snapshot_to_reference(config: dict) -> dict:
     if H & (H - 1):
         raise RuntimeError("instant-ngp snapshot: density_grid_size must be a power of two (Morton order)")
     n_ngp = aabb_scale.bit_length()  # K + 1 cascades
-    blob = snap["density_grid_binary"]
+    blob = blob_bytes(snap["density_grid_binary"], "snapshot.density_grid_binary")
     cells = n_ngp * H ** 3
     kind = snap.get("density_grid_type")
     if kind is None:
@@ -382,7 +393,13 @@ def ngp_snapshot_to_reference(config: dict) -> dict:
            "scale": float(dataset.get("scale", 0.33)), "cascade": int(C), "density_grid_size": H,
            "mean_density": float(np.maximum(xmajor[0], 0.0).mean(dtype=np.float64)),
            "density_grid_binary": out.reshape(-1).tobytes(), "density_grid_type": "float",
-           "params_binary": snap["params_binary"], "params_type": snap.get("params_type", "__half")}
+           "params_binary": blob_bytes(snap["params_binary"], "snapshot.params_binary"), "params_type": snap.get("params_type", "__half")}
+    # tcnn's Trainer::serialize writes `n_params` beside the blob (T/include/tiny-cuda-nn/trainer.h:267-279: sizeof(PARAMS_T) *
+    # n_params bytes of the inference parameters, PARAMS_T = __half for a FullyFusedMLP model); a file whose two disagree is corrupt
+    if "n_params" in snap:
+        width = 4 if new["params_type"] == "float" else 2
+        if int(snap["n_params"]) * width != len(new["params_binary"]):
+            raise RuntimeError(f"snapshot.params_binary holds {len(new['params_binary']) // width} values, snapshot.n_params says {int(snap['n_params'])}")
     ref["snapshot"] = new
     return ref
 
@@ -487,7 +504,7 @@ def desc_from_config(config: dict, params: np.ndarray | None = None, density_gri
         """`key` as an array of numbers (the reference's format) or `key_binary` + `key_type` (instant-ngp's)."""
         if key in snap:
             return np.asarray(snap[key], dtype=np.float32)
-        blob = snap[key + "_binary"]
+        blob = blob_bytes(snap[key + "_binary"], f"snapshot.{key}_binary")
         kind = snap.get(key + "_type", "__half")
         if kind not in ("__half", "half", "float"):
             raise RuntimeError(f"snapshot.{key}_type: unknown element type '{kind}'")

@@ -150,3 +150,43 @@ def test_ngp_snapshot_renders_the_array_form_bytes_and_the_camera_path(tmp_path)
         ctx.render(cams[i], got_poses[i])
         np.testing.assert_array_equal(ctx.read_u8()[0].reshape(-1), outs["ngp"][1 + i])
     ctx.close()
+
+
+def test_params_blob_as_tcnn_trainer_serializes_it(tmp_path):
+    """The one part of instant-ngp's layout that the REFERENCE TREE itself pins: instant-ngp's snapshot block starts as
+    tcnn's `Trainer::serialize()` -- `{"n_params": n, "params_binary": <sizeof(PARAMS_T) * n bytes of the inference
+    parameters>}` (T/include/tiny-cuda-nn/trainer.h:267-279; PARAMS_T = __half for a FullyFusedMLP model, common.h:56-72), written
+    as a nlohmann binary_t (msgpack `bin`) by `gpu_memory_to_json_binary` and read back either as that or as the JSON object
+    `{"bytes": [...], "subtype": ...}` (gpu_memory_json.h:37-72) -- in the network's own parameter order, which is the
+    reference's `set_params` order (nerf_network.h:273-291).  A file holding exactly those two keys (no `params_type`: tcnn
+    v1.6 writes none) loads to the array-form model in both loaders, in both binary forms; a blob that disagrees with
+    `n_params` is refused."""
+    import msgpack
+    arr, ngp, desc, keep, cfg = _pair(tmp_path, 1)
+    base = syn.read_snapshot(ngp)
+    params16 = np.asarray(keep[0], np.float32).astype(np.float16)
+    want = nh.desc_from_config(syn.read_snapshot(arr))[1][0]
+    for form in ("bin", "object"):
+        c = {k: (dict(v) if isinstance(v, dict) else v) for k, v in base.items()}
+        snap = dict(c["snapshot"])
+        snap.pop("params_type", None)
+        snap["n_params"] = int(params16.size)                                   # trainer.h:271
+        blob = params16.tobytes()                                               # trainer.h:272: sizeof(PARAMS_T) * n_params bytes
+        snap["params_binary"] = blob if form == "bin" else {"bytes": list(blob), "subtype": None}  # gpu_memory_json.h:59-66
+        c["snapshot"] = snap
+        d, k = nh.desc_from_config(c)
+        np.testing.assert_array_equal(k[0], want)
+        assert d.n_params == params16.size == nh.expected_n_params(d)
+        f = tmp_path / f"tcnn_{form}.msgpack"
+        f.write_bytes(msgpack.packb(c, use_single_float=True, use_bin_type=True))
+        info = _info(f)                                                         # the C++ loader
+        assert info["n_params"] == info["expected"] == int(params16.size)
+        assert info == {**_info(ngp), **{k2: info[k2] for k2 in info if k2 not in _info(ngp)}}
+    bad = {k: (dict(v) if isinstance(v, dict) else v) for k, v in base.items()}
+    bad["snapshot"] = dict(bad["snapshot"], n_params=int(params16.size) - 8)
+    with pytest.raises(RuntimeError, match="n_params"):
+        nh.desc_from_config(bad)
+    f = tmp_path / "bad.msgpack"
+    f.write_bytes(msgpack.packb(bad, use_single_float=True, use_bin_type=True))
+    r = subprocess.run([str(HOST / "snapshot_info"), str(f)], capture_output=True, text=True)
+    assert r.returncode != 0 and "n_params" in r.stderr
