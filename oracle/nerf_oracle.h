@@ -9,7 +9,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or weights for
  * this path and cannot be built here (CUDA-only), so
  * this oracle is pinned only by the source-derived known answers of
- * SURVEY.md Appendix C (tests/test_oracle_kat.py).
+ * SURVEY.md Appendix C (tests/test_oracle_kat.py) -- plus, where a published
+ * definition exists that does not pass through this repository's reading of
+ * the source, by that: scipy's spherical harmonics for the SH table, the
+ * published film curves, numpy's and the CPU's fp16 conversions.
  *
  * Arithmetic contract (what "the reference's algorithm" means here): every
  * fp32 operation individually rounded (no FMA contraction), fp16 storage with

@@ -185,3 +185,64 @@ def test_fp16_instructions_equal_the_software_definition():
     assert op.lib().nrfo_fp16_selfcheck(3) == 0
     for x in (0.0, -0.0, 1.0, 65504.0, 65520.0, 2.0 ** -24, 2.0 ** -25, 3.0e-8, float("inf"), -1.5):
         assert op.lib().nrfo_f32_to_f16(x) == op.lib().nrfo_f32_to_f16_soft(x)
+
+
+def test_base_config_is_the_references_base_json():
+    """The four network blocks the path reads (R/src/nerf_render.cu:113-117) as R/configs/nerf/base.json states them
+    (encoding :23-29, network :30-36, dir_encoding :37-51, rgb_network :52-58): the model every benchmark and golden frame of
+    this repository is built on is the reference's own configuration, value for value (data restated from that file)."""
+    want = {
+        "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1},
+        "dir_encoding": {"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4},
+                                                         {"otype": "Identity", "n_bins": 4, "degree": 4}]},
+        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }
+    cfg = syn.base_config()
+    for block, values in want.items():
+        assert cfg[block] == values, block
+
+
+def test_sh_table_is_the_real_spherical_harmonics_basis():
+    """An independent pin of kernel_sh's 64-entry polynomial table (T/.../spherical_harmonics.h:66-152) that does not pass
+    through this repository's reading of it: scipy's complex spherical harmonics, folded into the real basis
+    (sqrt(2) Re / Im of Y_l^|m|, Condon-Shortley phase included), must equal every oracle coefficient up to degree 8 at
+    500 random directions, to fp16 rounding of values of magnitude <= 1.6."""
+    special = pytest.importorskip("scipy.special")
+    sph = getattr(special, "sph_harm_y", None)
+    desc, keep, _ = models.build_model(log2_hashmap_size=12, H=32, sh_degree=8)
+    o = op.Oracle(desc)
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(500, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d01 = (0.5 * d + 0.5).astype(np.float32)
+    got = o.encode_dir(d01).view(np.float16).astype(np.float64)
+    v = d01.astype(np.float64) * 2 - 1
+    theta, phi = np.arccos(np.clip(v[:, 2] / np.linalg.norm(v, axis=1), -1, 1)), np.arctan2(v[:, 1], v[:, 0])
+    for l in range(8):
+        for m in range(-l, l + 1):
+            Y = sph(l, abs(m), theta, phi) if sph is not None else special.sph_harm(abs(m), l, phi, theta)
+            want = Y.real if m == 0 else np.sqrt(2) * (Y.real if m > 0 else Y.imag)
+            assert np.abs(got[:, l * l + l + m] - want).max() <= 1e-3, (l, m)
+
+
+def test_film_curves_are_the_published_operators():
+    """The oracle's tonemap curves (restating R/src/render_buffer.cu:261-318, which folds each operator into a ratio of two
+    quadratics) against the operators as published: Narkowicz's ACES fit x (2.51 x + 0.03) / (x (2.43 x + 0.59) + 0.14) on
+    0.6 x, Hable's filmic curve ((x (A x + C B) + D E) / (x (A x + B) + D F)) - E / F on 2 x, divided by its value at the
+    white point 11.2, and Reinhard's x / (1 + Y) with Rec. 709 luminance."""
+    x = np.linspace(0.0, 8.0, 257, dtype=np.float32)
+    acc = np.zeros((len(x), 4), np.float32)
+    acc[:, 0], acc[:, 1], acc[:, 2], acc[:, 3] = x, 0.5 * x, 2.0 * x, 1.0
+    bg = [0, 0, 0, 0]
+    X = acc[:, :3].astype(np.float64)
+    aces = op.rb_tonemap(acc, 0.0, bg, nh.CS_LINEAR, nh.CS_LINEAR, nh.TM_ACES)[:, :3]
+    a = 0.6 * X
+    np.testing.assert_allclose(aces, a * (2.51 * a + 0.03) / (a * (2.43 * a + 0.59) + 0.14), rtol=2e-6, atol=1e-7)
+    A, B, Cc, D, E, F = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+    hable_f = lambda v: (v * (A * v + Cc * B) + D * E) / (v * (A * v + B) + D * F) - E / F  # noqa: E731
+    hable = op.rb_tonemap(acc, 0.0, bg, nh.CS_LINEAR, nh.CS_LINEAR, nh.TM_HABLE)[:, :3]
+    np.testing.assert_allclose(hable, hable_f(2.0 * X) / hable_f(11.2), rtol=3e-5, atol=2e-6)
+    rein = op.rb_tonemap(acc, 0.0, bg, nh.CS_LINEAR, nh.CS_LINEAR, nh.TM_REINHARD)[:, :3]
+    Y = 0.2126 * X[:, 0] + 0.7152 * X[:, 1] + 0.0722 * X[:, 2]
+    np.testing.assert_allclose(rein, X / (1.0 + Y)[:, None], rtol=2e-6, atol=1e-7)
