@@ -64,7 +64,8 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
-for p in (ROOT / "nerf-cuda_amd", ROOT / "tests"):
+# the package first (nerfhip, synthetic, models); tests/ only holds the oracle's binding, which the cpu_baseline leg imports
+for p in (ROOT / "tests", ROOT / "nerf-cuda_amd"):
     sys.path.insert(0, str(p))
 
 WIDTH, HEIGHT = 1920, 1080

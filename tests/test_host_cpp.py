@@ -121,6 +121,18 @@ def test_testbed_matches_python_binding(tmp_path, snapshot):
                        text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr + r.stdout
     np.testing.assert_array_equal(np.fromfile(out3 / "image.rgb", np.uint8).reshape(H, W, 3), rgb8)
+    # the same binary with the exchange step on RCCL (NRF_GROUP_GATHER=rccl: nrf_group_create opens librccl, builds a
+    # one-rank communicator and the lone member renders its shard tile-major, sends it to itself, untiles): same bytes; and a
+    # group that lists a device twice cannot take that transport -- the error is the library's, loud, not a silent fallback
+    outr = tmp_path / "rccl"
+    outr.mkdir()
+    r = subprocess.run([str(HOST / "testbed"), str(path), str(W), str(H), str(outr) + "/"], capture_output=True, text=True, timeout=180,
+                       env=dict(os.environ, NRF_GROUP_GATHER="rccl"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    np.testing.assert_array_equal(np.fromfile(outr / "image.rgb", np.uint8).reshape(H, W, 3), rgb8)
+    r = subprocess.run([str(HOST / "testbed"), str(path), str(W), str(H), str(outr) + "/"], capture_output=True, text=True, timeout=180,
+                       env=dict(os.environ, NRF_GROUP_GATHER="rccl", NERF_NGPU="2", NERF_DEVICES="0,0"))
+    assert r.returncode != 0 and "DISTINCT" in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu
