@@ -1039,3 +1039,45 @@ def test_fast_interp_is_opt_in_and_within_its_stated_tolerance(small):
     assert np.abs(f_fast - want).max() <= 2.0 / 255.0 and models.psnr(f_fast, want) >= 45.0
     assert not np.array_equal(f_fast, f_exact)
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H", [(3840, 2160), (7680, 4320)])
+def test_large_frames_4k_and_8k(W, H):
+    """Maximum sizes: one 4K / 8K view of the config-2 model (130 k / 518 k tiles: 32 k / 130 k strips in the work queues -- the 8K
+    one is beyond what a planned launch takes, PLAN_CAP).  Size-independent properties: two renders are the same bits, alpha in
+    [0, 1], background exactly the background outside the object's projection, the host-frame path returns the bytes of
+    nrf_read_u8, two crops (centre, silhouette) equal the oracle's render of the cropped camera, and the composited samples
+    scale with the pixel count of the 1080p frame of the same pose."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    c = nh.NerfHip(0)
+    c.load_model(desc)
+    c.set_resolution(W, H)
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(30, 30)
+    c.render(cam, pose)
+    rgba, depth = c.read_f32()
+    n1 = int(c.stats().n_composited)
+    c.render(cam, pose)
+    rgba2, depth2 = c.read_f32()
+    assert np.array_equal(rgba, rgba2) and np.array_equal(depth, depth2) and int(c.stats().n_composited) == n1
+    assert np.all(np.isfinite(rgba)) and rgba[..., 3].min() >= 0.0 and rgba[..., 3].max() <= 1.0 + 1e-6
+    assert np.all(rgba[:8, :8, :3] == 1.0) and np.all(rgba[:8, :8, 3] == 0.0) and np.all(depth[:8, :8] == 0.0)  # a corner: background
+    assert rgba[H // 2, W // 2, 3] > 0.5  # the object is in the middle
+    rgb8, d8 = c.read_u8()
+    host_rgb, host_d = c.render_host_u8([cam], [pose])
+    np.testing.assert_array_equal(host_rgb[0], rgb8)
+    np.testing.assert_array_equal(host_d[0], d8)
+    o = op.Oracle(desc)
+    cw, ch = 96, 48
+    ys, xs = np.nonzero(rgba[..., 3] > 0.5)
+    for x0, y0 in ((W // 2 - cw // 2, H // 2 - ch // 2), (max(int(xs.min()) - cw // 2, 0) & ~7, int(ys[np.argmin(xs)]) & ~7)):
+        y0 = min(y0, H - ch)
+        ccam = cam.copy(); ccam[2] -= x0; ccam[3] -= y0
+        want, wdepth, _ = o.render(ccam, pose, cw, ch, schedule=op.SCHED_PER_RAY)
+        crop = rgba[y0:y0 + ch, x0:x0 + cw]
+        assert np.abs(crop - want).max() <= 2.0 / 255.0 and models.psnr(crop, want) >= 45.0, (x0, y0)
+        assert np.abs(depth[y0:y0 + ch, x0:x0 + cw] - wdepth).max() <= 2.0 / 255.0
+    c.set_resolution(1920, 1080)
+    c.render(syn.default_camera(1920, 1080), pose)
+    n_1080 = int(c.stats().n_composited)
+    assert abs(n1 / n_1080 - (W * H) / (1920 * 1080)) <= 0.02 * (W * H) / (1920 * 1080)
+    c.close()
