@@ -927,19 +927,21 @@ def mlp_microbench(ctx, torch, dev):
             "interleave_experiment": "forced MFMA / VALU issue patterns (sched_group_barrier): none beats the compiler's schedule, profiles/r03/mlp_interleave.txt"}
 
 
-def usable_cpus():
+def usable_cpus(cgroup_root="/sys/fs/cgroup"):
     """The CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (the one-GPU box shows 256
     logical CPUs and grants 16: more threads than the quota only take turns -- 128 threads measured 1.9 Msamples/s where 16
-    give 2.9, profiles/r05/cpu_threads.txt)."""
+    give 2.9, profiles/r05/cpu_threads.txt).  cgroup v2: `cpu.max` = "<quota> <period>" or "max <period>"; v1:
+    cpu/cpu.cfs_quota_us (-1: none) and cpu/cpu.cfs_period_us."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    root = Path(cgroup_root)
     try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        quota, period = (root / "cpu.max").read_text().split()[:2]
         if quota != "max":
             n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
     except Exception:  # noqa: BLE001  (cgroup v1, or none)
         try:
-            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
-            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            q = int((root / "cpu" / "cpu.cfs_quota_us").read_text())
+            p = int((root / "cpu" / "cpu.cfs_period_us").read_text())
             if q > 0 and p > 0:
                 n = min(n, max(1, int(q / p + 0.5)))
         except Exception:  # noqa: BLE001

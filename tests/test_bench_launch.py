@@ -131,3 +131,30 @@ def test_forced_single_rank_runs_the_real_rccl_exchange():
                        "--warmup", "1", "--views-per-step", "4"])
     assert out["distributed"]["backend"] == "nccl" and out["config"]["parallelism"] == "replica1"
     assert out["sharded_frame_equals_unsharded"] is True
+
+
+def test_cpu_baseline_counts_the_cpus_the_cgroup_grants(tmp_path):
+    """bench.py's cpu_baseline runs the oracle on the CPUs the box GRANTS, not on the ones it shows (the one-GPU box: 256 logical
+    CPUs, a cgroup quota of 16 -- rounds 1-4 ran 128 threads taking turns on them): cgroup v2 `cpu.max`, v1 quota / period,
+    "max" and a missing hierarchy, always capped by the affinity mask."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    have = len(os.sched_getaffinity(0))
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert bench.usable_cpus(v2) == min(16, have)
+    (v2 / "cpu.max").write_text("150000 100000\n")   # 1.5 CPUs -> 2 threads
+    assert bench.usable_cpus(v2) == min(2, have)
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert bench.usable_cpus(v2) == have
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("400000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.usable_cpus(v1) == min(4, have)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.usable_cpus(v1) == have
+    assert bench.usable_cpus(tmp_path / "none") == have
