@@ -6,7 +6,7 @@ set -eo pipefail
 mkdir -p gpurun_out
 : > gpurun_out/mlp_form_ab.txt
 for rep in 1 2 3; do
-  for form in 30 20 21; do
+  for form in ${FORMS:-30 20 21}; do
     echo -n "NRF_MLP_FORM=$form  " >> gpurun_out/mlp_form_ab.txt
     NRF_MLP_FORM=$form python3 scripts/mlp_steady.py 2>/dev/null | tail -1 >> gpurun_out/mlp_form_ab.txt
   done
