@@ -374,6 +374,10 @@ def main():
             kern_ms.append(float(st.render_ms))
             if st.shader_clock_mhz > 0:
                 clock_mhz.append(float(st.shader_clock_mhz))
+    # lane addresses a sample sends into the texture path with the loaded model: 8 per level, 2 for a level gathered from its
+    # cell-major quad copy (nrf_stats, ABI 6)
+    gather_addr_sample = int(ctx.stats().gather_addresses_per_sample) or GATHER_ADDR_PER_SAMPLE
+    grid_device_mb = round(int(ctx.stats().grid_device_bytes) / 1e6, 1)
     step_counts = [per_step[tuple(step_poses(i))] for i in range(args.steps)]
     # the sample count of the metric and of the roofline is the COMPOSITED one: the samples that reach a ray's compositing sum,
     # equal to the reference's own per-ray count (and the oracle's) and independent of timing; the kernel also evaluates the
@@ -455,7 +459,7 @@ def main():
     # sends 128: 16 levels x 8 corners, one address per lane whatever the entry size) against their rate at the clock the
     # launch itself measured (s_memtime / s_memrealtime inside the kernel, nrf_stats.shader_clock_mhz)
     clock_hz = float(np.mean(clock_mhz)) * 1e6 if clock_mhz else None
-    addr_per_s = float(np.mean(step_evaluated)) * GATHER_ADDR_PER_SAMPLE / iso_kern_s
+    addr_per_s = float(np.mean(step_evaluated)) * gather_addr_sample / iso_kern_s
     ta_peak = TA_UNITS * TA_ADDR_PER_CLK * clock_hz if clock_hz else None
     in_flight = mean_kern_s * 1e3 / ms_per_step
     single_view_ms = float(np.mean(single_ms))
@@ -531,7 +535,11 @@ def main():
             # (`configs`) -- because the table is served from L2 / Infinity Cache and an aligned 8- or 16-byte entry costs one
             # address like a 4-byte one: bytes per address change, addresses per second do not.
             "gather_addr_frac": round(addr_per_s / ta_peak, 5) if ta_peak else None,
-            "gather_addr_per_s": round(addr_per_s / 1e9, 2), "gather_addr_unit": "G lane-addresses/s (evaluated samples x 128 / isolated launch time)",
+            "gather_addr_per_s": round(addr_per_s / 1e9, 2), "gather_addr_unit": f"G lane-addresses/s (evaluated samples x {gather_addr_sample} / isolated launch time)",
+            "gather_addresses_per_sample": gather_addr_sample,
+            "grid_device_mb": grid_device_mb,
+            "gather_addresses_note": "8 per level read corner by corner (4-byte entries), 2 per level read as two aligned 16-byte quads from its "
+                                     "cell-major copy; 128 = no copies (the reference's table alone)",
             "gather_addr_peak": round(ta_peak / 1e9, 2) if ta_peak else None,
             "gather_addr_peak_is": f"{TA_UNITS} texture addressers x {TA_ADDR_PER_CLK:g} lane addresses per clock x the measured clock",
             "shader_clock_mhz_measured": round(clock_hz / 1e6, 1) if clock_hz else None,
@@ -642,7 +650,7 @@ def configs_bench(nh, torch, dev, desc2):
         t = float(np.mean(ms[2:])) * 1e-3
         comp, ev = int(stt.n_composited), int(stt.n_samples)
         # gathered bytes and lane addresses per sample of THIS model: levels x 8 corners x (F fp16 values | one address)
-        addrs, bytes_ = int(desc.n_levels) * 8, int(desc.n_levels) * 8 * 2 * int(desc.n_features_per_level)
+        addrs, bytes_ = int(stt.gather_addresses_per_sample), int(desc.n_levels) * 8 * 2 * int(desc.n_features_per_level)
         clk = float(stt.shader_clock_mhz) * 1e6
         return {"views_per_launch": V, "resolution": f"{W}x{H}", "ms_per_launch": round(t * 1e3, 4), "ms_per_view": round(t * 1e3 / V, 4),
                 "frames_per_s": round(V / t, 1), "msamples_s": round(comp / t / 1e6, 1), "evaluated_msamples_s": round(ev / t / 1e6, 1),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 5
+#define NRF_ABI_VERSION 6
 #define NRF_MAX_VIEWS 128 /* cameras one launch of the fused kernel takes (nrf_render_views) */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -124,6 +124,14 @@ typedef struct nrf_model_desc {
    * none -- nrf_generate_density_grid evaluates one from the network before the first render              */
   const float* density_grid;
   uint64_t n_density_grid;
+  /* (ABI 6) Device memory the library may spend on GATHER COPIES of the hash grid, in MB; 0 = the default: 8192, but no more
+   * than a sixteenth of the device's memory; 1 = none.  For the base.json grid shape (L = 16, F = 2, Linear) the render kernel
+   * reads a level's eight trilinear corners as two aligned 16-byte "quads" from a cell-major copy of the level (every entry
+   * copied, on the device, from the index grid.h:100-117 names: the same bits) instead of eight 4-byte table entries -- a
+   * quarter of the gather addresses.  Copies are made four levels at a time, in level order, while they fit: levels 0..7 of
+   * base.json's grid take 95 MB, levels 8..11 another 4.5 GB (MI355X, 1080p: 11.7 -> 10.7 -> 10.1 ms per 16 views).  The table
+   * the reference defines is kept beside them.  The environment variable NRF_QUAD_BUDGET_MB overrides this field.         */
+  uint32_t gather_copy_budget_mb;
 } nrf_model_desc;
 
 /* Level geometry derived on the host exactly as the reference does
@@ -200,6 +208,11 @@ typedef struct nrf_stats {
   float shader_clock_mhz; /* the core clock the last launch of the persistent render kernel ran at, measured in the launch:
                            d(s_memtime) / d(s_memrealtime) x 100 MHz between the entry and the exit of one wave per workgroup,
                            summed over the workgroups; 0 when the last render did not run that kernel                    */
+  uint32_t gather_addresses_per_sample; /* (ABI 6) lane addresses one evaluated sample sends into the texture path with the loaded
+                           model: 8 per level (the corners of grid.h:236-262), 2 for a level that is gathered from its cell-major quad
+                           copy (two aligned 16-byte entries), 1 per level with Nearest interpolation                              */
+  uint64_t grid_device_bytes; /* (ABI 6) device memory of the loaded model's hash grid: the reference-order table + its gather copies
+                           (nrf_model_desc.gather_copy_budget_mb)                                                                  */
 } nrf_stats;
 
 typedef struct nrf_context nrf_context;

@@ -292,6 +292,10 @@ struct nrf_context {
   int plan_max_pos = 1 << 14;  // launches of up to this many strips are planned (NRF_PLAN_MAX_POS; 0: never) -- one or two 1080p views
   void* d_counters = nullptr;  // CALL_RING slots of statistics counters + work queues, one per render call (call_slot)
   int call_index = 0;          // ring position of the last render call
+  int quad_levels = -1;        // NRF_QUAD_LEVELS=n: only the first n levels (whole steps of four) may get a cell-major quad copy (0: none; A/B runs)
+  int quad_budget_mb = -1;     // NRF_QUAD_BUDGET_MB=m overrides nrf_model_desc.gather_copy_budget_mb (A/B runs, render_server deployments)
+  uint64_t table_bytes = 0, table_ref_bytes = 0;  // device bytes of the grid table with / without the quad copies
+  uint32_t gather_addresses = 0;  // lane addresses one sample sends into the texture path with the loaded model (nrf_stats)
   bool allow_gen_fast_grid = true;  // NRF_GEN_FAST_GRID=0: the generic instance always encodes with gen_level (A/B runs)
   int march_ff = 1;            // NRF_MARCH_FF=0: no barrier fast-forward ahead of t_skip (A/B runs, equality tests)
   int tail_split = 1;          // NRF_TAIL_SPLIT=0: no tail splitting in the persistent kernel (A/B runs)
@@ -365,6 +369,8 @@ void free_model(nrf_context* c) {
 constexpr int CALL_RING = 16;  // render calls of one context that may be in flight on different streams
 constexpr size_t CALL_SLOT_BYTES = COUNTER_BYTES + 128 + 65536;  // statistics | work queues | the diagnostic build's per-wave stamps
 constexpr int HOST_SLOTS = 2;
+// Cell-major quad copies of grid levels (nrf_load_model; nrf_device.h level_gather_quad): which levels get one by default.
+constexpr uint32_t QUAD_BUDGET_MB_DEFAULT = 8192;  // base.json's grid: levels 0..7 take 95 MB, levels 8..11 4.5 GB; levels 12..15 (216 GB) are never worth it
 inline char* call_slot(const nrf_context* c, int index) { return (char*)c->d_counters + (size_t)(index % CALL_RING) * CALL_SLOT_BYTES; }
 
 void free_host_slots(nrf_context* c) {
@@ -830,6 +836,8 @@ int nrf_create(int device, nrf_context** out) {
   if (const char* e = std::getenv("NRF_TAIL_SPLIT")) c->tail_split = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("NRF_MARCH_FF")) c->march_ff = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("NRF_GEN_FAST_GRID")) c->allow_gen_fast_grid = std::atoi(e) != 0;
+  if (const char* e = std::getenv("NRF_QUAD_LEVELS")) c->quad_levels = std::atoi(e);
+  if (const char* e = std::getenv("NRF_QUAD_BUDGET_MB")) c->quad_budget_mb = std::max(0, std::atoi(e));
   HIP_TRY(hipMalloc(&c->d_counters, CALL_RING * CALL_SLOT_BYTES));
   HIP_TRY(hipMemset(c->d_counters, 0, CALL_RING * CALL_SLOT_BYTES));
   if (const char* e = std::getenv("NRF_PLAN_MAX_POS")) c->plan_max_pos = std::max(0, std::min(std::atoi(e), (int)PLAN_CAP));
@@ -1048,6 +1056,56 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   }
   if ((uint64_t)grid16.size() * 2 >= (1ull << 32))  // level_gather addresses the table by 32-bit byte offsets
     return fail(NRF_E_UNSUPPORTED, "hash tables of 4 GiB or more are not supported");
+  // Cell-major quad copies (round 6; nrf_device.h level_gather_quad) behind the reference-order table, for the instances whose
+  // network phase is network_from_lds with an F = 2 x 16 grid (the hot instance, its wide / width / depth forms): per cell
+  // (x, y, z), x, y < res, z <= res, the four entries of the corners (x | x + 1, y | y + 1, z) as grid_index (grid.h:100-117)
+  // names them.  The reference-order table stays: every other kernel (stage entry points, generic instance) reads it.
+  // A step of the fused kernel (levels 4 jl .. 4 jl + 3, one per lane group) takes quads as a whole or not at all (steps that
+  // mix the two forms run both instruction streams: measured no faster, profiles/r06/quad_sweep.txt); steps are granted in order
+  // while their copies fit the budget (nrf_model_desc.gather_copy_budget_mb).  Copies that end beyond the 4 GiB a buffer
+  // resource's byte offset reaches are FAR: addressed in 16-byte units from the table base (level_gather_quad_far).
+  uint32_t quad_mask = 0, quad_far = 0;
+  uint64_t table_bytes = (uint64_t)grid16.size() * 2;  // device bytes: the reference-order table + the quad copies (built on the device, below)
+  const bool quad_shape = !generic_grid && F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR && !hot_grid &&
+                          (!generic || hot_width || wide_sh);
+  if (quad_shape) {
+    uint64_t budget_mb = QUAD_BUDGET_MB_DEFAULT;  // ... but no more than a sixteenth of the device's memory
+    {
+      size_t mem_free = 0, mem_total = 0;
+      if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) budget_mb = std::min<uint64_t>(budget_mb, (uint64_t)mem_total >> 24);
+      else (void)hipGetLastError();
+    }
+    if (d->gather_copy_budget_mb) budget_mb = d->gather_copy_budget_mb;
+    if (c->quad_budget_mb >= 0) budget_mb = (uint64_t)c->quad_budget_mb;
+    uint64_t budget = budget_mb << 20;
+    const int max_steps = c->quad_levels < 0 ? 4 : std::min(c->quad_levels, 16) / 4;
+    uint64_t end_bytes = ((uint64_t)grid16.size() * 2 + 15) & ~15ull;
+    for (int jl = 0; jl < max_steps; ++jl) {
+      uint64_t step_bytes = 0;
+      bool ok = true;
+      for (int g = 0; g < 4; ++g) {
+        const LevelParams& Lv = lp[4 * jl + g];
+        ok = ok && (Lv.mode == LV_DENSE || Lv.mode == LV_HASH_POW2) && Lv.res >= 2 && Lv.res < 1024u;  // (res^2 << 4 < 2^24)
+        step_bytes += (uint64_t)Lv.res * Lv.res * ((uint64_t)Lv.res + 1) * 16;
+      }
+      if (!ok || step_bytes > budget || end_bytes + step_bytes >= (1ull << 36)) continue;
+      const bool far = end_bytes + step_bytes >= (1ull << 32);
+      if (far && !generic && wide) continue;  // (NET_WIDE is compiled without the far form: nrf_render.h network_from_lds)
+      budget -= step_bytes;
+      quad_mask |= 15u << (4 * jl);
+      if (far) quad_far |= 1u << jl;
+      for (int g = 0; g < 4; ++g) {
+        LevelParams& Lv = lp[4 * jl + g];
+        const uint32_t res = Lv.res;
+        Lv.q_off_b = far ? (uint32_t)(end_bytes >> 4) : (uint32_t)end_bytes;
+        Lv.q_my_b = far ? res : res << 4;
+        Lv.q_mz_b = far ? res * res : (res * res) << 4;
+        Lv.q_max = res - 1;
+        end_bytes += (uint64_t)res * res * (res + 1) * 16;
+      }
+    }
+    table_bytes = end_bytes;
+  }
   // Uploads go through the context's own stream and the device is drained afterwards: the
   // render stream is non-blocking, so a NULL-stream hipMemcpy gives no ordering against it
   // (seen on MI355X as a few stale table entries in the first frame after a reload).
@@ -1071,7 +1129,22 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     }
     L.mask_b = (hashed_pow2 || L.mode == LV_ADD_POW2) ? ((L.size - 1) << sh_b) : 0xffffffffu;
   }
-  HIP_TRY(upload(&c->d_grid, grid16.data(), grid16.size() * 2));
+  if (hipMalloc(&c->d_grid, table_bytes) != hipSuccess) {  // no room for the copies: the reference-order table alone
+    (void)hipGetLastError();
+    c->d_grid = nullptr;
+    for (LevelParams& Lv : lp) Lv.q_off_b = Lv.q_my_b = Lv.q_mz_b = Lv.q_max = 0;
+    quad_mask = quad_far = 0;
+    table_bytes = (uint64_t)grid16.size() * 2;
+    HIP_TRY(hipMalloc(&c->d_grid, table_bytes));
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_grid, grid16.data(), grid16.size() * 2, hipMemcpyHostToDevice, c->stream));
+  for (uint32_t l = 0; l < L; ++l) {  // the quad copies, from the table just uploaded (same stream)
+    if (!((quad_mask >> l) & 1u)) continue;
+    const LevelParams& Lv = lp[l];
+    const uint64_t q_bytes = ((quad_far >> (l >> 2)) & 1u) ? (uint64_t)Lv.q_off_b << 4 : (uint64_t)Lv.q_off_b;
+    HIP_TRY(launch_build_quads((const char*)c->d_grid + (size_t)Lv.offset * 4, Lv.res, Lv.size, Lv.mode == LV_HASH_POW2,
+                               (char*)c->d_grid + q_bytes, c->stream));
+  }
   HIP_TRY(upload(&c->d_wfrag, frags.data(), frags.size() * 2));
   if (generic || wide) HIP_TRY(upload(&c->d_gen, &G, sizeof(G)));
   if (wide) HIP_TRY(upload(&c->d_wfrag_gen, frags_gen.data(), frags_gen.size() * 2));
@@ -1087,7 +1160,7 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   DevModel& M = c->dm;
   std::memset(&M, 0, sizeof(M));
   M.grid = (const uint32_t*)c->d_grid;
-  M.grid_bytes = (uint32_t)(grid16.size() * 2);
+  M.grid_bytes = (uint32_t)std::min<uint64_t>(table_bytes, 0xffffffffull);  // (far quad copies lie beyond: no resource reads them)
   M.wfrag = (const uint4*)c->d_wfrag;
   M.lv = (const LevelParams*)c->d_lv;
   for (int i = 0; i < 6; ++i) M.aabb[i] = d->aabb[i];
@@ -1119,6 +1192,12 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
     }
     M.uni_modes |= (all_dense ? 1u : (all_hash ? 2u : 0u)) << (2 * jl);
   }
+  M.quad_mask = quad_mask;
+  M.quad_far = quad_far;
+  c->table_bytes = table_bytes;
+  c->table_ref_bytes = (uint64_t)grid16.size() * 2;
+  c->gather_addresses = 0;
+  for (uint32_t l = 0; l < L; ++l) c->gather_addresses += ((quad_mask >> l) & 1u) ? 2u : (d->interpolation == NRF_INTERP_NEAREST ? 1u : 8u);
   M.generic = generic ? 1u : 0u;
   M.wide = (!generic && wide) ? 1u : 0u;
   M.gen = (const GenModel*)c->d_gen;
@@ -1835,6 +1914,8 @@ int nrf_get_stats(nrf_context* c, nrf_stats* s) {
   s->n_composited = cnt[3];
   s->render_ms = ms;
   s->shader_clock_mhz = 0.f;
+  s->gather_addresses_per_sample = c->gather_addresses;
+  s->grid_device_bytes = c->table_bytes;
 #ifndef NRF_PHASE_TIMING  // (a diagnostic build keeps other quantities in these two counters)
   if (cnt[5] > 0) s->shader_clock_mhz = (float)((double)cnt[4] / (double)cnt[5] * 100.0);
 #endif

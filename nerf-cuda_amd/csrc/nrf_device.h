@@ -56,9 +56,14 @@ struct LevelParams {
   uint32_t my_b;    // y stride in bytes: LV_DENSE res << 2, LV_HASH_POW2 2654435761 << 2
   uint32_t mz_b;    // z stride in bytes: LV_DENSE (res * res) << 2, LV_HASH_POW2 805459861 << 2
   uint32_t mask_b;  // LV_HASH_POW2 (size - 1) << 2, else 0xffffffff
+  // cell-major quad copy of the level (round 6; level_gather_quad): q_off_b != 0 iff the level has one
+  uint32_t q_off_b;  // byte offset of the level's first quad (a multiple of 16) -- in units of 16 bytes for a FAR level (below)
+  uint32_t q_my_b;   // res << 4            (far: res)
+  uint32_t q_mz_b;   // (res * res) << 4    (far: res * res); all below 2^24 (v_mad_u32_u24)
+  uint32_t q_max;    // res - 1: the largest cell coordinate (far levels clamp to it: their gathers have no range check)
   uint32_t pad0, pad1;
 };
-static_assert(sizeof(LevelParams) == 48, "LevelParams layout");
+static_assert(sizeof(LevelParams) == 64, "LevelParams layout");
 
 // MFMA weight fragments, packed on the host (nrf_model.cpp: pack_fragments):
 // one fragment = 64 lanes x 8 halves (1 KiB), lane l, element j holds
@@ -154,6 +159,9 @@ struct DevModel {
   uint32_t grid_nearest;    // InterpolationType::Nearest (grid.h:215-232): the entry at floor(pos), no weights -- ONE gather per level (GRID instances)
   uint32_t wide_sh;         // SphericalHarmonics of degree 5..8 on the base.json shape: NET_WIDE_SH renders the frames (persistent kernel)
   uint32_t dir_w;           // padded width of the direction encoding (16 .. 80)
+  uint32_t quad_far;        // bit jl: step jl's four levels have FAR quad copies (beyond a buffer resource's 4 GiB: level_gather_quad_far)
+  uint32_t quad_mask;       // bit l: level l is gathered from its cell-major quad copy (level_gather_quad); granted four levels -- one unrolled
+                            // step jl of the fused kernel, all of its lane groups -- at a time (nrf_load_model)
 };
 
 // One camera of a batched launch (nrf_render_views): what differs between the views of a batch.
@@ -794,6 +802,60 @@ __device__ __forceinline__ void level_gather(const uint32_t* __restrict__ grid, 
 #endif
 #pragma unroll
   for (int c = 0; c < 8; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[c], 0, 0);
+}
+
+// Cell-major quad copy of a level (round 6): nrf_load_model stores, for every cell (x, y, z) a sample of the level can fall into
+// (x, y < res, z <= res), ONE 16-byte entry holding the four half2 table entries of the corners (x, y, z), (x + 1, y, z),
+// (x, y + 1, z), (x + 1, y + 1, z) -- each COPIED from the entry grid_index (grid.h:100-117) names for that corner, hash collisions
+// and wrapped dense indices included, so the eight values are bit for bit what level_gather returns, in the same corner order
+// (bit 0 of the corner number = x, bit 1 = y, bit 2 = z: grid.h:236-262).  A level's eight corners are then TWO aligned 16-byte
+// gathers -- the quads of cells (x, y, z) and (x, y, z + 1) -- instead of eight 4-byte ones: the texture addressers charge per
+// lane address (profiles/r02/gather_probe.txt), and the index arithmetic shrinks from ~20 vector instructions to 5.
+__device__ __forceinline__ void level_gather_quad(const uint32_t* __restrict__ grid, uint32_t grid_bytes, const LevelParams L, float px,
+                                                  float py, float pz, uint32_t (&v)[8], float (&frac)[3]) {
+  float fx = px * L.scale; fx = fx + 0.5f;
+  float fy = py * L.scale; fy = fy + 0.5f;
+  float fz = pz * L.scale; fz = fz + 0.5f;
+  const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;  // (floor: f >= 0.5, see level_offsets)
+  frac[0] = __builtin_amdgcn_fractf(fx);
+  frac[1] = __builtin_amdgcn_fractf(fy);
+  frac[2] = __builtin_amdgcn_fractf(fz);
+  // byte offset of quad (gx, gy, gz): every factor is below 2^24 (nrf_load_model grants quads to levels of res < 1024 only)
+  const uint32_t row = __umul24(gy, L.q_my_b) + L.q_off_b;
+  const uint32_t slab = __umul24(gz, L.q_mz_b) + row;
+  const uint32_t off0 = (gx << 4) + slab;
+  const uint32_t off1 = off0 + L.q_mz_b;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(grid), 0, grid_bytes, 0x00020000);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off0, 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off1, 0, 0);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// The same for quad copies beyond the 4 GiB a buffer resource's 32-bit byte offset reaches (levels 8..11 of base.json's grid are
+// 0.16 + 0.41 + 1.08 + 2.85 GB of quads): global loads from a 64-bit address, base + 16 x (a 32-bit quad number: 64 GiB of reach).
+// A global load has no range check, so the cell coordinates are clamped to the level's last cell -- the identity for positions
+// in [0, 1] (floor(scale + 0.5) <= ceil(scale) = res - 1), NaN converts to 0.
+__device__ __forceinline__ void level_gather_quad_far(const uint32_t* __restrict__ grid, const LevelParams L, float px, float py, float pz,
+                                                      uint32_t (&v)[8], float (&frac)[3]) {
+  float fx = px * L.scale; fx = fx + 0.5f;
+  float fy = py * L.scale; fy = fy + 0.5f;
+  float fz = pz * L.scale; fz = fz + 0.5f;
+  uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+  frac[0] = __builtin_amdgcn_fractf(fx);
+  frac[1] = __builtin_amdgcn_fractf(fy);
+  frac[2] = __builtin_amdgcn_fractf(fz);
+  gx = gx < L.q_max ? gx : L.q_max;
+  gy = gy < L.q_max ? gy : L.q_max;
+  gz = gz < L.q_max ? gz : L.q_max;
+  const uint32_t row = __umul24(gy, L.q_my_b) + L.q_off_b;
+  const uint32_t cell = __umul24(gz, L.q_mz_b) + row + gx;
+  const uint4* q = reinterpret_cast<const uint4*>(grid) + cell;
+  const uint4 a = q[0];
+  const uint4 b = q[L.q_mz_b];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
 // FAST (opt-in, nrf_options::fast_interp; never the default): acc = (half)(w * h + acc) as ONE v_fma_mixlo/hi_f16 per half and

@@ -607,6 +607,8 @@ int nrf_group_get_stats(nrf_group* g, nrf_stats* s) {
     s->n_network_evals += m.n_network_evals;
     s->n_composited += m.n_composited;
     if (m.render_ms > s->render_ms) s->render_ms = m.render_ms;  // members run concurrently
+    s->gather_addresses_per_sample = m.gather_addresses_per_sample;  // (one model, replicated)
+    s->grid_device_bytes = m.grid_device_bytes;
     if (m.shader_clock_mhz > 0.f && (s->shader_clock_mhz == 0.f || m.shader_clock_mhz < s->shader_clock_mhz))
       s->shader_clock_mhz = m.shader_clock_mhz;  // (the slowest member's)
   }

@@ -23,10 +23,33 @@ __global__ __launch_bounds__(256) void encode_grid_kernel(const DevModel M, cons
     const uint32_t s = (uint32_t)(i >> 4), level = (uint32_t)(i & 15u);
     const float px = pos01[3 * (size_t)s], py = pos01[3 * (size_t)s + 1], pz = pos01[3 * (size_t)s + 2];
     const uint32_t uni = (M.uni_modes >> (2 * (level >> 2))) & 3u;
-    if (uni == 2u) out[i] = encode_level<2, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
+    if ((M.quad_mask >> level) & 1u) {  // the render kernel gathers this level from its cell-major quad copy: so does this entry point
+      uint32_t v[8];
+      float fr[3];
+      if ((M.quad_far >> (level >> 2)) & 1u) level_gather_quad_far(M.grid, lvs[level], px, py, pz, v, fr);
+      else level_gather_quad(M.grid, M.grid_bytes, lvs[level], px, py, pz, v, fr);
+      out[i] = level_interp<FAST>(v, fr);
+    } else if (uni == 2u) out[i] = encode_level<2, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
     else if (uni == 1u) out[i] = encode_level<1, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
     else out[i] = encode_level<0, FAST>(M.grid, M.grid_bytes, lvs[level], px, py, pz);
   }
+}
+
+// The cell-major quad copy of a level (level_gather_quad): one thread per cell (x, y, z), x, y < res, z <= res, copies the entries
+// grid_index (T/.../grid.h:100-117) names for the corners (x | x + 1, y | y + 1, z) -- fast_hash & (size - 1) on a hashed level,
+// (x + y res + z res^2) % size on a dense one -- into one 16-byte entry.  Runs once per level at nrf_load_model.
+__global__ __launch_bounds__(256) void build_quads_kernel(const uint32_t* __restrict__ table, uint32_t res, uint32_t size, uint32_t hashed,
+                                                          uint4* __restrict__ quads) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+  if (x >= res) return;
+  uint32_t e[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t cx = x + (k & 1u), cy = y + (k >> 1);
+    const uint32_t idx = hashed ? ((cx ^ (cy * 2654435761u) ^ (z * 805459861u)) & (size - 1u)) : ((cx + cy * res + z * res * res) % size);
+    e[k] = table[idx];
+  }
+  quads[((size_t)z * res + y) * res + x] = make_uint4(e[0], e[1], e[2], e[3]);
 }
 
 // Generic instance: one thread per (sample, level) writes F halves of the row [feat_w]; level 0's thread also
@@ -822,6 +845,13 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
   const bool pow2 = lds_tab && pow2_h && M.cascade > 1 && pow2_bound;
   const hipError_t es = launch_strip(StripLaunch{&M, &P, &VB, rgba, depth, counters, st, lds, blocks, lds_tab, unit, pow2});
   if (es != hipSuccess) return es;
+  return hipGetLastError();
+}
+
+hipError_t launch_build_quads(const void* table, uint32_t res, uint32_t size, bool hashed, void* quads, hipStream_t st) {
+  if (res < 2 || res > 65535u) return hipErrorInvalidValue;  // (grid dimensions y, z)
+  const dim3 grid((res + 255u) / 256u, res, res + 1u);
+  hipLaunchKernelGGL(build_quads_kernel, grid, dim3(256), 0, st, (const uint32_t*)table, res, size, hashed ? 1u : 0u, (uint4*)quads);
   return hipGetLastError();
 }
 

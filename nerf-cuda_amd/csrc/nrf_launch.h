@@ -18,6 +18,9 @@ hipError_t launch_render(const DevModel& M, const FrameParams& P, const ViewBatc
 // a call's plan buffer (plan_price_kernel / plan_sort_kernel): 4 header words + a price and an order entry per queue position
 constexpr unsigned PLAN_CAP = 60u * 1024u;  // queue positions (strips) of a launch that may be planned (its last workgroup keeps a byte per position in LDS)
 constexpr size_t PLAN_BYTES = (4 + 2 * (size_t)PLAN_CAP) * 4;
+// Builds the cell-major quad copy of one level of an F = 2 grid (nrf_device.h level_gather_quad) on the device: table = the level's
+// entries in the reference order, quads = res * res * (res + 1) 16-byte entries.
+hipError_t launch_build_quads(const void* table, uint32_t res, uint32_t size, bool hashed, void* quads, hipStream_t st);
 hipError_t launch_encode_grid(const DevModel& M, const void* pos01, uint32_t n, void* out, hipStream_t st, bool fast_interp = false);
 hipError_t launch_encode_dir(const DevModel& M, const void* dir01, uint32_t n, void* out, hipStream_t st);
 hipError_t launch_mlp_forward(const DevModel& M, const void* feat, const void* dirfeat, uint32_t n, void* out, uint32_t repeat,

@@ -261,7 +261,14 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       for (int jl = 0; jl < 4; ++jl) {
         const LevelParams L = lvs[4 * jl + g];
         const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
-        if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        if ((M.quad_mask >> (4 * jl)) & 1u) {  // wave-uniform: the step's four levels are gathered from their cell-major quad copies
+          // (NET_WIDE -- Frequency directions evaluated per sample in-lane -- has no registers left for the far form's 64-bit
+          // addresses: nrf_load_model grants a wide model no far copies)
+          constexpr bool FARQ = !(RK > 1 && !SHROWS);
+          if (FARQ && ((M.quad_far >> jl) & 1u)) level_gather_quad_far(M.grid, L, px, py, pz, gv[jl], gf[jl]);
+          else level_gather_quad(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
+        }
+        else if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
         else if (uni == 1u) level_gather<1>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
         else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
       }

@@ -23,7 +23,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libnerfhip.so"
 
-NRF_ABI_VERSION = 5
+NRF_ABI_VERSION = 6
 GATHER_PEER_COPY, GATHER_RCCL = 0, 1  # nrf_group_set_gather
 NRF_MAX_VIEWS = 128
 NRF_OK, NRF_E_INVALID, NRF_E_UNSUPPORTED, NRF_E_NODEVICE, NRF_E_HIP, NRF_E_STATE, NRF_E_PARAMS = range(7)
@@ -66,6 +66,7 @@ class ModelDesc(C.Structure):
         ("n_params", C.c_uint64),
         ("density_grid", C.POINTER(C.c_float)),
         ("n_density_grid", C.c_uint64),
+        ("gather_copy_budget_mb", C.c_uint32),
     ]
 
 
@@ -132,6 +133,8 @@ class Stats(C.Structure):
         ("render_ms", C.c_float),
         ("n_composited", C.c_uint64),
         ("shader_clock_mhz", C.c_float),
+        ("gather_addresses_per_sample", C.c_uint32),
+        ("grid_device_bytes", C.c_uint64),
     ]
 
 

@@ -1081,3 +1081,49 @@ def test_large_frames_4k_and_8k(W, H):
     n_1080 = int(c.stats().n_composited)
     assert abs(n1 / n_1080 - (W * H) / (1920 * 1080)) <= 0.02 * (W * H) / (1920 * 1080)
     c.close()
+
+
+@pytest.mark.parametrize("log2T", [12, 19])
+def test_quad_gather_copies_change_no_bit(log2T):
+    """Round 6: the render kernel reads the levels of an F = 2 x 16 grid from cell-major quad copies (two aligned 16-byte gathers
+    per level instead of eight 4-byte ones; nrf_device.h level_gather_quad / _far) as far as nrf_model_desc.gather_copy_budget_mb
+    allows.  The copies hold the entries grid_index (T/.../grid.h:100-117) names, so NOTHING may change: features against the
+    oracle, and features / frames / sample counts between no copies (128 lane addresses per sample), the copies of levels 0..7
+    (95 MB: 80 addresses) and those of levels 0..11 (4.6 GB, the last four beyond a buffer resource's reach: 56 addresses)."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=log2T, H=32)
+    o = op.Oracle(desc)
+    rng = np.random.default_rng(11)
+    pos = rng.random((20000, 3), dtype=np.float32)
+    edge = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 1, 0], [1 - 2 ** -24, 2 ** -24, 0.5], [1, 1, 0], [0, 1, 1]], np.float32)
+    pos = np.concatenate([edge, pos])
+    # positions outside [0, 1] (a caller's garbage through the stage entry point): no value is promised, no fault may happen
+    wild = np.array([[-0.5, 0.5, 0.5], [1.5, 2.0, -3.0], [np.nan, 0.5, 0.5], [np.inf, -np.inf, 0.5], [1e30, 1e30, 1e30]], np.float32)
+    want = o.encode_grid(pos)
+    W, H = 96, 64
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(40, 25)
+    seen = {}
+    for budget, addrs in ((1, 128), (256, 80), (0, 56)):
+        d = nh.ModelDesc.from_buffer_copy(desc)  # (the pointers stay `keep`'s)
+        d.gather_copy_budget_mb = budget
+        h = nh.NerfHip(0)
+        try:
+            h.load_model(d)
+            p_d = dev(np.concatenate([pos, wild]))
+            out = torch.empty((len(pos) + len(wild), 32), dtype=torch.int16, device="cuda")
+            sync()
+            h.encode_grid(p_d.data_ptr(), len(pos) + len(wild), out.data_ptr())
+            got = out.cpu().numpy().view(np.uint16)[:len(pos)]
+            np.testing.assert_array_equal(got, want, err_msg=f"budget {budget} MB")
+            h.set_resolution(W, H)
+            h.render(cam, pose)
+            rgba, depth = h.read_f32()
+            st = h.stats()
+            assert st.gather_addresses_per_sample == addrs, (budget, st.gather_addresses_per_sample)
+            seen[budget] = (rgba.copy(), depth.copy(), int(st.n_composited), int(st.grid_device_bytes))
+        finally:
+            h.close()
+    for budget in (256, 0):
+        np.testing.assert_array_equal(seen[budget][0], seen[1][0])
+        np.testing.assert_array_equal(seen[budget][1], seen[1][1])
+        assert seen[budget][2] == seen[1][2]
+    assert seen[1][3] < 40e6 and 90e6 < seen[256][3] - seen[1][3] < 100e6 and 4.4e9 < seen[0][3] - seen[256][3] < 4.6e9
