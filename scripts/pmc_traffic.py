@@ -23,11 +23,13 @@ for f in glob.glob(f"{root}/pmc_*/**/*_counter_collection.csv", recursive=True):
                (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
         if "render_kernel" in r["Kernel_Name"] or "render_persistent_kernel" in r["Kernel_Name"]:
             rows.append(rec)
-        elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<false>", "mlp_forward_kernel<0>", "mlp_forward_kernelILb0E")) and "gen_mlp" not in r["Kernel_Name"]:
+        elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<false", "mlp_forward_kernel<0", "mlp_forward_kernelILb0E")) and "gen_mlp" not in r["Kernel_Name"]:
             # (rocprofv3 leaves this symbol mangled: its _Float16 parameter)
             mlp_rows.append(rec)  # the fused-MLP stage kernel, HBM-fed (scripts/mlp_steady.py under --pmc: profile_gpu.sh `mlp_*` passes)
         elif any(t in r["Kernel_Name"] for t in ("mlp_forward_kernel<true", "mlp_forward_kernel<1", "mlp_forward_kernelILb1E")) and "gen_mlp" not in r["Kernel_Name"]:
             mlp_res_rows.append(rec)  # the same kernel's register-resident loop (every chunk evaluated 64 times: no HBM stream)
+if glob.glob(f"{root}/pmc_mlp_*/**/*_counter_collection.csv", recursive=True) and not mlp_rows:
+    sys.exit("pmc_traffic.py: the mlp_* passes hold counter rows but none matched mlp_forward_kernel<false, ...>: kernel renamed?")
 # the batched launches of the timed region: the persistent kernel's grid is the same for every launch (one workgroup per
 # CU), so the single-view replays are told apart by their duration
 longest = max(r[4] for r in rows)
