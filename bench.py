@@ -1054,9 +1054,19 @@ def cpu_baseline(nh, dev, desc, cam, pose, W, H, div):
                                                                                       n_threads=threads)
     sampling = int((counts > 0).sum())
     dpx = np.abs(got - fused).max(axis=-1)  # per pixel
+    # which product of two a compiler fuses, and whether it fuses a product that has other uses, is its own choice: the same frame
+    # with the OTHER choice at every such site (nrfo_set_contract(2)) -- the spread is the uncertainty of this emulated distance
+    fused2, _, stf2, fcounts2, fhashes2 = op.Oracle(desc, contract=2).render_rays(c, pose, w, h, schedule=op.SCHED_PER_RAY, n_threads=threads)
+    sensitivity = {"what": "the same comparison with the other fusion choice at every ambiguous site (right product of two fused; "
+                           "`alpha * T`, which has other uses, not fused)",
+                   **dist_of(got, fused2), "rays_with_other_sample_set_frac": round(int((hashes != fhashes2).sum()) / max(sampling, 1), 6),
+                   "choice_1_vs_choice_2": dist_of(fused, fused2),
+                   "rays_differing_between_the_choices": int((fhashes != fhashes2).sum())}
     parity["vs_fma_contract"] = {
         "what": "HIP frame (every fp32 operation rounded) against the oracle with a * b + c fused wherever the reference's device "
-                "source has it in one expression (nvcc's default contraction)",
+                "source has it in one expression (nvcc's default contraction).  AN EMULATION of the reference binary's arithmetic "
+                "(parity unpinned: the reference cannot run here); `sensitivity` gives the spread over the compiler's own choices",
+        "sensitivity": sensitivity,
         **dist_of(got, fused), "frame": f"{w}x{h}", "max_abs_depth": float(np.abs(got_depth - fdepth).max()),
         # a ray whose sample set changes (one occupied cell more or less at a grazing hit) changes its pixel by whatever that
         # sample weighs: max_abs is not bounded by rounding here, the share of such pixels is

@@ -104,7 +104,13 @@ inline float h2f(uint16_t h) { return h2f_soft(h); }
 // is fused; of two products in one sum the LEFT one is fused and the right one rounded first (LLVM's combine order:
 // fadd(fmul(a, b), z) -> fma(a, b, z) is tried before fadd(z, fmul(a, b))); a product whose value is cast in between
 // ((T)(weight * data), grid.h:260) is not.
-inline float mad(bool contract, float a, float b, float c) { return contract ? fmaf(a, b, c) : a * b + c; }
+inline float mad(int contract, float a, float b, float c) { return contract ? fmaf(a, b, c) : a * b + c; }
+// `a * b + c * d`: which product is fused is the compiler's choice.  Mode 1: the left one (above); mode 2 (the sensitivity run of
+// nrfo_set_contract): the right one.
+inline float mad2(int contract, float a, float b, float c, float d) {
+  return contract == 2 ? fmaf(c, d, a * b) : (contract ? fmaf(a, b, c * d) : a * b + c * d);
+}
+static thread_local bool tl_fuse_right = false;  // operator+(Prod, Prod) below: set by the caller of a formula table (mode 2)
 
 // The same rule for whole formula tables (kernel_sh): a float that remembers being a product until it is used.  With
 // S = float a table is plain individually-rounded arithmetic; with S = Fx every `a*b + c`, `a*b - c`, `c + a*b`, `c - a*b`
@@ -143,8 +149,8 @@ inline Fx operator+(Fx c, Prod p) { return fmaf(p.a, p.b, c.v); }
 inline Fx operator-(Fx c, Prod p) { return fmaf(-p.a, p.b, c.v); }
 inline Fx operator+(float c, Prod p) { return fmaf(p.a, p.b, c); }
 inline Fx operator-(float c, Prod p) { return fmaf(-p.a, p.b, c); }
-inline Fx operator+(Prod p, Prod q) { return fmaf(p.a, p.b, q.value()); }
-inline Fx operator-(Prod p, Prod q) { return fmaf(p.a, p.b, -q.value()); }
+inline Fx operator+(Prod p, Prod q) { return tl_fuse_right ? fmaf(q.a, q.b, p.value()) : fmaf(p.a, p.b, q.value()); }
+inline Fx operator-(Prod p, Prod q) { return tl_fuse_right ? fmaf(-q.a, q.b, p.value()) : fmaf(p.a, p.b, -q.value()); }
 struct ShOut {  // one coefficient of the table: takes whatever the formula's last operation produced
   float v;
   ShOut& operator=(float f) { v = f; return *this; }
@@ -159,9 +165,18 @@ inline uint16_t hadd(uint16_t a, uint16_t b) { return f2h(h2f(a) + h2f(b)); }
 // T/include/tiny-cuda-nn/common_device.h:68-114 (warp_activation), applied to
 // an fp32 pre-activation; the caller rounds the result to fp16.
 inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tcnn's ReLU is a PRODUCT in the network's precision: `frag.x[t] * (T)((T)frag.x[t] > (T)0.0f)` with T = __half
+// (T/include/tiny-cuda-nn/common_device.h:71-76; R/include/nerf-cuda/nerf_network.h:36-37 for the sigma activation): a negative
+// value gives -0, NaN stays NaN and -inf -- an fp16 accumulator below -65504 -- becomes NaN (-inf * 0); max(x, 0) would give +0
+// for all three.  v is rounded to fp16 first (the reference's accumulator IS an fp16 value); the product of an fp16 value with
+// 0 or 1 is exact.  The HIP path clamps with v_pk_max_f16 instead: DESIGN.md deviation D-10, tests/test_parity_gpu.py.
+inline float relu_half(float v) {
+  const float h = h2f(f2h(v));
+  return h * (h > 0.0f ? 1.0f : 0.0f);
+}
 inline float activate(uint32_t act, float v) {
   switch (act) {
-    case NRF_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case NRF_ACT_RELU: return relu_half(v);
     case NRF_ACT_EXPONENTIAL: return expf(v);
     case NRF_ACT_SIGMOID: return logistic(v);
     case NRF_ACT_SQUAREPLUS: {
@@ -193,7 +208,8 @@ struct nrfo_model {
   std::vector<uint16_t> grid;                 // fp16 table
   std::vector<float> density_grid;
   uint32_t mlp_acc_block = 0;  // nrfo_set_mlp_accumulate: 0 = fp32 sums; n = fp16 accumulator updated every n products
-  bool contract = false;       // nrfo_set_contract: a * b + c as one fmaf wherever the reference's source has it in one expression
+  int contract = 0;            // nrfo_set_contract: a * b + c as one fmaf wherever the reference's source has it in one expression
+                               // (1: the rule of `mad` above; 2: the OTHER choice at every site where the compiler has one -- the sensitivity run)
   float scale_dev[16] = {};    // the level scale as the KERNEL computes it under contraction (grid.h:189): fmaf(exp2f(..), base, -1)
 };
 
@@ -202,6 +218,7 @@ extern "C" {
 const char* nrfo_last_error(void) { return g_err.c_str(); }
 uint16_t nrfo_f32_to_f16(float f) { return f2h(f); }
 float nrfo_f16_to_f32(uint16_t h) { return h2f(h); }
+float nrfo_activation(uint32_t act, float v) { return activate(act, v); }
 uint16_t nrfo_f32_to_f16_soft(float f) { return f2h_soft(f); }
 float nrfo_f16_to_f32_soft(uint16_t h) { return h2f_soft(h); }
 // the conversions in use against their bit-level definition: every 16-bit pattern one way, every `stride`-th 32-bit pattern
@@ -447,7 +464,8 @@ int nrfo_set_mlp_accumulate(nrfo_model* m, int mode) {
 // see `mad` above; the default (0) is the arithmetic contract shared with the HIP path
 int nrfo_set_contract(nrfo_model* m, int on) {
   if (!m) return fail(NRF_E_INVALID, "null model");
-  m->contract = on != 0;
+  if (on < 0 || on > 2) return fail(NRF_E_INVALID, "contract mode must be 0 (off), 1 (left product fused, aggressive fusion) or 2 (the other choices)");
+  m->contract = on;
   return NRF_OK;
 }
 
@@ -609,6 +627,7 @@ void encode_dir_one(const nrfo_model* m, const float d01[3], uint16_t* out) {
     for (uint32_t j = 0; j < pad; ++j) *o++ = f2h(1.0f);  // SH pads in FRONT (:57-64)
     const float x = d01[0] * 2.f - 1.f, y = d01[1] * 2.f - 1.f, z = d01[2] * 2.f - 1.f;  // (x 2: exact, fused or not)
     ShOut c[64];
+    tl_fuse_right = m->contract == 2;
     if (m->contract) sh_coefficients<Fx>(d.sh_degree, Fx(x), Fx(y), Fx(z), c);
     else sh_coefficients<float>(d.sh_degree, x, y, z, c);
     for (uint32_t j = 0; j < m->dir_raw; ++j) o[j] = f2h(c[j].v);
@@ -687,7 +706,7 @@ void network_encoded_one(const nrfo_model* m, const uint16_t* feat, const uint16
   // extract_density, nerf_network.h:49-61 + wrap_a_activation :32-47: fp32 math, fp16 store
   float s = dens[0];
   switch (m->d.sigma_activation) {
-    case NRF_ACT_RELU: s = s > 0.0f ? s : 0.0f; break;
+    case NRF_ACT_RELU: s = relu_half(s); break;
     case NRF_ACT_EXPONENTIAL: s = expf(s); break;
     case NRF_ACT_SIGMOID: s = logistic(s); break;
     default: break;  // wrap_a_activation returns the value unchanged otherwise
@@ -721,15 +740,15 @@ inline float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)
 
 // set_rays_d (render_utils.h:31-52): Eigen's fixed-size reductions are
 // unrolled as a + (b + c) (redux_novec_unroller splits [0,1) | [1,3)).
-inline void ray_dir(const float R[9], const float cam[4], int px, int py, float d[3], bool fm = false) {
+inline void ray_dir(const float R[9], const float cam[4], int px, int py, float d[3], int fm = 0) {
   const float i = (float)((double)px + 0.5);
   const float j = (float)((double)py + 0.5);
   const float zs = 1;
   const float xs = (i - cam[2]) / cam[0] * zs;
   const float ys = (j - cam[3]) / cam[1] * zs;
-  const float n = sqrtf(mad(fm, xs, xs, mad(fm, ys, ys, zs * zs)));
+  const float n = sqrtf(mad(fm, xs, xs, mad2(fm, ys, ys, zs, zs)));
   const float v[3] = {xs / n, ys / n, zs / n};
-  for (int r = 0; r < 3; ++r) d[r] = mad(fm, R[3 * r + 0], v[0], mad(fm, R[3 * r + 1], v[1], R[3 * r + 2] * v[2]));
+  for (int r = 0; r < 3; ++r) d[r] = mad(fm, R[3 * r + 0], v[0], mad2(fm, R[3 * r + 1], v[1], R[3 * r + 2], v[2]));
 }
 
 // kernel_near_far_from_aabb, render_utils.h:353-391
@@ -772,7 +791,7 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
   const float dt_min = 2 * 1.7320508075688772f / 1024;  // MIN_STEPSIZE :181-183
   const float dt_max = 2 * bound / (float)H;
   const float Hm1 = (float)(H - 1);
-  const bool fm = m->contract;  // nrfo_set_contract: :595-597 `ox + t * dx`, :609-614 `x * mip_rbound + 1`, :643-645 `(..) * mip_bound - x`
+  const int fm = m->contract;  // nrfo_set_contract: :595-597 `ox + t * dx`, :609-614 `x * mip_rbound + 1`, :643-645 `(..) * mip_bound - x`
   uint32_t step = 0;
   float last_t = t;
   while (t < far && step < n_step) {
@@ -823,7 +842,7 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
 // fmaf(alpha, T, weight_sum) -- the product `alpha * T` has other uses, which the NVPTX back end fuses all the same
 // (enableAggressiveFMAFusion); `weight` itself stays the rounded product.
 inline float composite_one(const float* sigmas, const float* rgbs, const float* deltas,
-                           uint32_t n_step, float t, float* st, bool fm = false) {
+                           uint32_t n_step, float t, float* st, int fm = 0) {
   float weight_sum = st[0], dd = st[1], r = st[2], g = st[3], b = st[4];
   uint32_t step = 0;
   while (step < n_step) {
@@ -831,7 +850,7 @@ inline float composite_one(const float* sigmas, const float* rgbs, const float* 
     const float alpha = 1.0f - expf(-sigmas[step] * deltas[2 * step]);  // reference: __expf
     const float T = 1 - weight_sum;
     const float weight = alpha * T;
-    weight_sum = fm ? fmaf(alpha, T, weight_sum) : weight_sum + weight;
+    weight_sum = fm == 1 ? fmaf(alpha, T, weight_sum) : weight_sum + weight;  // (mode 2: a product with other uses is NOT fused)
     t += deltas[2 * step + 1];
     dd = mad(fm, weight, t, dd);
     r = mad(fm, weight, rgbs[3 * step + 0], r);

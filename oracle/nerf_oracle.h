@@ -69,7 +69,10 @@ int nrfo_set_mlp_accumulate(nrfo_model* m, int mode);
  * (grid.h:189), kernel_sh's polynomials (spherical_harmonics.h:66-152), frequency_encoding (frequency.h:88), the sums of
  * kernel_composite_rays (:712-720) and get_image_and_depth (:258-260).  Not fused: products cast before they are added
  * (grid.h:260), host code (nerf_matrix_to_ngp, the offset table).  Exists to MEASURE the distance between the contract and
- * what the reference binary computes; which of two products of a sum a compiler fuses is its choice (here: the left). */
+ * what the reference binary computes; which of two products of a sum a compiler fuses is its choice (here: the left).
+ * on == 2: the sensitivity run -- the OTHER choice at every site that has one: of two products the right one is fused, and a
+ * product with other uses (`alpha * T` in kernel_composite_rays) is not fused at all; the spread between modes 1 and 2 is the
+ * uncertainty of the emulated distance (tests/test_contract_modes.py, bench.py parity.vs_fma_contract).                    */
 int nrfo_set_contract(nrfo_model* m, int on);
 
 /* fp16 helpers (round-to-nearest-even, IEEE binary16).  nrfo_f32_to_f16 / nrfo_f16_to_f32 are what the oracle computes
@@ -79,6 +82,9 @@ float nrfo_f16_to_f32(uint16_t h);
 uint16_t nrfo_f32_to_f16_soft(float f);
 float nrfo_f16_to_f32_soft(uint16_t h);
 const char* nrfo_fp16_backend(void); /* "f16c" or "software" */
+/* one activation of the MLPs on an fp32 pre-activation (T/.../common_device.h:68-114), as mlp_one applies it -- for the known
+ * answers of tcnn's ReLU-as-a-product: negative -> -0, NaN -> NaN, below -65504 (an fp16 -inf) -> NaN                        */
+float nrfo_activation(uint32_t act, float v);
 /* conversions in use vs the software definition: all 2^16 halves, every stride-th of the 2^32 floats; returns mismatches */
 uint64_t nrfo_fp16_selfcheck(uint32_t stride);
 

@@ -46,6 +46,8 @@ def lib():
     L.nrfo_f32_to_f16_soft.restype = C.c_uint16
     L.nrfo_f16_to_f32_soft.argtypes = [C.c_uint16]
     L.nrfo_f16_to_f32_soft.restype = C.c_float
+    L.nrfo_activation.argtypes = [C.c_uint32, C.c_float]
+    L.nrfo_activation.restype = C.c_float
     L.nrfo_fp16_backend.restype = C.c_char_p
     L.nrfo_fp16_selfcheck.argtypes = [C.c_uint32]
     L.nrfo_fp16_selfcheck.restype = C.c_uint64
@@ -103,7 +105,7 @@ def _fp(a):
 
 
 class Oracle:
-    def __init__(self, desc: nh.ModelDesc, accumulate: int = ACC_FP32, contract: bool = False):
+    def __init__(self, desc: nh.ModelDesc, accumulate: int = ACC_FP32, contract: int = 0):
         self.L = lib()
         h = C.c_void_p()
         _ck(self.L.nrfo_create(C.byref(desc), C.byref(h)))
@@ -111,7 +113,7 @@ class Oracle:
         if accumulate != ACC_FP32:
             self.set_mlp_accumulate(accumulate)
         if contract:
-            self.set_contract(True)
+            self.set_contract(contract)
         fw, dw = C.c_uint32(), C.c_uint32()
         self.L.nrfo_widths(h, C.byref(fw), C.byref(dw))
         self.feat_width, self.dir_width = int(fw.value), int(dw.value)  # padded encoding widths (MLP input widths)
@@ -186,10 +188,12 @@ class Oracle:
         _ck(self.L.nrfo_density_grid(self.h, int(n_iterations), C.c_float(decay), grid.ctypes.data, C.byref(mean)))
         return grid, float(mean.value)
 
-    def set_contract(self, on: bool):
+    def set_contract(self, on: int):
         """`a * b + c` as one fused multiply-add wherever the reference's device source has it in one expression (nvcc's
-        default contraction); False (default): every operation rounded, the contract shared with the HIP path."""
-        _ck(self.L.nrfo_set_contract(self.h, int(bool(on))))
+        default contraction); 0 / False (default): every operation rounded, the contract shared with the HIP path; 1 / True: of two
+        products in a sum the left one is fused, products with other uses are fused as well; 2: the other choice at each of those
+        sites (the sensitivity run: an emulation's uncertainty)."""
+        _ck(self.L.nrfo_set_contract(self.h, int(on)))
 
     def render_rays(self, cam, pose, W, H, opts=None, schedule=SCHED_PER_RAY, n_threads=0):
         """render() + per ray the number of samples its march emitted and a hash of their (dt, t - last_t) bits."""

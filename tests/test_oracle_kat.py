@@ -133,6 +133,35 @@ def test_sigma_exp_saturates_to_fp16_inf():
     assert op.f16(math.exp(11.10)) == 0x7c00
 
 
+def test_relu_is_tcnns_product_not_a_max():
+    """tcnn's ReLU is `x * (T)(x > 0)` in the network's precision (T/include/tiny-cuda-nn/common_device.h:71-76, and
+    R/include/nerf-cuda/nerf_network.h:36-37 for the sigma activation): negative -> -0, NaN -> NaN, an fp16 accumulator of -inf
+    (any pre-activation below -65504) -> -inf * 0 = NaN, +inf -> +inf.  max(x, 0) -- the HIP path's v_pk_max_f16, DESIGN.md
+    deviation D-10 -- gives +0 for the first three."""
+    import struct
+    relu = lambda v: op.lib().nrfo_activation(nh.ACT["relu"], v)  # noqa: E731
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]  # noqa: E731
+    assert bits(relu(-1.5)) == 0x80000000 and bits(relu(-6e-8)) == 0x80000000   # -0 (also for what rounds to the smallest subnormal)
+    assert bits(relu(0.0)) == 0 and bits(relu(-0.0)) == 0x80000000                # 0 * 0, -0 * 0
+    assert math.isnan(relu(float("nan"))) and math.isnan(relu(float("-inf"))) and math.isnan(relu(-1.0e6))
+    assert relu(float("inf")) == float("inf") and relu(1.0e6) == float("inf")    # fp16 overflow of the accumulator
+    assert relu(3.0003) == 3.0 and relu(65504.0) == 65504.0                       # the value is an fp16 value
+    # a whole network: one hidden pre-activation below -65504 makes every output of the sample NaN (NaN x 0 in the next layers)
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    p = keep[0].copy()
+    D0 = np.zeros((64, 32), np.float32)
+    D0[np.arange(32), np.arange(32)] = 1.0
+    D0[1, 1] = -2.0
+    p[:64 * 32] = D0.reshape(-1)
+    desc2, keep2 = nh.desc_from_config({**cfg}, p, keep[1])
+    feat = np.full((3, 32), 0.25, np.float16)
+    feat[1, 1] = 60000.0          # -120000: an fp16 -inf
+    feat[2, 1] = np.float16("nan")
+    dirf = np.full((3, 16), 0.5, np.float16)
+    out = op.Oracle(desc2).mlp_forward(feat.view(np.uint16), dirf.view(np.uint16)).view(np.float16).astype(np.float32)
+    assert np.all(np.isfinite(out[0])) and np.all(np.isnan(out[1])) and np.all(np.isnan(out[2]))
+
+
 def test_param_and_grid_size_errors(base):
     desc, keep, _ = base
     import copy, ctypes

@@ -1127,3 +1127,37 @@ def test_quad_gather_copies_change_no_bit(log2T):
         np.testing.assert_array_equal(seen[budget][1], seen[1][1])
         assert seen[budget][2] == seen[1][2]
     assert seen[1][3] < 40e6 and 90e6 < seen[256][3] - seen[1][3] < 100e6 and 4.4e9 < seen[0][3] - seen[256][3] < 4.6e9
+
+
+def test_relu_non_finite_hidden_activations_clamp_to_zero_deviation_d10(ctx):
+    """DESIGN.md deviation D-10.  tcnn's ReLU is the product x * (half)(x > 0) (T/include/tiny-cuda-nn/common_device.h:71-76): a
+    hidden pre-activation that is NaN, or below -65504 (an fp16 -inf), stays / becomes NaN and poisons every output of the sample
+    -- the oracle says so (tests/test_oracle_kat.py::test_relu_is_tcnns_product_not_a_max).  The HIP path's ReLU is v_pk_max_f16
+    (and `v > 0 ? v : 0` in the generic instance): both cases clamp to 0, the sample's outputs are those of a network whose
+    hidden value is 0.  Pinned here so that the behaviour is a decision, not an accident."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32)
+    p = keep[0].copy()
+    D0 = np.zeros((64, 32), np.float32)
+    D0[np.arange(32), np.arange(32)] = 1.0
+    D0[1, 1] = -2.0
+    p[:64 * 32] = D0.reshape(-1)
+    desc2, keep2 = nh.desc_from_config({**cfg}, p, keep[1])
+    ctx.load_model(desc2)
+    feat = np.full((5, 32), 0.25, np.float16)
+    feat[1, 1] = 60000.0           # hidden row 1: -120000 -> fp16 -inf -> (reference: NaN) HIP: 0 ...
+    feat[2, 1] = 1.0               # ... like any other negative pre-activation
+    feat[3, 5] = np.float16("nan")  # NaN x 0 = NaN in EVERY row of the layer: (reference: all NaN) HIP: every hidden value 0 ...
+    feat[4, :] = 0.0               # ... like an all-zero input
+    dirf = np.full((5, 16), 0.5, np.float16)
+    out = torch.empty((5, 4), dtype=torch.float16, device="cuda")
+    f_d, d_d = dev(feat.view(np.uint16).view(np.int16)), dev(dirf.view(np.uint16).view(np.int16))
+    sync()
+    ctx.mlp_forward(f_d.data_ptr(), d_d.data_ptr(), 5, out.data_ptr())
+    got = out.cpu().numpy().view(np.uint16)
+    want = op.Oracle(desc2).mlp_forward(feat.view(np.uint16), dirf.view(np.uint16))
+    wf = want.view(np.float16).astype(np.float32)
+    assert np.all(np.isnan(wf[1])) and np.all(np.isnan(wf[3])) and np.all(np.isfinite(wf[[0, 2, 4]]))  # the reference's semantics
+    assert np.all(np.isfinite(got.view(np.float16).astype(np.float32)))
+    np.testing.assert_array_equal(got[1], got[2])
+    np.testing.assert_array_equal(got[3], got[4])
+    mlp_close(got[[0, 2, 4]].view(np.float16).astype(np.float32), wf[[0, 2, 4]], "finite samples")
