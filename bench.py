@@ -131,6 +131,10 @@ def parse_args():
     ap.add_argument("--check", action="store_true", default=None,
                     help="rank 0 also renders the frame unsharded and compares (default: on whenever there is more than one rank)")
     ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--dry-exchange", action="store_true",
+                    help="rehearsal of the N > 1 plumbing WITHOUT a GPU: the same launch, step plan (views per rank, shard / replica "
+                         "blocks, pose indices), rotating sink, gloo gather, untile and check, with shards filled by a per-pixel function "
+                         "of (pose, x, y) instead of renders.  What 8 ranks can execute on a box whose GPU takes at most 6 processes")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU exchange even with ONE rank: init_process_group(--backend), the shard rendered tile-major "
                          "and packed, the gather through the backend (RCCL: a one-rank communicator), the untile, the one-stream "
@@ -154,6 +158,113 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def step_plan(args, rank, world, replica):
+    """What a rank renders per step: (V views per rank and step, V_step views per step, shard_index, shard_count, scaling)."""
+    scaling = args.scaling or ("strong" if replica else "weak")
+    if replica:
+        # rank r takes the contiguous block r*V .. of the step's requests: whole frames, shard_count 1
+        if scaling == "strong":  # BASELINE's form: 64 requests per step whatever N is
+            V_step = args.views_per_step or CONFIG5_REQUESTS
+            assert V_step % world == 0, "config 5: the requests of a step must divide over the ranks"
+            V = V_step // world
+        else:                    # 8 requests per rank and step (= the 8-GPU share of BASELINE's 64)
+            V = args.views_per_step or CONFIG5_REQUESTS // 8
+            V_step = V * world
+        return V, V_step, 0, 1, scaling
+    # tile-parallel: every rank renders its strips of ALL V_step frames (launches of up to NRF_MAX_VIEWS views)
+    base = args.views_per_step or DEFAULT_VIEWS
+    V = V_step = base * world if scaling == "weak" else base
+    return V, V_step, rank, world, scaling
+
+
+def step_pose_indices(i, rank, V, V_step, replica, n_poses):
+    """(global pose indices of step i rendered by rank `rank`)"""
+    if replica:
+        return [(i * V_step + rank * V + v) % n_poses for v in range(V)]
+    return [(i * V + v) % n_poses for v in range(V)]
+
+
+def step_root(i, world, gather_root):
+    """the rank that assembles step i's frames: step % N (every rank is the sink once in N steps) or always rank 0"""
+    return i % world if gather_root == "rotate" else 0
+
+
+def dry_exchange(args, rank, world):
+    """--dry-exchange: every part of an N-rank step except the render, on the CPU (gloo).  A "rendered" pixel is the packed
+    value f(pose, x, y); rank r fills its tile-major shard of all the step's views (configs 2/3) or its block of whole frames
+    (config 5), the step's sink gathers, untiles (nerfhip.untile_numpy: the mapping the device kernel is tested against) and
+    compares with f evaluated directly.  One JSON line from rank 0, like a real run's, with `dry_exchange: true`."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import nerfhip as nh
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world
+    config = args.config or 3
+    replica = config == 5
+    W = args.width or (CONFIG5_RES if replica else WIDTH)
+    H = args.height or (CONFIG5_RES if replica else HEIGHT)
+    V, V_step, shard_index, shard_count, scaling = step_plan(args, rank, world, replica)
+    n_poses = CONFIG5_REQUESTS if replica else 8
+    tps = nh.tiles_per_shard(W, H, shard_count)
+    ys, xs = np.mgrid[0:H, 0:W]
+
+    def frame_of(pose):  # the "render" of a pose: one packed int32 per pixel
+        return (xs | (ys << 11) | ((pose + 1) << 22)).astype(np.int32)
+
+    if replica:
+        n_px = W * H
+    else:
+        n_px = tps * 64
+        tiles = nh.shard_tile_ids(W, H, rank, world)
+        lane = np.arange(64)
+        px = np.array([t[0] for t in tiles])[:, None] * 8 + (lane & 7)[None, :]
+        py = np.array([t[1] for t in tiles])[:, None] * 8 + (lane >> 3)[None, :]
+        inside = (px < W) & (py < H)
+    ok, sink_steps = True, 0
+    t0 = time.perf_counter()
+    for i in range(args.warmup + args.steps):
+        mine = step_pose_indices(i, rank, V, V_step, replica, n_poses)
+        send = np.zeros((V, n_px), np.int32)
+        for v, pose in enumerate(mine):
+            f = frame_of(pose)
+            if replica:
+                send[v] = f.reshape(-1)
+            else:
+                send[v, :len(tiles) * 64].reshape(len(tiles), 64)[inside] = f[py[inside], px[inside]]  # (a rank may own fewer tiles than tps)
+        root = step_root(i, world, args.gather_root)
+        parts = [torch.empty((V, n_px), dtype=torch.int32) for _ in range(world)] if rank == root else None
+        dist.gather(torch.from_numpy(send), parts, dst=root)
+        if rank == root:
+            sink_steps += 1
+            g = np.stack([p.numpy() for p in parts])  # [world][V][n_px]
+            for r in range(world if replica else 1):
+                for v, pose in enumerate(step_pose_indices(i, r, V, V_step, replica, n_poses)):
+                    got = g[r, v].reshape(H, W) if replica else nh.untile_numpy(g[:, v, :, None], W, H)[..., 0]
+                    ok = ok and np.array_equal(got, frame_of(pose))
+    elapsed = time.perf_counter() - t0
+    flags = torch.tensor([int(ok), sink_steps], dtype=torch.int64)
+    all_flags = [torch.zeros(2, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
+    dist.gather(flags, all_flags, dst=0)
+    dist.barrier()
+    if rank == 0:
+        sinks = [int(f[1]) for f in all_flags]
+        print(json.dumps({
+            "dry_exchange": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling,
+            "sharded_frame_equals_unsharded": all(int(f[0]) == 1 for f in all_flags),
+            "sink_steps_per_rank": sinks,
+            "config": {"workload": f"BASELINE config {config}: {W}x{H}, NO render (pixels = f(pose, x, y))",
+                       "parallelism": (f"replica{world}" if replica else f"tile{world}"), "views_per_step": V_step,
+                       "views_per_rank_and_step": V, "tiles_per_shard": (None if replica else tps),
+                       "gather_root": ("step % N" if args.gather_root == "rotate" else "rank 0")},
+            "distributed": {"world_size": world, "backend": "gloo",
+                            "launcher": "bench.py self-launch" if os.environ.get("NRF_BENCH_SELF_LAUNCHED") else "external"},
+            "elapsed_s": round(elapsed, 3)}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -168,6 +279,11 @@ def main():
         # a line with the wrong n_gpus is worse than no line
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the ranks itself)")
+
+    if args.dry_exchange:
+        if world < 2:
+            sys.exit("bench.py: --dry-exchange rehearses the N > 1 exchange: use --gpus N with N >= 2")
+        return dry_exchange(args, rank, world)
 
     import numpy as np
     import torch
@@ -214,22 +330,7 @@ def main():
     # batch (a few long-lived tiles) overlaps the head of the next.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
     depth = args.frames_in_flight or (2 if dist_on else DEFAULT_DEPTH)
-    scaling = args.scaling or ("strong" if replica else "weak")
-    if replica:
-        # rank r takes the contiguous block r*V .. of the step's requests: whole frames, shard_count 1
-        if scaling == "strong":  # BASELINE's form: 64 requests per step whatever N is
-            V_step = args.views_per_step or CONFIG5_REQUESTS
-            assert V_step % world == 0, "config 5: the requests of a step must divide over the ranks"
-            V = V_step // world
-        else:                    # 8 requests per rank and step (= the 8-GPU share of BASELINE's 64)
-            V = args.views_per_step or CONFIG5_REQUESTS // 8
-            V_step = V * world
-        shard_index, shard_count = 0, 1
-    else:
-        # tile-parallel: every rank renders its strips of ALL V_step frames (launches of up to NRF_MAX_VIEWS views)
-        base = args.views_per_step or DEFAULT_VIEWS
-        V = V_step = base * world if scaling == "weak" else base
-        shard_index, shard_count = rank, world
+    V, V_step, shard_index, shard_count, scaling = step_plan(args, rank, world, replica)
     opts = nh.default_options()
     opts.shard_index, opts.shard_count = shard_index, shard_count
     # one rank alone renders row-major frames; with --force-dist its single shard takes the shard layout, as every rank's does at N > 1
@@ -245,9 +346,7 @@ def main():
 
     def step_poses(i):
         """(global pose indices of step i rendered by THIS rank)"""
-        if replica:
-            return [(i * V_step + rank * V + v) % len(poses) for v in range(V)]
-        return [(i * V + v) % len(poses) for v in range(V)]
+        return step_pose_indices(i, rank, V, V_step, replica, len(poses))
 
     class Slot:
         pass
@@ -317,7 +416,7 @@ def main():
             # the rank that assembles this step's frames: step % N -- the receive of N - 1 shards (link-bound: 930 MB over
             # seven xGMI links at N = 8) and the untile of the step's frames are then every rank's duty once in N steps
             # instead of rank 0's in every step (scripts/overlap_test.py: 14.4 -> 13.5 ms per step on the sink)
-            root = i % world if args.gather_root == "rotate" else 0
+            root = step_root(i, world, args.gather_root)
             with torch.cuda.stream(comm):
                 comm.wait_event(sl.rendered)
                 dist.gather(sl.send, sl.parts if rank == root else None, dst=root)

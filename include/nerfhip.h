@@ -384,8 +384,9 @@ int nrf_group_destroy(nrf_group* grp);
  * communicator per member (ncclCommInitAll) and one group of ncclSend / ncclRecv to devices[0] per call -- a direct gather
  * over the point-to-point xGMI links; needs distinct devices (NRF_E_UNSUPPORTED otherwise) and librccl, which is opened
  * on this call (a process that never asks never loads it).  In this mode a ONE-member group runs the whole exchange too
- * (tile-major shard, send to self, untile).  Frames are the same bits either way.  May be called at any time between
- * renders; the environment variable NRF_GROUP_GATHER=rccl|peer sets it at nrf_group_create.                          */
+ * (tile-major shard, send to self, untile).  Frames are the same bits either way.  May be called between renders; it
+ * reallocates the group's buffers, so host-frame pointers handed out earlier become invalid and a ticket that has not been
+ * waited for makes it return NRF_E_STATE.  The environment variable NRF_GROUP_GATHER=rccl|peer sets it at nrf_group_create. */
 enum { NRF_GATHER_PEER_COPY = 0, NRF_GATHER_RCCL = 1 };
 int nrf_group_set_gather(nrf_group* grp, int mode);
 /* rccl_version: ncclGetVersion() of the opened library in RCCL mode (e.g. 22703), else 0 */

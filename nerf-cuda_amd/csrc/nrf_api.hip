@@ -689,7 +689,7 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
                          : M.hot_grid ? (size_t)render_persistent_lds_fixed_bytes(0u, 0u, 0u, 16) : (size_t)render_persistent_lds_width_bytes((int)M.hot_width);
     if (fixed + tables <= 160u * 1024u) {
       M.persistent = 1;
-      M.persist_waves = M.wide_sh ? 8 : (M.hot_width == 128 ? 12 : 16);  // nrf_render.h persist_waves(net)
+      M.persist_waves = (uint32_t)render_persist_waves_for(M.generic, M.wide, M.wide_sh, M.hot_width, M.hot_grid, march_form(M.H, M.cascade, M.bound));
       M.gen_weights_lds = 0;
       M.lds_dilated_words = (uint32_t)dilated.size();
       width_instance = true;
@@ -704,13 +704,9 @@ int set_density_grid(nrf_context* c, const float* density_grid, float mean_densi
     M.gen_weights_lds = 0;
     // (the wide instance with the generic march -- a grid size or bound that is no power of two -- is compiled for 8 waves:
     //  launch_render's choice of the march form, nrf_kernels_wide.hip)
-    int eb = 0;
-    const bool pow2_h = (M.H & (M.H - 1)) == 0;
-    const bool unit_march = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
-    const bool pow2_march = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
-    const bool wide_generic_march = M.wide && !M.generic && !unit_march && !pow2_march;
-    for (int waves : {wide_generic_march ? WIDE_GENERIC_MARCH_WAVES : render_persistent_waves(M.generic, M.wide), 8}) {
-      if (waves == 8 && !M.generic && !wide_generic_march) break;  // (only the generic instance has a second workgroup size)
+    const int first_waves = render_persist_waves_for(M.generic, M.wide, 0u, 0u, 0u, march_form(M.H, M.cascade, M.bound));
+    for (int waves : {first_waves, M.generic && first_waves != 8 ? 8 : 0}) {  // (only the generic instance has a second workgroup size)
+      if (waves == 0) break;
       const size_t fixed = (size_t)render_persistent_lds_fixed_bytes(M.generic, M.wide, M.gen_wave_bytes, waves) + tables;
       for (int wlds : {1, 0}) {
         if (wlds && (!M.generic || !allow_wlds)) continue;

@@ -304,6 +304,10 @@ int nrf_group_create(int n_devices, const int* devices, nrf_group** out) {
 int nrf_group_set_gather(nrf_group* g, int mode) {
   if (!g || (mode != NRF_GATHER_PEER_COPY && mode != NRF_GATHER_RCCL)) return gfail(NRF_E_INVALID, "nrf_group_set_gather: bad argument");
   if (mode == g->gather) return NRF_OK;
+  // the switch frees the host-frame slots (set_resolution below): a ticket that has not been waited for would be dropped, and its
+  // copy would land in freed pinned memory
+  for (const auto& h : g->hs)
+    if (h.pending) return gfail(NRF_E_STATE, "nrf_group_set_gather: a host-frame ticket is outstanding (nrf_group_wait_host_u8 first)");
   const size_t n = g->ctx.size();
   for (size_t i = 0; i < n; ++i) {  // nothing of the other transport is left in flight
     GHIP(hipSetDevice(g->devices[i]));

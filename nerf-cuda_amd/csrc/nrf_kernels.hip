@@ -815,10 +815,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
       e = first_launch ? clear_for_first() : hipMemsetAsync(queue, 0, RENDER_QUEUE_BYTES, st);
     }
     if (e != hipSuccess) return e;
-    const bool pow2_h = (M.H & (M.H - 1)) == 0;
-    int eb = 0;
-    const bool unit = pow2_h && M.cascade == 1 && M.bound >= 1.0f;
-    const bool pow2 = pow2_h && M.cascade > 1 && M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
+    const int form = march_form(M.H, M.cascade, M.bound);
+    const bool unit = form == MARCH_FORM_UNIT, pow2 = form == MARCH_FORM_POW2;
     const PersistLaunch L{&M, &P, &VB, rgba, depth, counters, queue, st, lds, wgs, waves, unit, pow2};
     if (M.wide_sh || M.wide) e = launch_persistent_wide(L);   // Frequency / SH directions beyond 16 values (nrf_kernels_wide.hip)
     else if (M.hot_width) e = launch_persistent_width(L);     // 16 / 32 / 128 neurons, other depths (nrf_kernels_width.hip)
@@ -838,11 +836,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
   const int lds = fixed + (lds_tab ? 4 * (int)(M.lds_coarse_words + M.lds_ctab_floats) : 0);
   // hot instances: compile-time activations, march tables in LDS; a power-of-two grid with either one cascade and
   // mip_bound == 1 (MARCH_UNIT) or several cascades and a power-of-two bound (MARCH_POW2)
-  const bool pow2_h = (M.H & (M.H - 1)) == 0;
-  const bool unit = lds_tab && pow2_h && M.cascade == 1 && M.bound >= 1.0f;
-  int eb = 0;
-  const bool pow2_bound = M.bound >= 1.0f && frexpf(M.bound, &eb) == 0.5f;
-  const bool pow2 = lds_tab && pow2_h && M.cascade > 1 && pow2_bound;
+  const int form = march_form(M.H, M.cascade, M.bound);
+  const bool unit = lds_tab && form == MARCH_FORM_UNIT, pow2 = lds_tab && form == MARCH_FORM_POW2;
   const hipError_t es = launch_strip(StripLaunch{&M, &P, &VB, rgba, depth, counters, st, lds, blocks, lds_tab, unit, pow2});
   if (es != hipSuccess) return es;
   return hipGetLastError();
@@ -1078,15 +1073,22 @@ int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t 
   return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + waves * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
 }
 // ... of the 16-wave workgroup of a width instance (NET_W16 / NET_W32 / NET_W128)
+static int width_net(int width) { return width == 16 ? NET_W16 : (width == 32 ? NET_W32 : (width == 64 ? NET_DEPTH : NET_W128)); }
 int render_persistent_lds_width_bytes(int width) {
-  const int net = width == 16 ? NET_W16 : (width == 32 ? NET_W32 : (width == 64 ? NET_DEPTH : NET_W128));
-  return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + 16 * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
+  const int net = width_net(width);
+  return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + persist_waves(net) * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
+}
+int render_persist_waves_for(uint32_t generic, uint32_t wide, uint32_t wide_sh, uint32_t hot_width, uint32_t hot_grid, int form) {
+  if (wide_sh) return persist_waves(NET_WIDE_SH);
+  if (hot_grid) return persist_waves(hot_grid == 1 ? NET_GRID1 : (hot_grid == 2 ? NET_GRID2 : (hot_grid == 4 ? NET_GRID4 : NET_GRID8)));
+  if (hot_width) return persist_waves(width_net((int)hot_width));
+  if (wide && !generic && form == MARCH_FORM_GENERIC) return WIDE_GENERIC_MARCH_WAVES;  // (nrf_kernels_wide.hip)
+  return persist_waves(generic ? NET_GENERIC : (wide ? NET_WIDE : NET_HOT));
 }
 int render_persistent_lds_widesh_bytes() {  // the 8-wave workgroup of NET_WIDE_SH without its march tables
   return net_wfrag_bytes(NET_WIDE_SH) + LDS_LEVEL_BYTES + persist_waves(NET_WIDE_SH) * ((int)sizeof(WaveLds) + LDS_SHROW_BYTES) + LDS_QUEUE_BYTES;
 }
 int render_width_frags(int width) { return width == 16 ? MlpShape<16>::N : (width == 32 ? MlpShape<32>::N : (width == 128 ? MlpShape<128>::N : N_FRAGS)); }
-int render_persistent_waves(uint32_t generic, uint32_t wide) { return persist_waves(generic ? NET_GENERIC : (wide ? NET_WIDE : NET_HOT)); }
 int render_wide_lds_fixed_bytes() { return LDS_FIXED_BYTES + (LDS_WFRAG_WIDE_BYTES - LDS_WFRAG_BYTES) + RENDER_WAVES * LDS_RAYD_BYTES; }
 int render_lds_table_max_bytes() { return LDS_MARCH_TABLE_MAX; }
 int render_gen_lds_fixed_bytes(uint32_t gen_wave_bytes) { return LDS_LEVEL_BYTES + RENDER_WAVES * ((int)sizeof(WaveLds) + (int)gen_wave_bytes); }

@@ -1,6 +1,7 @@
 // nrf_launch.h -- host-callable launchers implemented in nrf_kernels.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 namespace nrf {
@@ -40,11 +41,25 @@ hipError_t launch_untile_rgbd8_u8(const void* gathered, int shard_count, int til
                                   void* depth8, hipStream_t st);
 hipError_t launch_quantize_rgbd8(const void* rgba, const void* depth, uint64_t n, void* out, hipStream_t st);
 hipError_t launch_quantize(const void* rgba, const void* depth, int n, void* rgb8, void* depth8, hipStream_t st);
+// The march form of a model and the waves of its persistent workgroup: ONE rule, read by set_density_grid (which sizes the
+// workgroup's LDS and decides whether the model fits the persistent kernel) and by launch_render (which picks the kernel
+// instance); the launch macros refuse a workgroup size other than their instance's.
+enum : int { MARCH_FORM_GENERIC = 0, MARCH_FORM_UNIT = 1, MARCH_FORM_POW2 = 2 };
+inline int march_form(uint32_t H, uint32_t cascade, float bound) {
+  const bool pow2_h = H != 0 && (H & (H - 1)) == 0;
+  int eb = 0;
+  if (pow2_h && cascade == 1 && bound >= 1.0f) return MARCH_FORM_UNIT;                                  // one cascade with mip_bound == 1
+  if (pow2_h && cascade > 1 && bound >= 1.0f && frexpf(bound, &eb) == 0.5f) return MARCH_FORM_POW2;    // several, power-of-two bound
+  return MARCH_FORM_GENERIC;
+}
+// waves of the persistent workgroup of the instance that renders such a model (hot_width: 0 or 16 / 32 / 64 / 128; hot_grid: 0 or the
+// F of a GRID instance); the generic
+// instance may also run WITH 8 (set_density_grid tries 12 first)
+int render_persist_waves_for(uint32_t generic, uint32_t wide, uint32_t wide_sh, uint32_t hot_width, uint32_t hot_grid, int form);
 // loads the code objects of the render kernel's instance families now instead of at their first launch
 void preload_kernels(bool all);
 int render_lds_bytes();
 int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t gen_wave_bytes, int waves);
-int render_persistent_waves(uint32_t generic, uint32_t wide);
 int render_persistent_lds_width_bytes(int width);  // LDS of a width instance's persistent workgroup (16 waves) without its march tables
 int render_persistent_lds_widesh_bytes();
 int render_width_frags(int width);                 // weight fragments of MlpShape<width>

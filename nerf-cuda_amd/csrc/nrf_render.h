@@ -1635,6 +1635,7 @@ void preload_grid();
 // one instance of the persistent form: WV waves per workgroup, WL = generic weights in LDS, 8-bit output / fast_interp chosen at run time
 #define NRF_LAUNCH_PERSISTENT_F(G, U, WV, WL, O8, FI)                                                                    \
   do {                                                                                                                   \
+    if (L.waves != (WV)) return hipErrorInvalidConfiguration; /* the host sized the workgroup's LDS for another instance */ \
     hipError_t e_ = allow_lds(render_persistent_kernel<G, U, WV, WL, O8, FI>, L.lds);                                    \
     if (e_ != hipSuccess) return e_;                                                                                     \
     hipLaunchKernelGGL((render_persistent_kernel<G, U, WV, WL, O8, FI>), dim3(L.wgs), dim3(64 * WV), L.lds, L.st, *L.M,  \

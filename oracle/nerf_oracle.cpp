@@ -216,14 +216,32 @@ struct nrfo_model {
 extern "C" {
 
 const char* nrfo_last_error(void) { return g_err.c_str(); }
-uint16_t nrfo_f32_to_f16(float f) { return f2h(f); }
-float nrfo_f16_to_f32(uint16_t h) { return h2f(h); }
-float nrfo_activation(uint32_t act, float v) { return activate(act, v); }
+// The entry points that need no model convert halves as well: on a CPU without the F16C instructions a -mf16c build answers
+// them with the software forms (the same bits) instead of an illegal instruction; everything that takes a model is behind
+// nrfo_create's refusal.
+static bool f16c_usable() {
+#ifdef __F16C__
+  static const bool ok = __builtin_cpu_supports("f16c");
+  return ok;
+#else
+  return true;  // (f2h / h2f ARE the software forms)
+#endif
+}
+uint16_t nrfo_f32_to_f16(float f) { return f16c_usable() ? f2h(f) : f2h_soft(f); }
+float nrfo_f16_to_f32(uint16_t h) { return f16c_usable() ? h2f(h) : h2f_soft(h); }
+float nrfo_activation(uint32_t act, float v) {
+  if (!f16c_usable() && act == NRF_ACT_RELU) {
+    const float h = h2f_soft(f2h_soft(v));
+    return h * (h > 0.0f ? 1.0f : 0.0f);
+  }
+  return activate(act, v);
+}
 uint16_t nrfo_f32_to_f16_soft(float f) { return f2h_soft(f); }
 float nrfo_f16_to_f32_soft(uint16_t h) { return h2f_soft(h); }
 // the conversions in use against their bit-level definition: every 16-bit pattern one way, every `stride`-th 32-bit pattern
 // the other (stride 1: all 2^32); returns the number of disagreements (NaNs must agree in their bits as well)
 uint64_t nrfo_fp16_selfcheck(uint32_t stride) {
+  if (!f16c_usable()) return 0;  // nothing but the software forms can run here (nrfo_create refuses this build on this CPU)
   uint64_t bad = 0;
   for (uint32_t h = 0; h < 65536u; ++h) {
     const float a = h2f((uint16_t)h), b = h2f_soft((uint16_t)h);

@@ -133,6 +133,51 @@ def test_forced_single_rank_runs_the_real_rccl_exchange():
     assert out["sharded_frame_equals_unsharded"] is True
 
 
+@pytest.mark.parametrize("cfg_args,want", [
+    # BASELINE config 3 at its own size: 8 shards of a 1920x1080 frame (tiles_per_shard(1920, 1080, 8) = 4 052 tiles: 8 100 strips, four ranks own one more than the others;
+    # weak scaling (1 x 8 frames per step), every rank the sink of exactly one of the 8 steps
+    (["--steps", "7", "--warmup", "1", "--views-per-step", "1"],
+     dict(parallelism="tile8", views_per_step=8, views_per_rank=8, sinks=[1] * 8, scaling="weak", tps=4052)),
+    # config 5 at its own size: 64 requests of 800x800 per step in 8 blocks of 8 whole frames, strong scaling
+    (["--config", "5", "--steps", "1", "--warmup", "1"],
+     dict(parallelism="replica8", views_per_step=64, views_per_rank=8, sinks=[1, 1, 0, 0, 0, 0, 0, 0], scaling="strong", tps=None)),
+    # a sink fixed at rank 0 and a frame whose strips do not divide over the ranks
+    (["--steps", "2", "--warmup", "0", "--views-per-step", "2", "--width", "328", "--height", "200", "--gather-root", "0", "--scaling", "strong"],
+     dict(parallelism="tile8", views_per_step=2, views_per_rank=2, sinks=[2, 0, 0, 0, 0, 0, 0, 0], scaling="strong", tps=None)),
+])
+def test_eight_rank_dry_exchange_through_bench_itself(cfg_args, want):
+    """the first real 8-GPU run should exercise only RCCL / xGMI for the first time.  A one-GPU box takes at
+    most 6 processes on its card, so the 8-rank rehearsal runs WITHOUT the card: `bench.py --gpus 8 --dry-exchange` starts its 8
+    ranks itself (torch.distributed.run, 127.0.0.1), runs bench.py's own step plan (step_plan / step_pose_indices / step_root:
+    the functions the GPU path calls), the gloo gather to the rotating sink, the untile and the check -- with f(pose, x, y) in
+    place of the render (the reference's exchange: R/src/nerf_render.cu:345-359)."""
+    out = _bench_line(["--gpus", "8", "--dry-exchange", *cfg_args], timeout=600)
+    assert out["dry_exchange"] is True and out["n_gpus"] == 8 and out["distributed"]["world_size"] == 8
+    assert out["distributed"]["launcher"] == "bench.py self-launch"
+    assert out["sharded_frame_equals_unsharded"] is True
+    c = out["config"]
+    assert c["parallelism"] == want["parallelism"] and c["views_per_step"] == want["views_per_step"]
+    assert c["views_per_rank_and_step"] == want["views_per_rank"] and out["scaling"] == want["scaling"]
+    assert out["sink_steps_per_rank"] == want["sinks"]
+    if want["tps"]:
+        assert c["tiles_per_shard"] == want["tps"]
+
+
+@pytest.mark.gpu
+def test_self_launched_four_rank_rehearsal_configs_3_and_5():
+    """Four ranks on the one device (with the test process: five on the card, the box allows six): the rotating sink over more
+    than two ranks, tiles_per_shard(.., 4), four replica blocks -- rendered, gathered (gloo), untiled on the GPU and checked
+    against unsharded renders.  Eight ranks: test_eight_rank_dry_exchange_through_bench_itself (no card)."""
+    out = _bench_line(["--gpus", "4", "--backend", "gloo", "--single-device", "--check", "--steps", "4", "--warmup", "1",
+                       "--views-per-step", "1", "--width", "488", "--height", "272"])
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "tile4" and out["config"]["views_per_step"] == 4
+    assert out["sharded_frame_equals_unsharded"] is True and out["config"]["gather_root"] == "step % N"
+    out = _bench_line(["--gpus", "4", "--config", "5", "--backend", "gloo", "--single-device", "--check", "--steps", "2",
+                       "--warmup", "1", "--views-per-step", "8", "--width", "200", "--height", "200"])
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "replica4" and out["config"]["views_per_rank_and_step"] == 2
+    assert out["sharded_frame_equals_unsharded"] is True
+
+
 def test_cpu_baseline_counts_the_cpus_the_cgroup_grants(tmp_path):
     """bench.py's cpu_baseline runs the oracle on the CPUs the box GRANTS, not on the ones it shows (the one-GPU box: 256 logical
     CPUs, a cgroup quota of 16 -- rounds 1-4 ran 128 threads taking turns on them): cgroup v2 `cpu.max`, v1 quota / period,

@@ -752,6 +752,16 @@ def test_device_group_rccl_gather_one_member(ctx):
     g.set_gather(nh.GATHER_RCCL)  # (a second communicator in one process)
     g.set_resolution(W, H)
     _check_group(g, n, cams, poses, want, want_u8, want_samples, "RCCL again")
+    # the switch reallocates the host-frame slots: refused while a ticket has not been waited for
+    ticket = g.submit_host_u8(cams, poses)
+    with pytest.raises(nh.NerfHipError, match="outstanding"):
+        g.set_gather(nh.GATHER_PEER_COPY)
+    assert g.gather()[0] == nh.GATHER_RCCL
+    rgb8, d8 = g.wait_host_u8(ticket)
+    for i in range(n):
+        np.testing.assert_array_equal(rgb8[i], want_u8[i][0])
+    g.set_gather(nh.GATHER_PEER_COPY)
+    _check_group(g, n, cams, poses, want, want_u8, want_samples, "peer copies after a waited ticket")
     g.close()
     g2 = nh.NerfGroup([0, 0])
     with pytest.raises(nh.NerfHipError, match="DISTINCT"):
