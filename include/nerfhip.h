@@ -151,7 +151,11 @@ typedef struct nrf_options {
   float dt_gamma;      /* 1/128  m_dt_gamma                                   */
   int32_t max_steps;   /* 1024   m_max_infer_steps                            */
   float density_scale; /* 1      m_density_scale                              */
-  int32_t perturb;     /* 0      m_perturb (only 0 implemented)               */
+  int32_t perturb;     /* 0      m_perturb.  > 0: the seed of kernel_march_rays' perturb branch (render_utils.h:550,
+                          585-589: t += MIN_STEPSIZE() * pcg32(n, perturb).next_float() ahead of every march call) -- in
+                          nrf_march n = the ray's place in the call; in rendered frames n = the ray's pixel and every sample's
+                          search is a call (the per-ray loop), in instances of the per-strip kernel (slower than the default
+                          path: the reference never takes this branch, m_perturb = false).  < 0: NRF_E_INVALID            */
   /* Sharding of one frame over ranks: the frame is cut into 8x8-pixel tiles
    * and those into strips of 4 horizontally adjacent tiles (32x8 pixels, one
    * workgroup); strip id = ty*ceil(ceil(W/8)/4) + tx/4, and strip id %

@@ -455,7 +455,8 @@ int fill_frame_params(nrf_context* c, const float cam[4], const float pose[16], 
   P.prog_done = P.prog_flags = nullptr;
   P.prog_epoch = 0;
   P.tail_split = c->tail_split;
-  P.march_ff = c->march_ff;
+  P.perturb = c->opt.perturb;
+  P.march_ff = c->opt.perturb ? 0 : c->march_ff;  // (the fast-forward replays a chain that starts at `near`: a shifted chain keeps its trips)
   P.fast_interp = c->opt.fast_interp ? 1 : 0;
   P.queue_classes = c->queue_classes;
   return NRF_OK;
@@ -1298,7 +1299,7 @@ int nrf_set_options(nrf_context* c, const nrf_options* o) {
   if (!c || !o) return fail(NRF_E_INVALID, "null argument");
   if (o->shard_count < 1 || o->shard_index < 0 || o->shard_index >= o->shard_count)
     return fail(NRF_E_INVALID, "bad shard");
-  if (o->perturb) return fail(NRF_E_UNSUPPORTED, "perturb is not implemented (m_perturb=false in the reference)");
+  if (o->perturb < 0) return fail(NRF_E_INVALID, "perturb must be >= 0 (0: off, the reference's m_perturb = false; > 0: the seed, render_utils.h:550)");
   if (o->max_steps < 1) return fail(NRF_E_INVALID, "max_steps must be >= 1");
   int rc = set_device(c);
   if (rc) return rc;
@@ -2127,7 +2128,7 @@ int nrf_march(nrf_context* c, const void* rays_o, const void* rays_d, const void
   STAGE_PROLOGUE();
   if (n_step < 1 || n_step > 8) return fail(NRF_E_INVALID, "n_step must be 1..8");
   if (n && (!rays_o || !rays_d || !rays_t || !fars || !xyzs || !dirs || !deltas)) return fail(NRF_E_INVALID, "null argument");
-  HIP_TRY(launch_march(c->dm, c->opt.dt_gamma, rays_o, rays_d, rays_t, fars, n, n_step, xyzs, dirs, deltas, st));
+  HIP_TRY(launch_march(c->dm, c->opt.dt_gamma, rays_o, rays_d, rays_t, fars, n, n_step, xyzs, dirs, deltas, st, (uint32_t)c->opt.perturb));
   STAGE_EPILOGUE();
 }
 

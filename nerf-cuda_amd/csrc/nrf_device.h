@@ -221,6 +221,8 @@ struct FrameParams {
                     // workgroup (tail splitting, nrf_render.h); 0 = they leave (A/B runs: NRF_TAIL_SPLIT=0)
   int march_ff;     // 1 = a ray steps straight to its last barrier plane ahead of t_skip (fast_forward_to_barrier); 0 = every
                     // trip of that stretch is simulated (A/B runs and the equality tests: NRF_MARCH_FF=0)
+  int perturb;      // nrf_options.perturb (render_utils.h:550, 585-589): > 0 = the seed of the march's per-ray shift of t (the host turns
+                    // the barrier fast-forward off with it: march_ff == 0)
   int sample_cap;   // the samples a ray may queue per round shrink with its transmittance T: fewer samples evaluated behind a ray's
                     // terminating one, frames unchanged (per-ray semantics).  2 (default) = what the ray still needs to reach
                     // T < 1e-4 if every sample halves T (clamp(exponent(T) + 13, 1, 8): never short of the need unless alpha > 0.5);
@@ -414,6 +416,21 @@ __device__ __forceinline__ MarchConst march_const(const DevModel& M, float dt_ga
     c.log2_bound = e - 1;  // exact when bound is a power of two (the only case it is used in)
   }
   return c;
+}
+
+// The perturb branch of kernel_march_rays (render_utils.h:585-589): `pcg32 rng(n, perturb); t += MIN_STEPSIZE() * rng.next_float()`
+// ahead of every march call.  pcg32_first_float = pcg32(initstate, initseq).next_float() (T/dependencies/pcg32/pcg32.h:48-62
+// seed, :65-71 next_uint, :108-117 next_float): the one number a freshly seeded generator is asked for.
+__device__ __forceinline__ float pcg32_first_float(uint64_t initstate, uint64_t initseq) {
+  const uint64_t MULT = 0x5851f42d4c957f2dULL;  // PCG32_MULT
+  const uint64_t inc = (initseq << 1u) | 1u;
+  uint64_t state = inc;            // seed(): state = 0; next_uint()
+  state += initstate;
+  state = state * MULT + inc;      // seed(): next_uint()
+  const uint32_t xorshifted = (uint32_t)(((state >> 18u) ^ state) >> 27u);  // next_float(): next_uint()'s output of this state
+  const uint32_t rot = (uint32_t)(state >> 59u);
+  const uint32_t r = (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+  return __builtin_bit_cast(float, (r >> 9) | 0x3f800000u) - 1.0f;
 }
 
 enum : int { MARCH_FOUND = 0, MARCH_EXHAUSTED = 1, MARCH_OUT_OF_BUDGET = 2 };

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
                                                     const float* __restrict__ rays_d, const float* __restrict__ rays_t,
                                                     const float* __restrict__ fars, uint32_t n, uint32_t n_step,
                                                     float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                    float* __restrict__ deltas) {
+                                                    float* __restrict__ deltas, uint32_t perturb) {
   const MarchConst mc = march_const(M, dt_gamma);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float ox = rays_o[3 * (size_t)i], oy = rays_o[3 * (size_t)i + 1], oz = rays_o[3 * (size_t)i + 2];
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256) void march_kernel(const DevModel M, float dt_g
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
     const int sx = __builtin_signbitf(dx) ? 0 : 1, sy = __builtin_signbitf(dy) ? 0 : 1, sz = __builtin_signbitf(dz) ? 0 : 1;
     const float far = fars[i];
-    float t = rays_t[i], last_t = t;  // kernel_march_rays with an explicit n_step: render_utils.h:591-653
+    float t = rays_t[i];  // kernel_march_rays with an explicit n_step: render_utils.h:591-653
+    if (perturb) t = t + mc.dt_min * pcg32_first_float((uint64_t)i, (uint64_t)perturb);  // :585-589, n = the ray's place in the call
+    float last_t = t;
     bool marching = true;
     for (uint32_t k = 0; k < n_step; ++k) {
       const size_t s = (size_t)i * n_step + k;
@@ -762,7 +764,8 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
   if (VB.blocks_per_view <= 0 || VB.n_views <= 0) return clear_for_first();  // a shard without a strip (tiny frames, many ranks)
   if (VB.n_views > MAX_VIEWS) return hipErrorInvalidValue;
   const int blocks = VB.blocks_per_view * VB.n_views;
-  const bool lds_tab = M.lds_coarse_words > 0;
+  const bool perturb = P.perturb != 0;  // (render_kernel's PERTURB instances: per-strip workgroups, tables in global memory)
+  const bool lds_tab = M.lds_coarse_words > 0 && !perturb;
   if (M.persistent && lds_tab) {
     // work queues: per view the strip rows its region of interest touches (sharded: the local strips of those rows)
     const int strips_x = (P.tiles_x + 3) >> 2, N = P.shard_count, idx = P.shard_index;
@@ -838,7 +841,7 @@ hipError_t launch_render(const DevModel& M, const FrameParams& Pin, const ViewBa
   // mip_bound == 1 (MARCH_UNIT) or several cascades and a power-of-two bound (MARCH_POW2)
   const int form = march_form(M.H, M.cascade, M.bound);
   const bool unit = lds_tab && form == MARCH_FORM_UNIT, pow2 = lds_tab && form == MARCH_FORM_POW2;
-  const hipError_t es = launch_strip(StripLaunch{&M, &P, &VB, rgba, depth, counters, st, lds, blocks, lds_tab, unit, pow2});
+  const hipError_t es = launch_strip(StripLaunch{&M, &P, &VB, rgba, depth, counters, st, lds, blocks, lds_tab, unit, pow2, perturb});
   if (es != hipSuccess) return es;
   return hipGetLastError();
 }
@@ -949,16 +952,16 @@ hipError_t launch_generate_rays(const DevModel& M, const FrameParams& P, void* r
 }
 
 hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, const void* rays_d, const void* rays_t,
-                        const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st) {
+                        const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st, uint32_t perturb) {
   if (!n) return hipSuccess;
   if (M.coarse_shift)
     hipLaunchKernelGGL(march_kernel<true>, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o,
                        (const float*)rays_d, (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs,
-                       (float*)deltas);
+                       (float*)deltas, perturb);
   else
     hipLaunchKernelGGL(march_kernel<false>, dim3(grid_for(n)), dim3(256), 0, st, M, dt_gamma, (const float*)rays_o,
                        (const float*)rays_d, (const float*)rays_t, (const float*)fars, n, n_step, (float*)xyzs, (float*)dirs,
-                       (float*)deltas);
+                       (float*)deltas, perturb);
   return hipGetLastError();
 }
 

@@ -12,7 +12,22 @@ namespace nrf {
                        (float4*)L.rgba, (float*)L.depth, (unsigned long long*)L.counters);                               \
   } while (0)
 
+#define NRF_LAUNCH_RENDER_PERTURB(G)                                                                                      \
+  do {                                                                                                                   \
+    hipError_t e_ = allow_lds(render_kernel<G, false, MARCH_GENERIC, true>, L.lds);                                      \
+    if (e_ != hipSuccess) return e_;                                                                                     \
+    hipLaunchKernelGGL((render_kernel<G, false, MARCH_GENERIC, true>), dim3(L.blocks), dim3(RENDER_THREADS), L.lds, L.st, *L.M, *L.P, \
+                       *L.VB, (float4*)L.rgba, (float*)L.depth, (unsigned long long*)L.counters);                        \
+  } while (0)
+
 hipError_t launch_strip(const StripLaunch& L) {
+  if (L.perturb) {  // nrf_options.perturb > 0 (render_utils.h:585-589): three instances of their own, march tables in global memory
+    if (L.lds_tab) return hipErrorInvalidConfiguration;
+    if (L.M->generic) NRF_LAUNCH_RENDER_PERTURB(NET_GENERIC);
+    else if (L.M->wide) NRF_LAUNCH_RENDER_PERTURB(NET_WIDE);
+    else NRF_LAUNCH_RENDER_PERTURB(NET_HOT);
+    return hipGetLastError();
+  }
   if (L.M->generic) {
     if (L.lds_tab) NRF_LAUNCH_RENDER(NET_GENERIC, true, MARCH_GENERIC); else NRF_LAUNCH_RENDER(NET_GENERIC, false, MARCH_GENERIC);
   } else if (L.M->wide) {

@@ -32,7 +32,8 @@ hipError_t launch_density_update(const void* sigma, uint32_t n, float decay, int
 hipError_t launch_generate_rays(const DevModel& M, const FrameParams& P, void* rays_o, void* rays_d, void* nears, void* fars,
                                 hipStream_t st);
 hipError_t launch_march(const DevModel& M, float dt_gamma, const void* rays_o, const void* rays_d, const void* rays_t,
-                        const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st);
+                        const void* fars, uint32_t n, uint32_t n_step, void* xyzs, void* dirs, void* deltas, hipStream_t st,
+                        uint32_t perturb = 0);
 hipError_t launch_composite(const void* sigmas, const void* rgbs, const void* deltas, uint32_t n, uint32_t n_step, void* rays_t,
                             void* state, hipStream_t st);
 hipError_t launch_untile(const void* gathered, int shard_count, int tiles_per_shard, int C, int W, int H, int n_views, void* out,

@@ -658,9 +658,25 @@ struct TileStats {
 // The rounds of one 8x8 tile (one wave, no workgroup barrier inside): march -> network -> compositing until no ray
 // of the tile is alive.  t / tc / alive: the rays' state after ray generation and the visibility walk.
 // acc: in = what the rays have composited before (zero for a fresh tile), out = after their last round.
+// The number n of a ray for the march's perturb branch (render_utils.h:585-589: pcg32(n, perturb)): its pixel, py * W + px -- what the
+// reference's first round uses for every ray (rays_alive starts as the identity).  pix_idx is that number for a row-major
+// frame; in the shard layout it is (local tile) * 64 + lane, from which the pixel follows through the strip arithmetic of
+// nrf_options (strip id % shard_count == shard_index).
+__device__ __forceinline__ uint32_t ray_number(const FrameParams& P, uint32_t pix_idx) {
+  if (!P.tile_major) return pix_idx;
+  const uint32_t k_local = pix_idx >> 6, l = pix_idx & 63u;
+  const uint32_t strips_x = ((uint32_t)P.tiles_x + 3u) >> 2;
+  const uint32_t strip = (k_local >> 2) * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
+  const uint32_t tx = (strip % strips_x) * 4u + (k_local & 3u), ty = strip / strips_x;
+  return (ty * 8u + (l >> 3)) * (uint32_t)P.W + tx * 8u + (l & 7u);
+}
+
 // HELP (persistent kernel): tail splitting -- ha names the workgroup's HelpLds; pix_idx / near / far travel with a ray that
 // is handed to a helper; *given = the lane's ray was handed over (its pixel is the helper's to store).
-template <int NET, bool COARSE_LDS, int MARCH, bool HELP = false, bool FAST = false>
+// PERTURB: the march's perturb branch (render_utils.h:585-589; nrf_options.perturb > 0).  Dead in the reference (m_perturb = false,
+// no setter), so it lives in instances of its own -- render_kernel<.., PERTURB = true>, nrf_kernels_strip.hip -- and costs the
+// product path no register: several persistent instances sit at their register limit.
+template <int NET, bool COARSE_LDS, int MARCH, bool HELP = false, bool FAST = false, bool PERTURB = false>
 __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams& P, const MarchConst& mc, const LdsMap& lm,
                                             const uint32_t* coarse_lds, const float* ctab_lds, int lane, const float (&o)[3],
                                             const float (&d)[3], float rdx, float rdy, float rdz, int sx, int sy, int sz,
@@ -744,6 +760,13 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
 #ifdef NRF_PHASE_TIMING
       const int budget_before = budget;
 #endif
+      float last_t = tc;  // (last_t == composited t)
+      if constexpr (PERTURB) {
+        // render_utils.h:585-589 with the per-ray loop's n_step == 1: EVERY sample's search starts at rays_t + the ray's shift,
+        // and last_t with it; a search that ran out of budget in the round before (t != tc) goes on where it was
+        last_t = tc + mc.dt_min * pcg32_first_float((uint64_t)ray_number(P, pix_idx), (uint64_t)(uint32_t)P.perturb);
+        if (t == tc) t = last_t;
+      }
       if (marching) {
         const int r = COARSE_LDS ? march_next<true, MARCH>(mc, M.occ_bits, coarse_lds, ctab_lds, o[0], o[1], o[2], d[0], d[1], d[2], rdx,
                                                     rdy, rdz, sx, sy, sz, far_m, t_skip, budget, t, x, y, z, dt)
@@ -765,7 +788,7 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
       if (found) {
         const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
         const float tn = t + dt;        // march: t += dt
-        const float delta = tn - tc;    // deltas[1] = t - last_t (last_t == composited t)
+        const float delta = tn - last_t;  // deltas[1] = t - last_t
         tc = tc + delta;                // composite: t += deltas[1]
         t = tc;                         // next march starts from rays_t
         W->pos[slot] = make_float4(x, y, z, __builtin_bit_cast(float, lane));
@@ -838,7 +861,7 @@ __device__ __forceinline__ void tile_rounds(const DevModel& M, const FrameParams
 // 128 VGPRs.  Small workgroups matter: a workgroup's LDS and wave slots are only released when its
 // slowest tile is done.
 // (the generic instance is bound by its LDS rows, not by registers: no 128-VGPR cap there)
-template <int NET, bool COARSE_LDS, int MARCH>
+template <int NET, bool COARSE_LDS, int MARCH, bool PERTURB = false>
 __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NET_WIDE ? 3 : 4)) void render_kernel(const DevModel M, const FrameParams P, const ViewBatch VB,
                                                      float4* __restrict__ rgba, float* __restrict__ depth,
                                                      unsigned long long* __restrict__ counters) {
@@ -1040,8 +1063,10 @@ __global__ __launch_bounds__(RENDER_THREADS, NET == NET_GENERIC ? 2 : (NET == NE
   NRF_STAMP(t_setup_done);
   TileAcc acc;
   TileStats ts;
-  tile_rounds<NET, COARSE_LDS, MARCH>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m, t_skip, t, tc,
-                                      alive, acc, ts);
+  // (pix_idx as in the persistent kernel: what ray_number reads for the perturb branch)
+  const uint32_t pix_idx = P.tile_major ? (uint32_t)k_local * 64u + (uint32_t)lane : (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+  tile_rounds<NET, COARSE_LDS, MARCH, false, false, PERTURB>(M, P, mc, lm, coarse_lds, ctab_lds, lane, o, d, rdx, rdy, rdz, sx, sy, sz, far_m,
+                                                             t_skip, t, tc, alive, acc, ts, 0, nullptr, pix_idx);
   const float ws = acc.ws, dep = acc.dep, cr = acc.cr, cg = acc.cg, cb = acc.cb;
   const unsigned n_samples = ts.n_samples, n_rounds = ts.n_rounds, n_tile_slots = ts.n_tile_slots;
   const unsigned n_composited = ts.n_composited;
@@ -1623,6 +1648,7 @@ struct StripLaunch {
   hipStream_t st;
   int lds, blocks;
   bool lds_tab, unit, pow2;
+  bool perturb;  // nrf_options.perturb > 0: the PERTURB instances (tables in global memory, generic march)
 };
 hipError_t launch_strip(const StripLaunch& L);
 void preload_hot();

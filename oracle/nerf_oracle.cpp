@@ -161,6 +161,25 @@ struct ShOut {  // one coefficient of the table: takes whatever the formula's la
 // fp16 addition: exact via fp32 (24 >= 2*11+2 bits, so double rounding is innocuous).
 inline uint16_t hadd(uint16_t a, uint16_t b) { return f2h(h2f(a) + h2f(b)); }
 
+// pcg32(initstate, initseq).next_float() (T/dependencies/pcg32/pcg32.h:48-62 seed, :65-71 next_uint, :108-117 next_float): the
+// first float of the generator the march seeds per ray and call (render_utils.h:586-589).
+inline float pcg32_first_float(uint64_t initstate, uint64_t initseq) {
+  const uint64_t MULT = 0x5851f42d4c957f2dULL;  // PCG32_MULT
+  const uint64_t inc = (initseq << 1u) | 1u;
+  uint64_t state = 0U;
+  state = state * MULT + inc;  // seed(): next_uint()
+  state += initstate;
+  state = state * MULT + inc;  // seed(): next_uint()
+  const uint64_t oldstate = state;  // next_float(): next_uint()
+  const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+  const uint32_t rot = (uint32_t)(oldstate >> 59u);
+  const uint32_t r = (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+  const uint32_t u = (r >> 9) | 0x3f800000u;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f - 1.0f;
+}
+
 // ---------------------------------------------------------- activations ----
 // T/include/tiny-cuda-nn/common_device.h:68-114 (warp_activation), applied to
 // an fp32 pre-activation; the caller rounds the result to fp16.
@@ -229,6 +248,7 @@ static bool f16c_usable() {
 }
 uint16_t nrfo_f32_to_f16(float f) { return f16c_usable() ? f2h(f) : f2h_soft(f); }
 float nrfo_f16_to_f32(uint16_t h) { return f16c_usable() ? h2f(h) : h2f_soft(h); }
+float nrfo_pcg32_first_float(uint64_t initstate, uint64_t initseq) { return pcg32_first_float(initstate, initseq); }
 float nrfo_activation(uint32_t act, float v) {
   if (!f16c_usable() && act == NRF_ACT_RELU) {
     const float h = h2f_soft(f2h_soft(v));
@@ -798,8 +818,10 @@ inline void near_far(const float* aabb, const float o[3], const float d[3], floa
 
 // kernel_march_rays for one ray, render_utils.h:556-653.  Returns the number
 // of emitted samples; xyz[k][3], delta[k][2].  *t_io is the march's own t.
+// perturb != 0 (:585-589): t += MIN_STEPSIZE() * pcg32(n, perturb).next_float() ahead of the loop, n = the ray's position in
+// the call's alive list; last_t starts at the shifted t, so the shift does not enter deltas[1] (nor rays_t).
 inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3], const float d[3],
-                          float far, float t, uint32_t n_step, float* xyz, float* delta) {
+                          float far, float t, uint32_t n_step, float* xyz, float* delta, uint32_t perturb = 0, uint64_t n = 0) {
   const float bound = m->d.bound;
   const uint32_t C = m->d.cascade, H = m->d.density_grid_size;
   const float* grid = m->density_grid.data();
@@ -811,6 +833,7 @@ inline uint32_t march_one(const nrfo_model* m, float dt_gamma, const float o[3],
   const float Hm1 = (float)(H - 1);
   const int fm = m->contract;  // nrfo_set_contract: :595-597 `ox + t * dx`, :609-614 `x * mip_rbound + 1`, :643-645 `(..) * mip_bound - x`
   uint32_t step = 0;
+  if (perturb) t = mad(fm, dt_min, pcg32_first_float(n, (uint64_t)perturb), t);
   float last_t = t;
   while (t < far && step < n_step) {
     const float x = clampf(mad(fm, t, dx, ox), -bound, bound);
@@ -889,6 +912,7 @@ struct RayState {
   float o[3], d[3], near, far;
   float st[5];
   float t;
+  uint32_t id;         // the ray's number: its pixel, py * W + px (the index of rays_o / rays_d in the reference)
   uint32_t n_emitted;  // samples the march emitted for this ray
   uint64_t hash;       // FNV-1a over the (dt, t - last_t) bits of every emitted sample: equal hashes <=> the same sample set
 };
@@ -938,7 +962,9 @@ void render_group(const nrfo_model* m, const nrf_options* opt, std::vector<RaySt
       RayState& r = rays[alive[a]];
       float xyz[8 * 3], delta[8 * 2], sig[8], rgb[8 * 3];
       for (int k = 0; k < n_step; ++k) delta[2 * k] = delta[2 * k + 1] = 0.0f;  // deviation D-1
-      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, (uint32_t)n_step, xyz, delta);
+      // (perturb: n = the ray's position in the alive list.  The reference compacts with atomicAdd, render_utils.h:394-415: its
+      //  order -- and with it every later round's random numbers -- differs from run to run; here the order is stable)
+      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, (uint32_t)n_step, xyz, delta, (uint32_t)opt->perturb, (uint64_t)a);
       note_samples(r, delta, cnt);
       for (uint32_t k = 0; k < cnt; ++k) network_one(m, opt->density_scale, xyz + 3 * k, r.d, sig + k, rgb + 3 * k);
       for (uint32_t k = cnt; k < (uint32_t)n_step; ++k) sig[k] = rgb[3 * k] = rgb[3 * k + 1] = rgb[3 * k + 2] = 0.0f;
@@ -971,7 +997,9 @@ void render_rays_independent(const nrfo_model* m, const nrf_options* opt, std::v
     uint64_t it = 0;
     while (it < (uint64_t)opt->max_steps && r.t >= 0) {
       float xyz[3], delta[2] = {0.0f, 0.0f}, sig = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
-      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, 1u, xyz, delta);
+      // (perturb: n = the ray's own number -- its pixel, what the reference's FIRST round uses for every ray; the schedule-free
+      //  definition the HIP kernel implements.  Differs from the round loop, whose n changes as other rays die)
+      const uint32_t cnt = march_one(m, opt->dt_gamma, r.o, r.d, r.far, r.t, 1u, xyz, delta, (uint32_t)opt->perturb, (uint64_t)r.id);
       note_samples(r, delta, cnt);
       if (cnt) network_one(m, opt->density_scale, xyz, r.d, &sig, rgb);
       r.t = composite_one(&sig, rgb, delta, 1u, r.t, r.st, m->contract);
@@ -1050,7 +1078,7 @@ int nrfo_march(const nrfo_model* m, const nrf_options* o, const float* rays_o, c
     std::fill(xyz, xyz + n_step * 3, 0.0f);
     std::fill(dl, dl + n_step * 2, 0.0f);
     std::fill(dr, dr + n_step * 3, 0.0f);
-    const uint32_t cnt = march_one(m, o->dt_gamma, rays_o + 3 * i, rays_d + 3 * i, fars[i], rays_t[i], n_step, xyz, dl);
+    const uint32_t cnt = march_one(m, o->dt_gamma, rays_o + 3 * i, rays_d + 3 * i, fars[i], rays_t[i], n_step, xyz, dl, (uint32_t)o->perturb, (uint64_t)i);
     for (uint32_t k = 0; k < cnt; ++k)
       for (int c = 0; c < 3; ++c) dr[3 * k + c] = rays_d[3 * i + c];
   }
@@ -1109,7 +1137,7 @@ namespace {
 int render_impl(const nrfo_model* m, const float cam[4], const float pose[16], int W, int H, const nrf_options* o, int schedule,
                 int n_threads, float* rgba, float* depth, nrf_stats* stats, uint32_t* ray_samples, uint64_t* ray_hash) {
   if (!m || !cam || !pose || !o || !rgba || !depth || W <= 0 || H <= 0) return fail(NRF_E_INVALID, "bad argument");
-  if (o->perturb) return fail(NRF_E_UNSUPPORTED, "perturb not implemented");
+  if (o->perturb < 0) return fail(NRF_E_INVALID, "perturb must be >= 0 (0: off; > 0: the random seed, render_utils.h:550)");
 #ifdef _OPENMP
   const int saved = omp_get_max_threads();
   if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -1127,6 +1155,7 @@ int render_impl(const nrfo_model* m, const float cam[4], const float pose[16], i
     ray_dir(R, cam, px, py, r.d, m->contract);
     near_far(m->d.aabb, r.o, r.d, o->min_near, &r.near, &r.far);
     for (float& v : r.st) v = 0.0f;  // zero fills nerf_render.cu:262-264
+    r.id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
     r.n_emitted = 0;
     r.hash = 0xcbf29ce484222325ull;
   };

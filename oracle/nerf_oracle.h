@@ -85,6 +85,9 @@ const char* nrfo_fp16_backend(void); /* "f16c" or "software" */
 /* one activation of the MLPs on an fp32 pre-activation (T/.../common_device.h:68-114), as mlp_one applies it -- for the known
  * answers of tcnn's ReLU-as-a-product: negative -> -0, NaN -> NaN, below -65504 (an fp16 -inf) -> NaN                        */
 float nrfo_activation(uint32_t act, float v);
+/* pcg32(initstate, initseq).next_float() (T/dependencies/pcg32/pcg32.h): the number the march's perturb branch draws per ray and
+ * call (render_utils.h:585-589)                                                                                              */
+float nrfo_pcg32_first_float(uint64_t initstate, uint64_t initseq);
 /* conversions in use vs the software definition: all 2^16 halves, every stride-th of the 2^32 floats; returns mismatches */
 uint64_t nrfo_fp16_selfcheck(uint32_t stride);
 

@@ -46,6 +46,8 @@ def lib():
     L.nrfo_f32_to_f16_soft.restype = C.c_uint16
     L.nrfo_f16_to_f32_soft.argtypes = [C.c_uint16]
     L.nrfo_f16_to_f32_soft.restype = C.c_float
+    L.nrfo_pcg32_first_float.argtypes = [C.c_uint64, C.c_uint64]
+    L.nrfo_pcg32_first_float.restype = C.c_float
     L.nrfo_activation.argtypes = [C.c_uint32, C.c_float]
     L.nrfo_activation.restype = C.c_float
     L.nrfo_fp16_backend.restype = C.c_char_p

@@ -12,6 +12,9 @@ import nerfhip as nh
 import oracle_py as op
 import synthetic as syn
 
+import ctypes as _C
+C_FLOAT_P = _C.POINTER(_C.c_float)
+
 
 @pytest.fixture(scope="module")
 def base():
@@ -160,6 +163,41 @@ def test_relu_is_tcnns_product_not_a_max():
     dirf = np.full((3, 16), 0.5, np.float16)
     out = op.Oracle(desc2).mlp_forward(feat.view(np.uint16), dirf.view(np.uint16)).view(np.float16).astype(np.float32)
     assert np.all(np.isfinite(out[0])) and np.all(np.isnan(out[1])) and np.all(np.isnan(out[2]))
+
+
+def test_perturb_branch_pcg32_and_the_shifted_march(base):
+    """The perturb branch of kernel_march_rays (R/include/nerf-cuda/render_utils.h:585-589): `pcg32 rng(n, perturb); t +=
+    MIN_STEPSIZE() * rng.next_float()` ahead of a call's loop, `last_t = t` after it.  (1) The generator
+    (T/dependencies/pcg32/pcg32.h) against ITS OWN published vector -- pcg32-demo: seed(42, 54) yields 0xa15c02b7, 0x7b47f409,
+    ... -- an answer that does not come from this repository.  (2) The shift moves every sample by the same amount when the
+    whole stretch is occupied, does not enter deltas[1], and differs per ray number and per seed."""
+    import struct
+    first = op.lib().nrfo_pcg32_first_float(42, 54)
+    want = struct.unpack("<f", struct.pack("<I", (0xa15c02b7 >> 9) | 0x3f800000))[0] - 1.0
+    assert first == want and 0.0 <= first < 1.0
+    assert op.lib().nrfo_pcg32_first_float(0, 1) != op.lib().nrfo_pcg32_first_float(1, 1) != op.lib().nrfo_pcg32_first_float(1, 2)
+    desc, keep, cfg = base
+    full = nh.ModelDesc.from_buffer_copy(desc)
+    grid = np.full(int(desc.n_density_grid), 1.0, np.float32)  # every cell occupied: the march emits a sample per step
+    full.density_grid = grid.ctypes.data_as(C_FLOAT_P)
+    o = op.Oracle(full)
+    ro = np.tile(np.array([[0.1, 0.05, -0.9]], np.float32), (3, 1))
+    rd = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (3, 1))
+    t0, far = np.full(3, 0.3, np.float32), np.full(3, 1.5, np.float32)
+    plain = o.march(ro, rd, t0, far, 4)
+    opts = nh.default_options()
+    opts.perturb = 7
+    xyz, _, dl = o.march(ro, rd, t0, far, 4, opts)
+    dt_min = np.float32(2 * 1.7320508075688772 / 1024)
+    for n in range(3):
+        shift = np.float32(dt_min * np.float32(op.lib().nrfo_pcg32_first_float(n, 7)))
+        t_first = np.float32(t0[n] + shift)
+        assert xyz[n, 0, 2] == np.float32(np.float32(-0.9) + t_first)          # z = oz + t * dz with the shifted t
+        np.testing.assert_array_equal(dl[n, :, 0], plain[2][n, :, 0])           # dt = clamp(t / 128, dt_min, dt_max) = dt_min here
+        assert dl[n, 0, 1] == np.float32(np.float32(t_first + dl[n, 0, 0]) - t_first)  # t - last_t, last_t = the SHIFTED start
+    assert len({float(xyz[n, 0, 2]) for n in range(3)}) == 3                     # a different number per ray
+    opts.perturb = 8
+    assert not np.array_equal(o.march(ro, rd, t0, far, 4, opts)[0], xyz)         # ... and per seed
 
 
 def test_param_and_grid_size_errors(base):

@@ -1171,3 +1171,73 @@ def test_relu_non_finite_hidden_activations_clamp_to_zero_deviation_d10(ctx):
     np.testing.assert_array_equal(got[1], got[2])
     np.testing.assert_array_equal(got[3], got[4])
     mlp_close(got[[0, 2, 4]].view(np.float16).astype(np.float32), wf[[0, 2, 4]], "finite samples")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(bound=4.0, cascade=3), dict(rgb_output_activation="Sigmoid", n_neurons=32)])
+def test_perturb_branch_march_bit_exact_and_frames(ctx, kw):
+    """nrf_options.perturb > 0 -- the perturb branch of kernel_march_rays (R/include/nerf-cuda/render_utils.h:585-589:
+    `pcg32 rng(n, perturb); t += MIN_STEPSIZE() * rng.next_float()`, T/dependencies/pcg32/pcg32.h), dead in the reference
+    (m_perturb = false, nerf_render.h:75) and the last statement of a SURVEY 8(a) function that was not restated.
+    (1) nrf_march against the oracle, BIT-EXACT for n_step 1 / 3 / 8 (n = the ray's place in the call), another seed = other samples;
+    (2) whole frames: the kernel applies the branch with the per-ray loop's n_step == 1 and n = the ray's pixel (what the
+    reference's first round uses; its later rounds number the rays by an atomicAdd compaction whose order changes from run to
+    run) -- against the oracle's per-ray schedule at the frame tolerance, shards + untile bit-identical to the whole frame
+    (the ray number is the GLOBAL pixel), and a batch of views identical to single renders."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=12, H=32, **kw)
+    ctx.load_model(desc)
+    o = op.Oracle(desc)
+    W, H = 48, 40
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(45, 25)
+    opts = nh.default_options()
+    opts.perturb = 5
+    ctx.set_options(opts)
+    ro, rd, nr, fr = _rays(ctx, o, W, H, cam, pose)
+    n = W * H
+    seen = {}
+    for n_step in (1, 3, 8):
+        xyzs = torch.empty((n, n_step, 3), device="cuda"); dirs = torch.empty((n, n_step, 3), device="cuda")
+        deltas = torch.empty((n, n_step, 2), device="cuda")
+        sync()
+        ctx.march(ro.data_ptr(), rd.data_ptr(), nr.data_ptr(), fr.data_ptr(), n, n_step, xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr())
+        wx, wd, wdl = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), n_step, opts)
+        np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
+        np.testing.assert_array_equal(dirs.cpu().numpy(), wd)
+        np.testing.assert_array_equal(deltas.cpu().numpy(), wdl)
+        assert (wdl[:, :, 0] > 0).sum() > 0
+        seen[n_step] = wx
+    plain = o.march(ro.cpu().numpy(), rd.cpu().numpy(), nr.cpu().numpy(), fr.cpu().numpy(), 8)[0]
+    assert not np.array_equal(plain, seen[8])
+    # (2) frames
+    rgba, depth, st, want, wdepth, wst = _render_both(ctx, o, W, H, cam, pose, opts)
+    assert np.abs(rgba - want).max() <= 2.0 / 255.0 and np.abs(depth - wdepth).max() <= 2.0 / 255.0 and models.psnr(rgba, want) >= 45.0
+    assert abs(int(st.n_composited) - int(wst.n_samples)) <= 3 + int(wst.n_samples) // 1000   # a T ~ 1e-4 tie may fall either way (v_exp_f32)
+    off = nh.default_options()
+    plain_rgba, _, _, _, _, _ = _render_both(ctx, o, W, H, cam, pose, off)
+    assert not np.array_equal(plain_rgba, rgba)  # the branch does something
+    for count in (2, 3):
+        tps = nh.tiles_per_shard(W, H, count)
+        gathered = torch.zeros((count, tps * 64, 4), device="cuda")
+        for idx in range(count):
+            so = nh.default_options(); so.perturb = 5; so.shard_index, so.shard_count = idx, count
+            ctx.set_options(so)
+            f = ctx.render(cam, pose)
+            n_px = f.n_tiles * 64
+            shard = torch.empty((n_px, 4), device="cuda")
+            sync()
+            _d2d(shard.data_ptr(), f.rgba, n_px * 16)
+            gathered[idx, :n_px] = shard
+        out = torch.empty((H, W, 4), device="cuda")
+        sync()
+        ctx.untile(gathered.data_ptr(), count, tps, 4, out.data_ptr())
+        np.testing.assert_array_equal(out.cpu().numpy(), rgba)
+    ctx.set_options(opts)
+    ctx.set_max_views(3)
+    poses = np.stack([pose, syn.orbit_pose(200, 10), pose])
+    ctx.render_views(np.stack([cam] * 3), poses)
+    np.testing.assert_array_equal(ctx.read_view_f32(0)[0], rgba)
+    np.testing.assert_array_equal(ctx.read_view_f32(2)[0], rgba)
+    bad = nh.default_options(); bad.perturb = -1
+    with pytest.raises(nh.NerfHipError, match="perturb"):
+        ctx.set_options(bad)
+    ctx.set_max_views(1)
+    ctx.set_options(nh.default_options())
