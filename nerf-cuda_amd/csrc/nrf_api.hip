@@ -974,15 +974,20 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
                                     d->sigma_activation == NRF_ACT_EXPONENTIAL;
   // ... and for its depth: 64 neurons with other numbers of hidden layers (>= 1 each, at most DEPTH_MAX_WW 64 -> 64 layers in all)
   // keep the register-resident form as the DEPTH instance -- reported as hot_width 64
-  const bool base_shape_but_depth = !generic_grid && F == 2 && L == 16 && Wn == 64 && dir_w == 16 && d->interpolation == NRF_INTERP_LINEAR &&
-                                    d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU &&
+  // ... and (round 6) for its hidden activations: any activation of tcnn's vocabulary in either MLP keeps the register-resident form in
+  // the same instance (the activation works on the fp32 accumulators, mlp_tiles_depth) -- base.json's own 1 + 2 layers included
+  const bool relu_both = d->density_activation == NRF_ACT_RELU && d->rgb_activation == NRF_ACT_RELU;
+  auto native_act = [](uint32_t a) {  // (nrf_device.h activate_native; Sine keeps the generic instance)
+    return a == NRF_ACT_RELU || a == NRF_ACT_NONE || a == NRF_ACT_EXPONENTIAL || a == NRF_ACT_SIGMOID || a == NRF_ACT_SQUAREPLUS || a == NRF_ACT_SOFTPLUS;
+  };
+  const bool base_shape_but_depth = native_act(d->density_activation) && native_act(d->rgb_activation) && !generic_grid && F == 2 && L == 16 && Wn == 64 && dir_w == 16 && d->interpolation == NRF_INTERP_LINEAR &&
                                     d->density_output_activation == NRF_ACT_NONE &&
                                     (d->rgb_output_activation == NRF_ACT_NONE || d->rgb_output_activation == NRF_ACT_SIGMOID) &&
                                     d->sigma_activation == NRF_ACT_EXPONENTIAL && d->density_hidden_layers >= 1 && d->rgb_hidden_layers >= 1 &&
-                                    !(d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2) &&
+                                    !(d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 && relu_both) &&
                                     (d->density_hidden_layers - 1) + (d->rgb_hidden_layers - 1) <= (uint32_t)DEPTH_MAX_WW;
   const bool hot_depth = base_shape_but_depth && c->allow_width_instances;
-  const uint32_t hot_width = hot_depth ? 64u : ((base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u);
+  const uint32_t hot_width = hot_depth ? (relu_both ? 64u : HOT_WIDTH_ACT) : ((base_shape_but_width && (Wn == 16 || Wn == 32 || Wn == 128) && c->allow_width_instances) ? Wn : 0u);
   // ... and for its direction encoding: SphericalHarmonics of degree 5..8 (32..64 padded values) keeps the register-resident
   // MLPs in the persistent kernel's NET_WIDE_SH form (per-ray rows of coefficients in LDS)
   const bool wide_sh = !generic_grid && F == 2 && L == 16 && Wn == 64 && d->density_hidden_layers == 1 && d->rgb_hidden_layers == 2 &&

@@ -103,6 +103,7 @@ static_assert(MlpShape<64>::D1 == FRAG_D1 && MlpShape<64>::R0 == FRAG_R0 && MlpS
 //   (8 fragments each: 2 m + s) | the rgb MLP's 64 -> 64 layers
 enum : int { DF_D0 = 0, DF_D1 = 4, DF_R0 = 6, DF_R2 = 10, DF_WW = 12, DEPTH_MAX_WW = 5, DEPTH_FRAGS = DF_WW + 8 * DEPTH_MAX_WW };
 
+constexpr uint32_t HOT_WIDTH_ACT = 65;  // DevModel::hot_width of the NET_ACT instance (64 neurons, runtime hidden activations)
 struct DevModel {
   const uint32_t* grid;      // half2 entries
   const uint32_t* occ_bits;  // 1 bit per density-grid cell: grid[cell] > min(0.01, mean_density)
@@ -150,6 +151,7 @@ struct DevModel {
   // the density-grid generation run the generic instance), but its frames are rendered by a register-resident instance of
   // the persistent kernel of that width, from fragments in the MlpShape<width> order
   uint32_t hot_width;       // 0, 16, 32 or 128 -- or 64: the DEPTH instance (64 neurons, other numbers of hidden layers: depth_xd / depth_xr)
+                            // -- or 65 (HOT_WIDTH_ACT): 64 neurons with hidden activations other than ReLU, the NET_ACT instance
   uint32_t depth_xd, depth_xr;  // hot_width == 64: 64 -> 64 layers of the density MLP (hidden layers - 1) and of the rgb MLP (hidden layers - 1)
   const uint4* wfrag_hot;   // MlpShape<hot_width>::N * 64 uint4; wide_sh: the wide layout (N_FRAGS_WIDE_ALL fragments)
   uint32_t hot_grid;        // 0, or F = 1 / 2 / 4 / 8 (F = 1: round 5): a grid other than base.json's 16 x 2 -- fewer than 16 levels at F = 2, F = 4 / 8 with up to 32
@@ -266,6 +268,24 @@ __device__ __forceinline__ float activate(uint32_t act, float v) {
     }
     case NRF_ACT_SOFTPLUS: return logf(expf(v * 10.0f) + 1.0f) / 10.0f;
     case NRF_ACT_SINE: return sinf(v);
+    default: return v;
+  }
+}
+
+// The same activations on the hardware's transcendental instructions (v_exp_f32, v_log_f32, v_rcp_f32, v_sqrt_f32: ~1 ulp of
+// fp32 each, no range reduction, no division sequence) -- for the hidden layers of the register-resident DEPTH instance
+// (mlp_tiles_depth), whose results are rounded to fp16 (11 bits) right after: the libm forms above cost that instance ~70
+// spilled registers.  Sine keeps the generic instance (v_sin_f32 loses accuracy with the argument's size).
+__device__ __forceinline__ float activate_native(uint32_t act, float v) {
+  switch (act) {
+    case NRF_ACT_RELU: return fmaxf(v, 0.0f);
+    case NRF_ACT_EXPONENTIAL: return __expf(v);
+    case NRF_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    case NRF_ACT_SQUAREPLUS: {
+      const float x = v * 10.0f;
+      return (0.5f * (x + __builtin_amdgcn_sqrtf(x * x + 4))) * 0.1f;
+    }
+    case NRF_ACT_SOFTPLUS: return __logf(__expf(v * 10.0f) + 1.0f) * 0.1f;
     default: return v;
   }
 }
@@ -1322,19 +1342,39 @@ __device__ __forceinline__ void mlp_tiles(const Frags frag, const half8_t (&feat
 // mlp_tiles for 64 neurons with a RUNTIME number of hidden layers (the DEPTH instance): xd / xr 64 -> 64 layers between the
 // first and the output layer of the density / rgb MLP (base.json: 0 / 1).  The same in-lane D -> B chaining, the same K
 // permutation in every 64-wide input (pack_fragments_depth); fragments in the DF_* order.
-template <int NT, typename Frags>
+template <int NT, typename Frags, bool ACTS = false>
 __device__ __forceinline__ void mlp_tiles_depth(const Frags frag, const half8_t (&feat)[NT], const half4_t (&dirf)[NT], MlpOut<NT>& out,
-                                                bool rgb_sigmoid, uint32_t xd, uint32_t xr) {
+                                                bool rgb_sigmoid, uint32_t xd, uint32_t xr, uint32_t act_d = NRF_ACT_RELU,
+                                                uint32_t act_r = NRF_ACT_RELU) {
   static_assert(NT == 1 || NT == 2, "tiles per pass");
   constexpr int MT = 4, KS = 2;
   const float4_t zero = {0.f, 0.f, 0.f, 0.f};
   float4_t acc[NT][MT];
   half8_t hb[NT][KS];
+  // Hidden activation of the MLP at hand (wave-uniform; round 6): ReLU on the packed halves (pack_acc); Squareplus, Softplus,
+  // Sigmoid, Exponential or None (T/include/tiny-cuda-nn/common_device.h:68-114) on the fp32 accumulators (activate_native), then
+  // the fp16 store -- the order the oracle's contract has (mlp_one: activation of the fp32 sum, rounded once).
+  uint32_t act = act_d;
   auto repack = [&]() {
+    if (!ACTS || act == NRF_ACT_RELU) {  // (ACTS = false: the NET_DEPTH instance, ReLU in both MLPs)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) hb[n][s] = pack_acc(acc[n][2 * s], acc[n][2 * s + 1]);
+        for (int s = 0; s < KS; ++s) hb[n][s] = pack_acc(acc[n][2 * s], acc[n][2 * s + 1]);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          half8_t r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r[j] = (half_t)activate_native(act, acc[n][2 * s][j]);
+            r[4 + j] = (half_t)activate_native(act, acc[n][2 * s + 1][j]);
+          }
+          hb[n][s] = r;
+        }
+    }
   };
   auto hidden = [&](int base) {  // one 64 -> 64 layer on hb, result back in hb
 #pragma unroll
@@ -1390,6 +1430,7 @@ __device__ __forceinline__ void mlp_tiles_depth(const Frags frag, const half8_t 
   if constexpr (NT >= 2) dall = __builtin_amdgcn_permlane16_swap(d01[0], d01[1], false, false)[0];
   out.sigma = (half_t)expf((float)bits_h2(dall).x);
   // ---- rgb MLP: 32 -> 64, xr x (64 -> 64), 64 -> 16
+  act = act_r;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const half8_t a = frag(DF_R0 + m);

@@ -1076,7 +1076,9 @@ int render_persistent_lds_fixed_bytes(uint32_t generic, uint32_t wide, uint32_t 
   return LDS_WFRAG_BYTES + LDS_LEVEL_BYTES + waves * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;
 }
 // ... of the 16-wave workgroup of a width instance (NET_W16 / NET_W32 / NET_W128)
-static int width_net(int width) { return width == 16 ? NET_W16 : (width == 32 ? NET_W32 : (width == 64 ? NET_DEPTH : NET_W128)); }
+static int width_net(int width) {
+  return width == 16 ? NET_W16 : (width == 32 ? NET_W32 : (width == 64 ? NET_DEPTH : (width == (int)HOT_WIDTH_ACT ? NET_ACT : NET_W128)));
+}
 int render_persistent_lds_width_bytes(int width) {
   const int net = width_net(width);
   return net_wfrag_bytes(net) + LDS_LEVEL_BYTES + persist_waves(net) * (int)sizeof(WaveLds) + LDS_QUEUE_BYTES;

@@ -9,6 +9,7 @@ hipError_t launch_persistent_width(const PersistLaunch& L) {
   if (w == 16) { if (L.unit) NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W16, MARCH_GENERIC); }
   else if (w == 32) { if (L.unit) NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W32, MARCH_GENERIC); }
   else if (w == 64) { if (L.unit) NRF_LAUNCH_PERSISTENT(NET_DEPTH, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_DEPTH, MARCH_GENERIC); }
+  else if (w == HOT_WIDTH_ACT) { if (L.unit) NRF_LAUNCH_PERSISTENT(NET_ACT, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_ACT, MARCH_GENERIC); }
   else { if (L.unit) NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_UNIT); else NRF_LAUNCH_PERSISTENT(NET_W128, MARCH_GENERIC); }
   return hipGetLastError();
 }

@@ -50,10 +50,12 @@ constexpr int LDS_WFRAG_BYTES = N_FRAGS * 64 * 16;  // 20480
 // NET_WIDE_SH: the wide form for SphericalHarmonics of degree 5..8 (32..64 direction values): the entries beyond the first sixteen
 // are computed once per ray into an LDS row (not per sample in-lane as for Frequency) -- persistent kernel only
 // NET_DEPTH: 64 neurons with other numbers of hidden layers than base.json's 1 + 2 (mlp_tiles_depth) -- persistent kernel only
+// NET_ACT (round 6): the same with hidden activations other than ReLU (Squareplus, Softplus, Sigmoid, Exponential, None: activate_native
+// on the fp32 accumulators) -- 12 waves per workgroup: the activation sequences need the registers
 // NET_GRID2 / 4 / 8: base.json's MLPs behind another grid -- F = 2 with fewer than 16 levels, F = 4 / 8 with up to 32 features in all,
 // Linear or Smoothstep (grid_features) -- persistent kernel only
 enum : int { NET_HOT = 0, NET_GENERIC = 1, NET_WIDE = 2, NET_W16 = 3, NET_W32 = 4, NET_W128 = 5, NET_WIDE_SH = 6, NET_DEPTH = 7,
-             NET_GRID2 = 8, NET_GRID4 = 9, NET_GRID8 = 10, NET_GRID1 = 11 };
+             NET_GRID2 = 8, NET_GRID4 = 9, NET_GRID8 = 10, NET_GRID1 = 11, NET_ACT = 12 };
 __host__ __device__ constexpr int net_grid_f(int net) {
   return net == NET_GRID2 ? 2 : (net == NET_GRID4 ? 4 : (net == NET_GRID8 ? 8 : (net == NET_GRID1 ? 1 : 0)));
 }
@@ -63,7 +65,7 @@ __host__ __device__ constexpr int net_width(int net) { return net == NET_W16 ? 1
 __host__ __device__ constexpr int net_wfrag_bytes(int net) {  // weight fragments a workgroup keeps in LDS
   return (net == NET_WIDE || net == NET_WIDE_SH) ? (N_FRAGS + 4 * (RK_WIDE - 1)) * 1024
        : net == NET_W16 ? MlpShape<16>::N * 1024 : net == NET_W32 ? MlpShape<32>::N * 1024 : net == NET_W128 ? MlpShape<128>::N * 1024
-       : net == NET_DEPTH ? DEPTH_FRAGS * 1024 : N_FRAGS * 1024;
+       : (net == NET_DEPTH || net == NET_ACT) ? DEPTH_FRAGS * 1024 : N_FRAGS * 1024;
 }
 constexpr int LDS_WFRAG_WIDE_BYTES = (N_FRAGS + 4 * (RK_WIDE - 1)) * 64 * 16;  // 28672: + the extra K steps of the first rgb layer
 constexpr int LDS_RAYD_BYTES = 64 * 3 * 4;  // wide instance: 0.5 d + 0.5 of every ray of a wave (fp32)
@@ -222,7 +224,7 @@ __device__ __forceinline__ void grid_features_f248(const DevModel& M, const Leve
   }
 }
 
-template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, bool DEPTH = false, int GF = 0>
+template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, int DEPTH = 0, int GF = 0>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale,
                                                  const half_t* rows = nullptr) {
@@ -299,7 +301,9 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     dirf[n] = __builtin_bit_cast(half4_t, db);
   }
   MlpOut<NT> o;
-  if constexpr (DEPTH) mlp_tiles_depth<NT>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, M.depth_xd, M.depth_xr);
+  if constexpr (DEPTH == 2) mlp_tiles_depth<NT, LdsFragsPlain, true>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, M.depth_xd,
+                                                                     M.depth_xr, M.density_activation, M.rgb_activation);
+  else if constexpr (DEPTH == 1) mlp_tiles_depth<NT>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, M.depth_xd, M.depth_xr);
   else if constexpr (WD == 64) mlp_tiles<NT, FRAG_D0, LdsFrags, RK>(LdsFrags{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID, dirx);
   else mlp_tiles<NT, 0, LdsFragsPlain, 1, WD>(LdsFragsPlain{wl, lane}, feat, dirf, o, M.rgb_output_activation == NRF_ACT_SIGMOID);
   if (g == 0) {  // decompose_network_in_and_out (render_utils.h:308-334): fp16 rows 0..2 -> fp32 rgb
@@ -385,7 +389,7 @@ __device__ __forceinline__ void network_dispatch(const DevModel& M, const uint4*
     constexpr int NTM = WD == 128 ? 1 : NT_MAX;  // 128 neurons: eight accumulator fragments per tile -- one tile per pass
     for (int base = 0; base < S; base += 16 * NTM) {  // wave-uniform
       const int ntile = (S - base + 15) >> 4;
-      constexpr bool DP = NET == NET_DEPTH;
+      constexpr int DP = NET == NET_DEPTH ? 1 : (NET == NET_ACT ? 2 : 0);  // (2: runtime hidden activations)
       constexpr int GF = net_grid_f(NET);
       if (ntile <= 1 || NTM == 1) network_from_lds<1, RK, FAST, WD, SHR, DP, GF>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
       else network_from_lds<NTM, RK, FAST, WD, SHR, DP, GF>(M, wl, lvs, W, Lw.rayd, S, base, lane, density_scale, Lw.dir);
@@ -442,7 +446,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, const DevModel& M
 // copies the instance's weight fragments into LDS (hot: 0 .. N_FRAGS - 1; wide: followed by FRAG_R0X ..)
 template <int NET>
 __device__ __forceinline__ void stage_fragments(const DevModel& M, uint4* wl) {
-  if constexpr (net_width(NET) != 64 || NET == NET_DEPTH || net_grid_f(NET) != 0) {  // (GRID: the hot layout, fragments 0 .. N_FRAGS - 1)
+  if constexpr (net_width(NET) != 64 || NET == NET_DEPTH || NET == NET_ACT || net_grid_f(NET) != 0) {  // (GRID: the hot layout, fragments 0 .. N_FRAGS - 1)
     for (int i = threadIdx.x; i < net_wfrag_bytes(NET) / 16; i += blockDim.x) wl[i] = M.wfrag_hot[i];
     return;
   }
@@ -1174,7 +1178,7 @@ __device__ __forceinline__ void encode_ray_dir(const DevModel& M, const LdsMap& 
 // the LDS rows of 12 waves fit beside the march tables, else 2.  NET_WIDE with the generic march runs 8 (WIDE_GENERIC_MARCH_WAVES:
 // at 12 it spilled 1-6 registers) -- no shipped instance has scratch (tests/test_abi_cpu.py).
 __host__ __device__ constexpr int persist_waves(int net) {
-  return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE || net == NET_W128) ? 12 : 16);
+  return net == NET_WIDE_SH ? 8 : ((net == NET_GENERIC || net == NET_WIDE || net == NET_W128 || net == NET_ACT) ? 12 : 16);
 }
 // (WIDE_GENERIC_MARCH_WAVES: nrf_launch.h -- the host sizes the workgroup with it as well)
 constexpr int LDS_CLOCK_BYTES = 16;  // wave 0's entry stamps (core-clock counter, 100 MHz counter), see shader_clock_mhz

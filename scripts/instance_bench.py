@@ -35,6 +35,11 @@ SHAPES = [
     ("hidden layers 2 + 2 (depth instance when persistent)", dict(density_hidden_layers=2, rgb_hidden_layers=2)),
     ("hidden layers 1 + 1 (depth instance)", dict(density_hidden_layers=1, rgb_hidden_layers=1)),
     ("hidden layers 3 + 4 (depth instance)", dict(density_hidden_layers=3, rgb_hidden_layers=4)),
+    ("Squareplus hidden activations (NET_ACT instance, round 6)", dict(activation="Squareplus")),
+    ("Softplus hidden activations (NET_ACT instance, round 6)", dict(activation="Softplus")),
+    ("Sigmoid hidden activations (NET_ACT instance, round 6)", dict(activation="Sigmoid")),
+    ("Squareplus hidden activations, NRF_WIDTH_INSTANCES=0 (generic)", dict(activation="Squareplus", _env={"NRF_WIDTH_INSTANCES": "0"})),
+    ("Sigmoid hidden activations, NRF_WIDTH_INSTANCES=0 (generic)", dict(activation="Sigmoid", _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("hidden layers 2 + 2, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=2, rgb_hidden_layers=2, _env={"NRF_WIDTH_INSTANCES": "0"})),
     ("hidden layers 3 + 4, NRF_WIDTH_INSTANCES=0 (generic)", dict(density_hidden_layers=3, rgb_hidden_layers=4, _env={"NRF_WIDTH_INSTANCES": "0"})),
 ]
