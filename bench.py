@@ -325,7 +325,7 @@ def main():
     W = args.width or (CONFIG5_RES if replica else WIDTH)
     H = args.height or (CONFIG5_RES if replica else HEIGHT)
 
-    # identical seeded model on every rank (replicated, 24.4 MB table + 256 KB occupancy bits).
+    # identical seeded model on every rank (replicated: 24.4 MB table + its 4.6 GB of cell-major gather copies + 256 KB occupancy bits).
     # `depth` steps are in flight: one context + stream + output buffers per slot, so the tail of one
     # batch (a few long-lived tiles) overlaps the head of the next.
     desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
@@ -620,17 +620,20 @@ def main():
         "roofline": {
             "kernel": "render_persistent_kernel",
             # the contract's figure: ALGORITHMIC gather bytes / kernel time against the HBM peak.  The table
-            # (24 MB) is served from L2 / Infinity Cache, so this is a cache-gather rate: see hbm_gbs_measured and limiter
+            # is served mostly from L2 / Infinity Cache (the 24 MB reference-order part and the copies of the coarse levels; the 4.5 GB of
+            # copies of levels 8..11 come from HBM), so this is a cache-gather rate: see hbm_gbs_measured and limiter
             "bound": "hbm",
             "bound_note": "the contract's figure: ALGORITHMIC gather bytes (512 B per composited sample) over the launch time, against the HBM "
-                          "peak; the table is served from L2 / Infinity Cache (hbm_gbs_measured), what binds the kernel is in `limiter`",
+                          "peak; most of it is served from L2 / Infinity Cache (hbm_gbs_measured), what binds the kernel is in `limiter`",
             "binding_unit": ((pmc.get("limiter") or {}).get("binding_unit") if pmc else None),
             "achieved": round(gather_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(gather_gbs / HBM_PEAK_GBS, 5),
-            # The bound that does bind (no PMC needed): gather lane-addresses per second over what 256 texture addressers take
-            # at the measured clock.  `frac` above can exceed what HBM could deliver -- 0.99 for config 4, 1.2 for an F = 8 grid
+            # Gather lane-addresses per second over what 256 texture addressers take at the measured clock (no PMC needed): the bound
+            # that bound the kernel through round 5 (0.76 with 128 addresses per sample); the cell-major quad copies of round 6 read a
+            # level as two 16-byte entries instead of eight 4-byte ones (56 addresses per sample), and what limits the kernel now is
+            # the VALU issue port and the overlap of memory latency (`binding_unit`).  `frac` above can exceed what HBM could deliver -- 0.99 for config 4, 1.2 for an F = 8 grid
             # (`configs`) -- because the table is served from L2 / Infinity Cache and an aligned 8- or 16-byte entry costs one
             # address like a 4-byte one: bytes per address change, addresses per second do not.
             "gather_addr_frac": round(addr_per_s / ta_peak, 5) if ta_peak else None,

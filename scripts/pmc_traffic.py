@@ -154,7 +154,10 @@ doc = {
         "valu_issue_counter": "SQ_INSTS_VALU_* classes x measured issue cost / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
         "valu_issue_cycles_per_launch": cycles,
         "simd_cycles_per_launch": simd_cycles,
-        "binding_unit": "VALU issue port and texture-address (gather) path, co-limiting",
+        "binding_unit": ("VALU issue port and texture-address (gather) path, co-limiting" if min(ta_busy, cycles / max(simd_cycles, 1)) >= 0.78 else
+                         f"VALU issue port ({cycles / max(simd_cycles, 1):.2f} of the SIMD cycles by instruction class x issue cost), the texture-address path "
+                         f"behind it ({ta_busy:.2f}); waves spend {g('SQ_WAIT_ANY') / wave_cycles:.2f} of their time parked on s_waitcnt: what is left is overlap "
+                         "(memory latency against four waves per SIMD), not a saturated unit"),
         # the in-situ check of that attribution (round 3): instructions of a KNOWN count added to / taken from the two big phases
         "marginal_cost_in_situ": marginal,
         "marginal_cost_reading": (None if not marginal else
@@ -169,8 +172,9 @@ doc = {
         "note": "The VALU has a 2.25-cycle class (fp32 add / mul / fma, v_add_u32, and / xor / bitop3, mov) and a 4.1-cycle class (min / max / "
                 "med3, conversions, shifts, v_mul_lo_u32, packed fp16, v_fma_mix); transcendentals 8; an MFMA holds the issue port for 8 "
                 "(scripts/issue_rate/issue_rate.hip, profiles/r02/issue_rate.txt: 34 opcodes; the int32 and remainder counter classes are "
-                "priced at the average of their opcodes in the kernel's listing, 3.0 and 3.2).  The texture addresser: every 64-lane gather of "
-                "4-byte table entries occupies it for ~17 cycles (4 addresses per clock), 128 such gathers per 16 samples.  "
+                "priced at the average of their opcodes in the kernel's listing, 3.0 and 3.2).  The texture addresser: a 64-lane gather of "
+                "4-byte table entries occupies it for ~17 cycles (4 addresses per clock), one of 16-byte quads (round 6: levels read from their "
+                "cell-major copies, two per level instead of eight) for ~32 -- ta_cycles_per_gather_instruction is the launch's mix.  "
                 f"HBM is not the limiter: hbm_bytes_per_launch / kernel time is {(g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / (statistics.mean(agg[grid]['_ms']) * 1e-3) / 1e12:.1f} TB/s "
                 "(the table lives in L2 / Infinity Cache).",
     },
