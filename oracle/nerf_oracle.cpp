@@ -189,10 +189,10 @@ inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
 // value gives -0, NaN stays NaN and -inf -- an fp16 accumulator below -65504 -- becomes NaN (-inf * 0); max(x, 0) would give +0
 // for all three.  v is rounded to fp16 first (the reference's accumulator IS an fp16 value); the product of an fp16 value with
 // 0 or 1 is exact.  The HIP path clamps with v_pk_max_f16 instead: DESIGN.md deviation D-10, tests/test_parity_gpu.py.
-inline float relu_half(float v) {
-  const float h = h2f(f2h(v));
-  return h * (h > 0.0f ? 1.0f : 0.0f);
+inline float relu_of_half(float h) {  // h: an fp16 value held in a float
+  return h > 0.0f ? h : h * 0.0f;  // == h * (half)(h > 0): negative -> -0, NaN and -inf -> NaN
 }
+inline float relu_half(float v) { return relu_of_half(h2f(f2h(v))); }
 inline float activate(uint32_t act, float v) {
   switch (act) {
     case NRF_ACT_RELU: return relu_half(v);
@@ -721,7 +721,19 @@ void mlp_one(const std::vector<std::vector<float>>& w, const std::vector<uint32_
           acc = h2f(f2h(part));
         }
       }
-      dst[o] = h2f(f2h(activate(last ? out_act : act, acc)));
+      const uint32_t a = last ? out_act : act;
+      if (a == NRF_ACT_RELU) {  // relu_half with ONE conversion pair: its result is an fp16 value already (h, +-0 or NaN)
+        // relu_half's value up to the sign of a zero: negative -> +0 here, -0 there.  No later value can tell -- every consumer of
+        // a hidden activation is a dot product whose running sum starts at +0, and +0 + (-0) = +0 --, while NaN and -inf -> NaN
+        // (the observable part of tcnn's product form) are kept.  The product form costs the whole MLP 35 % on the CPU (the sign
+        // of a pre-activation is a coin toss), and bench.py times this loop as the CPU baseline.
+        const float h = h2f(f2h(acc));
+        float r = h > 0.0f ? h : 0.0f;
+        if (!(h >= -FLT_MAX)) r = h * 0.0f;  // NaN, -inf: NaN
+        dst[o] = r;
+      } else {
+        dst[o] = h2f(f2h(activate(a, acc)));
+      }
     }
     cur = dst;
     nxt = (dst == buf0) ? buf1 : buf0;
