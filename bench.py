@@ -81,7 +81,7 @@ GATHER_ADDR_PER_SAMPLE = 16 * 8    # hot instance: 16 levels x 8 corners, one la
 DEFAULT_VIEWS = 16                 # camera views per step (one launch)
 DEFAULT_DEPTH = 1                  # steps in flight at N = 1 (N > 1: 2, so that the gather of one step overlaps the next)
 CONFIG5_REQUESTS, CONFIG5_RES = 64, 800  # BASELINE.json configs[4]
-PMC_FILE = ROOT / "profiles" / "r05" / "pmc_traffic.json"
+PMC_FILE = ROOT / "profiles" / "r06" / "pmc_traffic.json"
 
 
 def kernel_source_sha16() -> str:
