@@ -224,6 +224,36 @@ __device__ __forceinline__ void grid_features_f248(const DevModel& M, const Leve
   }
 }
 
+// One step (levels 4 jl .. 4 jl + 3, this lane's: 4 jl + g) of a sample's grid gathers, in the form nrf_load_model chose for the step
+template <int RK, bool SHROWS>
+__device__ __forceinline__ void gather_step(const DevModel& M, const LevelParams* lvs, int jl, int g, float px, float py, float pz,
+                                            uint32_t (&v)[8], float (&fr)[3]) {
+  const LevelParams L = lvs[4 * jl + g];
+  const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
+  if ((M.quad_mask >> (4 * jl)) & 1u) {  // wave-uniform: the step's four levels are gathered from their cell-major quad copies
+    // (NET_WIDE -- Frequency directions evaluated per sample in-lane -- has no registers left for the far form's 64-bit
+    // addresses: nrf_load_model grants a wide model no far copies)
+    constexpr bool FARQ = !(RK > 1 && !SHROWS);
+    if (FARQ && ((M.quad_far >> jl) & 1u)) level_gather_quad_far(M.grid, L, px, py, pz, v, fr);
+    else level_gather_quad(M.grid, M.grid_bytes, L, px, py, pz, v, fr);
+  }
+  else if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, v, fr);
+  else if (uni == 1u) level_gather<1>(M.grid, M.grid_bytes, L, px, py, pz, v, fr);
+  else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, v, fr);
+}
+__device__ __forceinline__ void sample_pos01(const DevModel& M, const float4 p, float& px, float& py, float& pz) {
+  // xyz -> [0,1]: linear_transformer(1/(2 bound), 0.5), R/src/nerf_render.cu:311-312
+  if (M.pos_w_pow2) {  // wave-uniform: the product cannot round, so the fma equals multiply-then-add
+    px = __builtin_fmaf(M.pos_w, p.x, 0.5f);
+    py = __builtin_fmaf(M.pos_w, p.y, 0.5f);
+    pz = __builtin_fmaf(M.pos_w, p.z, 0.5f);
+  } else {
+    px = M.pos_w * p.x; px = px + 0.5f;
+    py = M.pos_w * p.y; py = py + 0.5f;
+    pz = M.pos_w * p.z; pz = pz + 0.5f;
+  }
+}
+
 template <int NT, int RK = 1, bool FAST = false, int WD = 64, bool SHROWS = false, int DEPTH = 0, int GF = 0>
 __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4* wl, const LevelParams* lvs, WaveLds* W,
                                                  const float* rayd, int S, int base, int lane, float density_scale,
@@ -239,17 +269,8 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
     uint2 db = make_uint2(0u, 0u);
     if (slot < S) {
       const float4 p = W->pos[slot];
-      // xyz -> [0,1]: linear_transformer(1/(2 bound), 0.5), R/src/nerf_render.cu:311-312
       float px, py, pz;
-      if (M.pos_w_pow2) {  // wave-uniform: the product cannot round, so the fma equals multiply-then-add
-        px = __builtin_fmaf(M.pos_w, p.x, 0.5f);
-        py = __builtin_fmaf(M.pos_w, p.y, 0.5f);
-        pz = __builtin_fmaf(M.pos_w, p.z, 0.5f);
-      } else {
-        px = M.pos_w * p.x; px = px + 0.5f;
-        py = M.pos_w * p.y; py = py + 0.5f;
-        pz = M.pos_w * p.z; pz = pz + 0.5f;
-      }
+      sample_pos01(M, p, px, py, pz);
       // lane group g encodes levels {g, 4+g, 8+g, 12+g}: for each unrolled step jl the four groups work
       // on four ADJACENT levels, which for the usual tables are all dense (jl = 0) or all hashed
       // (jl >= 2), so the index arithmetic is specialised per step by a wave-uniform branch.
@@ -260,20 +281,7 @@ __device__ __forceinline__ void network_from_lds(const DevModel& M, const uint4*
       uint32_t gv[4][8];
       float gf[4][3];
 #pragma unroll
-      for (int jl = 0; jl < 4; ++jl) {
-        const LevelParams L = lvs[4 * jl + g];
-        const uint32_t uni = (M.uni_modes >> (2 * jl)) & 3u;
-        if ((M.quad_mask >> (4 * jl)) & 1u) {  // wave-uniform: the step's four levels are gathered from their cell-major quad copies
-          // (NET_WIDE -- Frequency directions evaluated per sample in-lane -- has no registers left for the far form's 64-bit
-          // addresses: nrf_load_model grants a wide model no far copies)
-          constexpr bool FARQ = !(RK > 1 && !SHROWS);
-          if (FARQ && ((M.quad_far >> jl) & 1u)) level_gather_quad_far(M.grid, L, px, py, pz, gv[jl], gf[jl]);
-          else level_gather_quad(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        }
-        else if (uni == 2u) level_gather<2>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else if (uni == 1u) level_gather<1>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-        else level_gather<0>(M.grid, M.grid_bytes, L, px, py, pz, gv[jl], gf[jl]);
-      }
+      for (int jl = 0; jl < 4; ++jl) gather_step<RK, SHROWS>(M, lvs, jl, g, px, py, pz, gv[jl], gf[jl]);
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) fb[jl] = level_interp<FAST>(gv[jl], gf[jl]);
       }
