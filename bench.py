@@ -645,6 +645,9 @@ def main():
             "gather_addr_peak": round(ta_peak / 1e9, 2) if ta_peak else None,
             "gather_addr_peak_is": f"{TA_UNITS} texture addressers x {TA_ADDR_PER_CLK:g} lane addresses per clock x the measured clock",
             "shader_clock_mhz_measured": round(clock_hz / 1e6, 1) if clock_hz else None,
+            # boxes of one pool run the same launch at different sustained clocks (2.02-2.25 GHz seen in round 6) and `value` follows:
+            # the clock-normalised figure is what compares across boxes and rounds
+            "msamples_s_per_ghz": round(msamples_s / (clock_hz / 1e9), 1) if clock_hz else None,
             "traffic": traffic,
             "from_committed_profile": bool(pmc),
             "traffic_source": (f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc passes of this command, kernel sources "
