@@ -124,8 +124,8 @@ typedef struct nrf_model_desc {
    * none -- nrf_generate_density_grid evaluates one from the network before the first render              */
   const float* density_grid;
   uint64_t n_density_grid;
-  /* (ABI 6) Device memory the library may spend on GATHER COPIES of the hash grid, in MB; 0 = the default: 8192, but no more
-   * than a sixteenth of the device's memory; 1 = none.  For the base.json grid shape (L = 16, F = 2, Linear) the render kernel
+  /* (ABI 6) Device memory the library may spend on GATHER COPIES of the hash grid, in MB; 0 = the default: a sixteenth of the
+   * device's memory (MI355X: 18 GB), at most half of what is free; 1 = none.  For the base.json grid shape (L = 16, F = 2, Linear) the render kernel
    * reads a level's eight trilinear corners as two aligned 16-byte "quads" from a cell-major copy of the level (every entry
    * copied, on the device, from the index grid.h:100-117 names: the same bits) instead of eight 4-byte table entries -- a
    * quarter of the gather addresses.  Copies are made four levels at a time, in level order, while they fit: levels 0..7 of

@@ -370,7 +370,8 @@ constexpr int CALL_RING = 16;  // render calls of one context that may be in fli
 constexpr size_t CALL_SLOT_BYTES = COUNTER_BYTES + 128 + 65536;  // statistics | work queues | the diagnostic build's per-wave stamps
 constexpr int HOST_SLOTS = 2;
 // Cell-major quad copies of grid levels (nrf_load_model; nrf_device.h level_gather_quad): which levels get one by default.
-constexpr uint32_t QUAD_BUDGET_MB_DEFAULT = 8192;  // base.json's grid: levels 0..7 take 95 MB, levels 8..11 4.5 GB; levels 12..15 (216 GB) are never worth it
+constexpr uint32_t QUAD_BUDGET_MB_DEFAULT = 8192;  // base.json's grid: levels 0..7 take 95 MB, levels 8..11 4.5 GB (levels 12..15: 216 GB, never copied);
+                                                   // an instant-ngp grid at aabb_scale 32: levels 0..3 2.4 MB, levels 4..7 9.2 GB
 inline char* call_slot(const nrf_context* c, int index) { return (char*)c->d_counters + (size_t)(index % CALL_RING) * CALL_SLOT_BYTES; }
 
 void free_host_slots(nrf_context* c) {
@@ -1071,10 +1072,10 @@ int nrf_load_model(nrf_context* c, const nrf_model_desc* d) {
   const bool quad_shape = !generic_grid && F == 2 && L == 16 && d->interpolation == NRF_INTERP_LINEAR && !hot_grid &&
                           (!generic || hot_width || wide_sh);
   if (quad_shape) {
-    uint64_t budget_mb = QUAD_BUDGET_MB_DEFAULT;  // ... but no more than a sixteenth of the device's memory
+    uint64_t budget_mb = QUAD_BUDGET_MB_DEFAULT;  // (when the device does not say how much memory it has)
     {
-      size_t mem_free = 0, mem_total = 0;
-      if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) budget_mb = std::min<uint64_t>(budget_mb, (uint64_t)mem_total >> 24);
+      size_t mem_free = 0, mem_total = 0;  // default: a sixteenth of the device's memory (MI355X: 18 GB), and no more than half of what is free
+      if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) budget_mb = std::min<uint64_t>((uint64_t)mem_total >> 24, (uint64_t)mem_free >> 21);
       else (void)hipGetLastError();
     }
     if (d->gather_copy_budget_mb) budget_mb = d->gather_copy_budget_mb;
