@@ -1241,3 +1241,29 @@ def test_perturb_branch_march_bit_exact_and_frames(ctx, kw):
         ctx.set_options(bad)
     ctx.set_max_views(1)
     ctx.set_options(nh.default_options())
+
+
+def test_quad_gather_copies_full_size_frame_identical():
+    """BASELINE config 2 at its own size: the 1920x1080 frame of the bench scene with no gather copies (the reference's table
+    alone, 128 lane addresses per sample) and with the default budget (levels 0-11 from their cell-major quad copies, 56) --
+    float planes and sample counts bit for bit (size-independent property of test_quad_gather_copies_change_no_bit)."""
+    desc, keep, cfg = models.build_model(log2_hashmap_size=19, H=128)
+    W, H = 1920, 1080
+    cam, pose = syn.default_camera(W, H), syn.orbit_pose(45, 30)
+    got = {}
+    for budget in (1, 0):
+        d = nh.ModelDesc.from_buffer_copy(desc)
+        d.gather_copy_budget_mb = budget
+        h = nh.NerfHip(0)
+        try:
+            h.load_model(d)
+            h.set_resolution(W, H)
+            h.render(cam, pose)
+            rgba, depth = h.read_f32()
+            st = h.stats()
+            got[budget] = (rgba, depth, int(st.n_composited), int(st.gather_addresses_per_sample))
+        finally:
+            h.close()
+    assert got[1][3] == 128 and got[0][3] == 56 and got[0][2] == got[1][2] > 5_000_000
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
