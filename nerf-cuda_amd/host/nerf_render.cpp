@@ -126,6 +126,7 @@ void NerfRender::load_snapshot(const std::string& filepath_string) {
   nrf_model_desc& d = m_desc;
   d = nrf_model_desc{};
   d.abi_version = NRF_ABI_VERSION;
+  d.gather_copy_budget_mb = m_gather_copy_budget_mb;
   m_ngp_per_level_scale = 0.0f;
   m_ngp_rgb_sigmoid = false;
   // instant-ngp's own snapshot layout (the reference reads only its array form): see load_ngp_snapshot

@@ -81,6 +81,9 @@ class NerfRender {
   void load_snapshot(const std::string& filepath_string);
 
   // additions (the reference has no accessors)
+  // Device memory a model may spend on gather copies of its hash grid (nrf_model_desc.gather_copy_budget_mb: 0 = the library's
+  // default, a sixteenth of the device's memory; 1 = none); takes effect at the next load_snapshot / reload_network_from_file
+  void set_gather_copy_budget_mb(uint32_t mb) { m_gather_copy_budget_mb = mb; }
   int n_gpus() const { return (int)m_ctx.size(); }
   const nrf_model_desc& model_desc() const { return m_desc; }
   nrf_stats last_stats(int gpu = 0) const;
@@ -97,6 +100,7 @@ class NerfRender {
   mpk::Value m_network_config;
   std::string m_network_config_path;
   nrf_model_desc m_desc{};
+  uint32_t m_gather_copy_budget_mb = 0;
   bool m_have_snapshot = false, m_have_network = false;
   std::vector<float> m_params, m_density_grid;
   Vector2i resolution;

@@ -891,6 +891,7 @@ class NerfRender:
 
     def reset_network(self):  # nerf_render.cu:111-184
         self.desc, self._keep = desc_from_config(self.network_config)
+        self.desc.gather_copy_budget_mb = int(getattr(self, "gather_copy_budget_mb", 0))  # 0: the library's default; 1: no gather copies
 
     def reload_network_from_file(self, path):  # nerf_render.cu:93-109
         self.load_snapshot(path)
